@@ -1,0 +1,231 @@
+"""CPU oracle for the stabilisation / undistort hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product (video-annotator_amd/) never does; it fails loudly when its HIP library is missing.
+
+Pixel / feature arithmetic: oracle/vstab_oracle.c (plain C, loaded with ctypes).
+Host geometry (cameras, point undistortion, Savitzky-Golay rotation filter, look-ahead state
+machine): numpy restatements below, each citing the reference file:line it follows
+(paths relative to /root/reference/opencv/).
+
+Parity pinning: see the header of vstab_oracle.c.  The reference holds no tests or golden
+vectors; only createMap.cl can be executed (oracle/_ref).  Everything that
+restates OpenCV / gram_savitzky_golay arithmetic is "parity unpinned".
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+
+def build(force=False):
+    """Compile the C restatement (and oracle/_ref when /root/reference exists)."""
+    so = os.path.join(_HERE, "_build", "libvstab_oracle.so")
+    src = os.path.join(_HERE, "vstab_oracle.c")
+    need = force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)
+    ref_so = os.path.join(_HERE, "_ref", "libcreatemap_ref.so")
+    if os.path.exists("/root/reference/opencv/createMap.cl") and not os.path.exists(ref_so):
+        need = True
+    if need:
+        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = build()
+        L = ctypes.CDLL(so)
+        c = ctypes
+        u8p, f32p, i16p = c.POINTER(c.c_uint8), c.POINTER(c.c_float), c.POINTER(c.c_int16)
+        L.vo_num_threads.restype = c.c_int
+        L.vo_set_num_threads.argtypes = [c.c_int]
+        L.vo_pack_nv12.argtypes = [u8p, c.c_size_t, u8p, c.c_size_t, c.c_int, c.c_int, u8p]
+        L.vo_pack_nv12.restype = c.c_int
+        L.vo_cvt_nv12_bgr.argtypes = [u8p, c.c_int, c.c_int, u8p]
+        L.vo_atanf.argtypes = [c.c_float]
+        L.vo_atanf.restype = c.c_float
+        L.vo_atanf_array.argtypes = [f32p, f32p, c.c_long]
+        L.vo_atanf_max_ulp.argtypes = [c.c_uint32, c.c_uint32, c.c_uint32]
+        L.vo_atanf_max_ulp.restype = c.c_double
+        L.vo_create_map.argtypes = [f32p, f32p, c.c_int, c.c_int, f32p]
+        L.vo_remap_bilinear.argtypes = [u8p, c.c_int, c.c_int, c.c_int, f32p, f32p, u8p, c.c_int, c.c_int]
+        L.vo_warp_nv12_reference_path.argtypes = [u8p, c.c_int, c.c_int, f32p, u8p, c.c_int, c.c_int, u8p]
+        L.vo_min_eig.argtypes = [u8p, c.c_size_t, c.c_int, c.c_int, f32p]
+        L.vo_good_features.argtypes = [u8p, c.c_size_t, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, f32p, f32p]
+        L.vo_good_features.restype = c.c_int
+        L.vo_pyr_down.argtypes = [u8p, c.c_size_t, c.c_int, c.c_int, u8p, c.c_size_t]
+        L.vo_scharr.argtypes = [u8p, c.c_size_t, c.c_int, c.c_int, i16p]
+        L.vo_pyramid_levels.argtypes = [c.c_int, c.c_int]
+        L.vo_pyramid_levels.restype = c.c_int
+        L.vo_pyr_lk.argtypes = [u8p, c.c_size_t, u8p, c.c_size_t, c.c_int, c.c_int, f32p, c.c_int, f32p, u8p]
+        L.vo_pyr_lk.restype = c.c_int
+        _LIB = L
+    return _LIB
+
+
+def ref_lib():
+    """The reference's own createMap.cl compiled for x86-64 (None if not built)."""
+    global _REF
+    if _REF is None:
+        so = os.path.join(_HERE, "_ref", "libcreatemap_ref.so")
+        if not os.path.exists(so):
+            try:
+                build()
+            except Exception:
+                pass
+        if not os.path.exists(so):
+            return None
+        R = ctypes.CDLL(so)
+        f32p = ctypes.POINTER(ctypes.c_float)
+        R.createmap_ref_run.argtypes = [f32p, f32p, ctypes.c_int, ctypes.c_int, f32p]
+        _REF = R
+    return _REF
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, _p(a, ctypes.c_uint8)
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, _p(a, ctypes.c_float)
+
+
+# ---------------------------------------------------------------------------------------------
+# pixel / feature steps (C)
+# ---------------------------------------------------------------------------------------------
+def pack_nv12(y, uv):
+    """FrameSourceFfmpegOpenCl.cpp:58-85.  y: (h, pitch_y) u8, uv: (h/2, pitch_uv) u8 views."""
+    h, w = y.shape
+    yy, yp = _u8(y)
+    uu, up = _u8(uv)
+    dst = np.empty((h * 3 // 2, w), np.uint8)
+    rc = lib().vo_pack_nv12(yp, yy.strides[0], up, uu.strides[0], w, h, _p(dst, ctypes.c_uint8))
+    if rc:
+        raise ValueError("Mismatched image dimensions")
+    return dst
+
+
+def cvt_nv12_bgr(nv12):
+    """FrameSourceWarp.cpp:401.  nv12: (h*3/2, w) u8 -> (h, w, 3) u8 BGR."""
+    rows, w = nv12.shape
+    h = rows * 2 // 3
+    a, ap = _u8(nv12)
+    out = np.empty((h, w, 3), np.uint8)
+    lib().vo_cvt_nv12_bgr(ap, w, h, _p(out, ctypes.c_uint8))
+    return out
+
+
+def atanf(x):
+    x, xp = _f32(x)
+    y = np.empty_like(x)
+    lib().vo_atanf_array(xp, _p(y, ctypes.c_float), x.size)
+    return y
+
+
+def create_map(params, cols, rows):
+    """createMap.cl:1-51 restated.  params: 17 floats in kernel-argument order."""
+    p, pp = _f32(params)
+    mx = np.empty((rows, cols), np.float32)
+    my = np.empty((rows, cols), np.float32)
+    lib().vo_create_map(_p(mx, ctypes.c_float), _p(my, ctypes.c_float), cols, rows, pp)
+    return mx, my
+
+
+def create_map_ref(params, cols, rows):
+    """The reference's own createMap.cl (oracle/_ref build)."""
+    R = ref_lib()
+    if R is None:
+        raise RuntimeError("oracle/_ref not built")
+    p, pp = _f32(params)
+    mx = np.zeros((rows, cols), np.float32)
+    my = np.zeros((rows, cols), np.float32)
+    R.createmap_ref_run(_p(mx, ctypes.c_float), _p(my, ctypes.c_float), cols, rows, pp)
+    return mx, my
+
+
+def remap_bilinear(src, mapx, mapy):
+    """FrameSourceWarp.cpp:306-312.  src: (h, w, cn) or (h, w) u8."""
+    s, sp = _u8(src)
+    cn = 1 if s.ndim == 2 else s.shape[2]
+    mx, mxp = _f32(mapx)
+    my, myp = _f32(mapy)
+    dh, dw = mx.shape
+    out = np.empty((dh, dw, cn), np.uint8)
+    lib().vo_remap_bilinear(sp, s.shape[1], s.shape[0], cn, mxp, myp, _p(out, ctypes.c_uint8), dw, dh)
+    return out[:, :, 0] if s.ndim == 2 else out
+
+
+def warp_nv12(nv12, params, dw, dh):
+    """cvtColor + createMap + remap exactly as FrameSourceWarp.cpp:401,272-314 chains them."""
+    rows, w = nv12.shape
+    h = rows * 2 // 3
+    a, ap = _u8(nv12)
+    p, pp = _f32(params)
+    out = np.empty((dh, dw, 3), np.uint8)
+    work = np.empty(w * h * 3 + 16 + 2 * dw * dh * 4, np.uint8)
+    lib().vo_warp_nv12_reference_path(ap, w, h, pp, _p(out, ctypes.c_uint8), dw, dh, _p(work, ctypes.c_uint8))
+    return out
+
+
+def min_eig(gray):
+    g, gp = _u8(gray)
+    h, w = g.shape
+    e = np.empty((h, w), np.float32)
+    lib().vo_min_eig(gp, g.strides[0], w, h, _p(e, ctypes.c_float))
+    return e
+
+
+def good_features(gray, max_corners=200, quality=0.01, min_distance=30.0, return_eig=False):
+    """find_corners, FrameSourceWarp.cpp:228-240."""
+    g, gp = _u8(gray)
+    h, w = g.shape
+    cap = max_corners if max_corners > 0 else w * h
+    xy = np.zeros((cap, 2), np.float32)
+    eig = np.empty((h, w), np.float32) if return_eig else None
+    n = lib().vo_good_features(gp, g.strides[0], w, h, max_corners, quality, min_distance,
+                               _p(xy, ctypes.c_float), _p(eig, ctypes.c_float) if return_eig else None)
+    return (xy[:n].copy(), eig) if return_eig else xy[:n].copy()
+
+
+def pyr_down(img):
+    s, sp = _u8(img)
+    h, w = s.shape
+    d = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    lib().vo_pyr_down(sp, s.strides[0], w, h, _p(d, ctypes.c_uint8), d.strides[0])
+    return d
+
+
+def scharr(img):
+    s, sp = _u8(img)
+    h, w = s.shape
+    d = np.empty((h, w, 2), np.int16)
+    lib().vo_scharr(sp, s.strides[0], w, h, _p(d, ctypes.c_int16))
+    return d
+
+
+def pyr_lk(prev, nxt, pts):
+    """find_point_pairs_with_optical_flow's calcOpticalFlowPyrLK, FrameSourceWarp.cpp:252."""
+    a, ap = _u8(prev)
+    b, bp = _u8(nxt)
+    h, w = a.shape
+    p, pp = _f32(np.asarray(pts, np.float32).reshape(-1, 2))
+    n = p.shape[0]
+    out = np.zeros((n, 2), np.float32)
+    st = np.zeros(n, np.uint8)
+    lib().vo_pyr_lk(ap, a.strides[0], bp, b.strides[0], w, h, pp, n, _p(out, ctypes.c_float), _p(st, ctypes.c_uint8))
+    return out, st
+
+
+from .geometry import *  # noqa: E402,F401,F403

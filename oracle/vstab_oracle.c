@@ -1,0 +1,591 @@
+/*
+ * vstab_oracle.c -- CPU restatement of the reference hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This file is the parity oracle for the HIP implementation in video-annotator_amd/csrc/.
+ * It is NOT part of the product: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  The product library never links or calls it.
+ *
+ * Each function restates one step of the reference pipeline
+ * (/root/reference/opencv/FrameSourceWarp.cpp, createMap.cl, FrameSourceFfmpegOpenCl.cpp).
+ * Where the arithmetic lives in a third-party dependency that is absent from the reference
+ * tree (OpenCV >= 4.5, meson.build:33; gram_savitzky_golay, meson.build:37) the published
+ * algorithm of that dependency is restated and the function says so.
+ *
+ * PARITY PINNING
+ *   - vo_create_map is pinned against the reference's own createMap.cl compiled for x86-64
+ *     (oracle/_ref, see oracle/Makefile) -- identical except for the atan implementation
+ *     (see vo_atanf) -- and against golden vectors generated from that build (tests/golden).
+ *   - every OpenCV-derived function below is "parity unpinned": the reference holds no tests,
+ *     fixtures or golden vectors and OpenCV is not installed in the build image.
+ *
+ * Floating point: compile with -ffp-contract=off and without -ffast-math.  Every fused
+ * multiply-add below is an explicit fmaf(); every other operation is a single IEEE-754
+ * binary32 operation, so the HIP kernels can reproduce the results bit for bit.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include <float.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define VO_API __attribute__((visibility("default")))
+
+VO_API int vo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+VO_API void vo_set_num_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a1: NV12 plane packing.  FrameSourceFfmpegOpenCl.cpp:58-85 -- two image->buffer copies:
+ * luma (w x h bytes) at offset 0, chroma (w/2 x h/2 two-byte texels) at offset w*h.
+ * ------------------------------------------------------------------------------------------ */
+VO_API int vo_pack_nv12(const uint8_t *y, size_t pitch_y, const uint8_t *uv, size_t pitch_uv,
+                        int w, int h, uint8_t *dst) {
+    if ((w & 1) || (h & 1) || w <= 0 || h <= 0) return 1; /* "Mismatched image dimensions", :53 */
+    for (int r = 0; r < h; r++) memcpy(dst + (size_t)r * w, y + (size_t)r * pitch_y, (size_t)w);
+    uint8_t *d = dst + (size_t)w * h;
+    for (int r = 0; r < h / 2; r++) memcpy(d + (size_t)r * w, uv + (size_t)r * pitch_uv, (size_t)w);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a2: cvtColor(COLOR_YUV2BGR_NV12), call site FrameSourceWarp.cpp:401.
+ * Third-party arithmetic (OpenCV 4.5 imgproc color_yuv, CPU path): integer
+ * BT.601 limited range, 20-bit fixed point.  nv12 = packed (h*3/2) x w bytes.
+ * ------------------------------------------------------------------------------------------ */
+#define VO_CY 1220542
+#define VO_CUB 2116026
+#define VO_CUG (-409993)
+#define VO_CVG (-852492)
+#define VO_CVR 1673527
+#define VO_YUV_SHIFT 20
+
+static inline uint8_t vo_sat8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+static inline void vo_yuv_to_bgr(int Y, int U, int V, uint8_t *bgr) {
+    int u = U - 128, v = V - 128;
+    int ruv = (1 << (VO_YUV_SHIFT - 1)) + VO_CVR * v;
+    int guv = (1 << (VO_YUV_SHIFT - 1)) + VO_CVG * v + VO_CUG * u;
+    int buv = (1 << (VO_YUV_SHIFT - 1)) + VO_CUB * u;
+    int y = (Y - 16 > 0 ? Y - 16 : 0) * VO_CY;
+    bgr[0] = vo_sat8((y + buv) >> VO_YUV_SHIFT);
+    bgr[1] = vo_sat8((y + guv) >> VO_YUV_SHIFT);
+    bgr[2] = vo_sat8((y + ruv) >> VO_YUV_SHIFT);
+}
+
+VO_API void vo_cvt_nv12_bgr(const uint8_t *nv12, int w, int h, uint8_t *bgr) {
+    const uint8_t *yp = nv12, *uvp = nv12 + (size_t)w * h;
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < h; r++) {
+        const uint8_t *yrow = yp + (size_t)r * w;
+        const uint8_t *uvrow = uvp + (size_t)(r >> 1) * w;
+        uint8_t *o = bgr + (size_t)r * w * 3;
+        for (int c = 0; c < w; c++)
+            vo_yuv_to_bgr(yrow[c], uvrow[c & ~1], uvrow[(c & ~1) + 1], o + 3 * c);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * atan used by the map.  OpenCL leaves atan() implementation defined (<= 5 ulp); the x86
+ * build of the reference kernel (oracle/_ref) uses libm atanf.  To let a GPU kernel match
+ * this restatement bit for bit the restatement fixes ONE algorithm built only from IEEE
+ * operations and fmaf: x > 1 -> pi/2 - atan(1/x); atan(t) = t + t*s*q(s), s = t*t, q a
+ * degree-7 minimax polynomial (max error < 1 ulp on [0, inf), verified exhaustively in
+ * tests).  Argument must be >= 0 or NaN (it is a vector length).
+ * ------------------------------------------------------------------------------------------ */
+static const float VO_ATAN_Q[8] = {
+    -0.33333125710487366f, 0.19993145763874054f,  -0.14205896854400635f, 0.1064559817314148f,
+    -0.07508683204650879f, 0.04269874095916748f,  -0.016053270548582077f, 0.0028423243202269077f};
+#define VO_PIO2_HI 1.57079637050628662109375f
+#define VO_PIO2_LO (-4.37113900018624283e-8f)
+
+VO_API float vo_atanf(float x) {
+    int inv = x > 1.0f;
+    float t = inv ? 1.0f / x : x;
+    float s = t * t;
+    float q = VO_ATAN_Q[7];
+    for (int i = 6; i >= 0; i--) q = fmaf(q, s, VO_ATAN_Q[i]);
+    float r = fmaf(t * s, q, t);
+    if (inv) r = (VO_PIO2_HI - r) + VO_PIO2_LO;
+    return r;
+}
+
+VO_API void vo_atanf_array(const float *x, float *y, long n) {
+    for (long i = 0; i < n; i++) y[i] = vo_atanf(x[i]);
+}
+
+/* max ulp error of vo_atanf over every binary32 in [lo_bits, hi_bits) vs double atan */
+VO_API double vo_atanf_max_ulp(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride) {
+    double worst = 0;
+#pragma omp parallel for reduction(max : worst) schedule(static)
+    for (int64_t b = lo_bits; b < (int64_t)hi_bits; b += stride) {
+        uint32_t u = (uint32_t)b;
+        float x;
+        memcpy(&x, &u, 4);
+        float a = vo_atanf(x);
+        double ref = atan((double)x);
+        float rf = (float)ref;
+        double ulp = (double)nextafterf(rf, INFINITY) - (double)rf;
+        double e = fabs((double)a - ref) / ulp;
+        if (e > worst) worst = e;
+    }
+    return worst;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a9: createMap.cl:1-51 restated.  p[17] = the 17 cl_float scalars in kernel-argument order
+ * (FrameSourceWarp.cpp:283-299): src cx,cy,fx,fy ; map(out) cx,cy,fx,fy ; rot00..rot22.
+ * dot() = products summed left to right, unfused (createMap.cl:27-31); length() =
+ * sqrtf(x*x+y*y) (createMap.cl:38); map planes are dense cols-wide float arrays.
+ * ------------------------------------------------------------------------------------------ */
+static inline void vo_map_pixel(int x, int y, const float *p, float *mx, float *my) {
+    float vx = ((float)x - p[4]) / p[6];
+    float vy = ((float)y - p[5]) / p[7];
+    float wx = (p[8] * vx + p[9] * vy) + p[10];
+    float wy = (p[11] * vx + p[12] * vy) + p[13];
+    float wz = (p[14] * vx + p[15] * vy) + p[16];
+    float cx = wx / wz, cy = wy / wz;
+    float r = sqrtf(cx * cx + cy * cy);
+    float k = vo_atanf(r) / r;
+    *mx = p[0] + (cx * k) * p[2];
+    *my = p[1] + (cy * k) * p[3];
+}
+
+VO_API void vo_create_map(float *mapx, float *mapy, int cols, int rows, const float *p) {
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++)
+            vo_map_pixel(x, y, p, mapx + (size_t)y * cols + x, mapy + (size_t)y * cols + x);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a10: cv::remap(src, dst, mapx, mapy, INTER_LINEAR), BORDER_CONSTANT 0; call site
+ * FrameSourceWarp.cpp:306-312.  Third-party arithmetic (OpenCV 4.5 imgproc remap, CPU path;
+ * SURVEY.md A.6): coordinates quantised to 1/32 px, 15-bit weights, round half up.
+ * ------------------------------------------------------------------------------------------ */
+static inline int vo_cvround(float v) {
+    /* cvRound = SSE cvtss2si: round half even; NaN / out of int range -> INT_MIN */
+    if (!(v >= -2147483648.0f && v < 2147483648.0f)) return INT_MIN;
+    return (int)lrintf(v);
+}
+
+static inline int vo_sat16(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
+
+static inline void vo_remap_pixel(const uint8_t *src, int sw, int sh, int cn, float mx, float my,
+                                  uint8_t *out) {
+    int sx = vo_cvround(mx * 32.0f), sy = vo_cvround(my * 32.0f);
+    int X = vo_sat16(sx >> 5), Y = vo_sat16(sy >> 5);
+    int fx = sx & 31, fy = sy & 31;
+    if (X >= sw || X + 1 < 0 || Y >= sh || Y + 1 < 0) {
+        for (int c = 0; c < cn; c++) out[c] = 0;
+        return;
+    }
+    int w00 = (32 - fx) * (32 - fy), w01 = fx * (32 - fy), w10 = (32 - fx) * fy, w11 = fx * fy;
+    int in00 = X >= 0 && Y >= 0, in01 = X + 1 < sw && Y >= 0;
+    int in10 = X >= 0 && Y + 1 < sh, in11 = X + 1 < sw && Y + 1 < sh;
+    for (int c = 0; c < cn; c++) {
+        int p00 = in00 ? src[((size_t)Y * sw + X) * cn + c] : 0;
+        int p01 = in01 ? src[((size_t)Y * sw + X + 1) * cn + c] : 0;
+        int p10 = in10 ? src[((size_t)(Y + 1) * sw + X) * cn + c] : 0;
+        int p11 = in11 ? src[((size_t)(Y + 1) * sw + X + 1) * cn + c] : 0;
+        /* weights*32 sum to 1<<15; (v + (1<<14)) >> 15 == (v' + 512) >> 10 */
+        out[c] = vo_sat8((p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + 512) >> 10);
+    }
+}
+
+VO_API void vo_remap_bilinear(const uint8_t *src, int sw, int sh, int cn, const float *mapx,
+                              const float *mapy, uint8_t *dst, int dw, int dh) {
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++)
+            vo_remap_pixel(src, sw, sh, cn, mapx[(size_t)y * dw + x], mapy[(size_t)y * dw + x],
+                           dst + ((size_t)y * dw + x) * cn);
+}
+
+/* a2+a9+a10 as the reference runs them (FrameSourceWarp.cpp:401 then :272-314): full-frame
+ * colour conversion, map planes written to memory, remap reading them back.  `work` must
+ * hold w*h*3 + 2*dw*dh*4 bytes.  Used as the CPU baseline in bench.py. */
+VO_API void vo_warp_nv12_reference_path(const uint8_t *nv12, int w, int h, const float *p,
+                                        uint8_t *dst, int dw, int dh, uint8_t *work) {
+    uint8_t *bgr = work;
+    float *mapx = (float *)(work + (((size_t)w * h * 3 + 15) & ~(size_t)15));
+    float *mapy = mapx + (size_t)dw * dh;
+    vo_cvt_nv12_bgr(nv12, w, h, bgr);
+    vo_create_map(mapx, mapy, dw, dh, p);
+    vo_remap_bilinear(bgr, w, h, 3, mapx, mapy, dst, dw, dh);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a3: goodFeaturesToTrack(gray, 200, 0.01, 30), call site FrameSourceWarp.cpp:230.
+ * Third-party arithmetic (OpenCV 4.5 imgproc featureselect/corner, CPU path).
+ * ------------------------------------------------------------------------------------------ */
+static inline int vo_reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+/* cornerMinEigenVal(blockSize 3, ksize 3): Sobel derivatives scaled by 1/(4*3*255), products,
+ * un-normalised 3x3 box sum (double accumulator, as OpenCV's boxFilter uses for 32F input),
+ * min eigenvalue in float.  gray has row pitch `pitch`.  eig is dense w x h float. */
+VO_API void vo_min_eig(const uint8_t *gray, size_t pitch, int w, int h, float *eig) {
+    const float scale = (float)(1.0 / (4.0 * 3.0 * 255.0));
+    const float k0 = 2.0f * scale, k1 = scale;
+    float *dx = (float *)malloc(sizeof(float) * (size_t)w * h);
+    float *dy = (float *)malloc(sizeof(float) * (size_t)w * h);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        int ym = vo_reflect101(y - 1, h), yp = vo_reflect101(y + 1, h);
+        for (int x = 0; x < w; x++) {
+            int xm = vo_reflect101(x - 1, w), xp = vo_reflect101(x + 1, w);
+            const uint8_t *r0 = gray + (size_t)ym * pitch, *r1 = gray + (size_t)y * pitch,
+                          *r2 = gray + (size_t)yp * pitch;
+            /* Dx: row [-1 0 1] (exact), column [1 2 1]*scale as (a+c)*k1 + b*k0 */
+            float d0 = (float)(r0[xp] - r0[xm]), d1 = (float)(r1[xp] - r1[xm]),
+                  d2 = (float)(r2[xp] - r2[xm]);
+            dx[(size_t)y * w + x] = (d0 + d2) * k1 + d1 * k0;
+            /* Dy: row [1 2 1]*scale as b*k0 + (a+c)*k1, column [-1 0 1] */
+            float s0 = (float)r0[x] * k0 + ((float)r0[xm] + (float)r0[xp]) * k1;
+            float s2 = (float)r2[x] * k0 + ((float)r2[xm] + (float)r2[xp]) * k1;
+            dy[(size_t)y * w + x] = s2 - s0;
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            double sxx = 0, sxy = 0, syy = 0;
+            for (int j = -1; j <= 1; j++) {
+                int yy = vo_reflect101(y + j, h);
+                for (int i = -1; i <= 1; i++) {
+                    int xx = vo_reflect101(x + i, w);
+                    float a = dx[(size_t)yy * w + xx], b = dy[(size_t)yy * w + xx];
+                    sxx += (double)(a * a);
+                    sxy += (double)(a * b);
+                    syy += (double)(b * b);
+                }
+            }
+            float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+            eig[(size_t)y * w + x] = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+        }
+    }
+    free(dx);
+    free(dy);
+}
+
+typedef struct {
+    float v;
+    int idx;
+} vo_cand;
+
+static int vo_cand_cmp(const void *pa, const void *pb) {
+    const vo_cand *a = (const vo_cand *)pa, *b = (const vo_cand *)pb;
+    if (a->v > b->v) return -1;
+    if (a->v < b->v) return 1;
+    return a->idx > b->idx ? -1 : a->idx < b->idx ? 1 : 0; /* ties: later raster position first */
+}
+
+/* Full detector.  Returns corner count; xy receives (x,y) pairs in acceptance order.
+ * If eig_out != NULL it receives the raw (un-thresholded) response map. */
+VO_API int vo_good_features(const uint8_t *gray, size_t pitch, int w, int h, int max_corners,
+                            double quality, double min_distance, float *xy, float *eig_out) {
+    float *eig = (float *)malloc(sizeof(float) * (size_t)w * h);
+    vo_min_eig(gray, pitch, w, h, eig);
+    if (eig_out) memcpy(eig_out, eig, sizeof(float) * (size_t)w * h);
+    float maxv = 0;
+    int any = 0;
+    for (size_t i = 0; i < (size_t)w * h; i++)
+        if (!any || eig[i] > maxv) maxv = eig[i], any = 1;
+    float thr = (float)((double)maxv * quality);
+    for (size_t i = 0; i < (size_t)w * h; i++)
+        if (!(eig[i] > thr)) eig[i] = 0;
+    vo_cand *cand = (vo_cand *)malloc(sizeof(vo_cand) * (size_t)w * h);
+    size_t nc = 0;
+    for (int y = 1; y < h - 1; y++)
+        for (int x = 1; x < w - 1; x++) {
+            float v = eig[(size_t)y * w + x];
+            if (v == 0) continue;
+            float m = v;
+            for (int j = -1; j <= 1; j++)
+                for (int i = -1; i <= 1; i++) {
+                    float n = eig[(size_t)(y + j) * w + (x + i)];
+                    if (n > m) m = n;
+                }
+            if (v == m) cand[nc].v = v, cand[nc].idx = y * w + x, nc++;
+        }
+    qsort(cand, nc, sizeof(vo_cand), vo_cand_cmp);
+    int cell = (int)lrint(min_distance);
+    int n = 0;
+    if (cell < 1) {
+        for (size_t i = 0; i < nc && (max_corners <= 0 || n < max_corners); i++) {
+            xy[2 * n] = (float)(cand[i].idx % w), xy[2 * n + 1] = (float)(cand[i].idx / w);
+            n++;
+        }
+    } else {
+        int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+        /* per-cell singly linked lists of accepted corners */
+        int *head = (int *)malloc(sizeof(int) * (size_t)gw * gh);
+        int cap = max_corners > 0 ? max_corners : (int)nc + 1;
+        int *next = (int *)malloc(sizeof(int) * (size_t)cap);
+        for (int i = 0; i < gw * gh; i++) head[i] = -1;
+        double md2 = min_distance * min_distance;
+        for (size_t i = 0; i < nc; i++) {
+            int x = cand[i].idx % w, y = cand[i].idx / w;
+            int xc = x / cell, yc = y / cell;
+            int x1 = xc - 1 < 0 ? 0 : xc - 1, y1 = yc - 1 < 0 ? 0 : yc - 1;
+            int x2 = xc + 1 > gw - 1 ? gw - 1 : xc + 1, y2 = yc + 1 > gh - 1 ? gh - 1 : yc + 1;
+            int good = 1;
+            for (int yy = y1; yy <= y2 && good; yy++)
+                for (int xx = x1; xx <= x2 && good; xx++)
+                    for (int j = head[yy * gw + xx]; j >= 0; j = next[j]) {
+                        float ddx = (float)x - xy[2 * j], ddy = (float)y - xy[2 * j + 1];
+                        if ((double)(ddx * ddx + ddy * ddy) < md2) {
+                            good = 0;
+                            break;
+                        }
+                    }
+            if (good) {
+                xy[2 * n] = (float)x, xy[2 * n + 1] = (float)y;
+                next[n] = head[yc * gw + xc];
+                head[yc * gw + xc] = n;
+                n++;
+                if (max_corners > 0 && n == max_corners) break;
+            }
+        }
+        free(head);
+        free(next);
+    }
+    free(cand);
+    free(eig);
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a4: calcOpticalFlowPyrLK defaults (win 21x21, maxLevel 3, 30 iterations, eps 0.01,
+ * minEigThreshold 1e-4), call site FrameSourceWarp.cpp:252.  Third-party arithmetic
+ * (OpenCV 4.5 video/lkpyramid + imgproc/pyramids, CPU path).
+ * One documented deviation: OpenCV accumulates A11/A12/A22/b1/b2 in float in a build-specific
+ * SIMD lane order; this restatement accumulates the (integer) products exactly in int64 and
+ * converts once, which is order free and within OpenCV's own rounding noise.
+ * ------------------------------------------------------------------------------------------ */
+VO_API void vo_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *dst,
+                        size_t dpitch) {
+    int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    static const int k[5] = {1, 4, 6, 4, 1};
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            int sum = 0;
+            for (int j = 0; j < 5; j++) {
+                int yy = vo_reflect101(2 * y + j - 2, sh);
+                int rs = 0;
+                for (int i = 0; i < 5; i++) rs += k[i] * src[(size_t)yy * spitch + vo_reflect101(2 * x + i - 2, sw)];
+                sum += k[j] * rs;
+            }
+            dst[(size_t)y * dpitch + x] = (uint8_t)((sum + 128) >> 8);
+        }
+}
+
+/* calcSharrDeriv: interleaved (dx,dy) int16, dense w x h, computed with REFLECT_101 borders */
+VO_API void vo_scharr(const uint8_t *src, size_t pitch, int w, int h, int16_t *deriv) {
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        const uint8_t *r0 = src + (size_t)vo_reflect101(y - 1, h) * pitch;
+        const uint8_t *r1 = src + (size_t)y * pitch;
+        const uint8_t *r2 = src + (size_t)vo_reflect101(y + 1, h) * pitch;
+        for (int x = 0; x < w; x++) {
+            int xm = vo_reflect101(x - 1, w), xp = vo_reflect101(x + 1, w);
+            int t0m = (r0[xm] + r2[xm]) * 3 + r1[xm] * 10, t0p = (r0[xp] + r2[xp]) * 3 + r1[xp] * 10;
+            int t1m = r2[xm] - r0[xm], t1c = r2[x] - r0[x], t1p = r2[xp] - r0[xp];
+            deriv[((size_t)y * w + x) * 2] = (int16_t)(t0p - t0m);
+            deriv[((size_t)y * w + x) * 2 + 1] = (int16_t)((t1p + t1m) * 3 + t1c * 10);
+        }
+    }
+}
+
+#define VO_LK_WIN 21
+#define VO_LK_MAXLEVEL 3
+#define VO_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+
+typedef struct {
+    int w, h;
+    uint8_t *img;   /* dense w x h */
+    int16_t *deriv; /* dense w x h x 2, only for the previous image */
+} vo_level;
+
+static inline int vo_img_at(const vo_level *L, int x, int y) { /* REFLECT_101 padded read */
+    return L->img[(size_t)vo_reflect101(y, L->h) * L->w + vo_reflect101(x, L->w)];
+}
+static inline int vo_der_at(const vo_level *L, int x, int y, int c) { /* zero padded read */
+    if (x < 0 || y < 0 || x >= L->w || y >= L->h) return 0;
+    return L->deriv[((size_t)y * L->w + x) * 2 + c];
+}
+
+static int vo_build_pyramid(const uint8_t *img, size_t pitch, int w, int h, vo_level *lv,
+                            int with_deriv) {
+    int nl = 0;
+    lv[0].w = w, lv[0].h = h;
+    lv[0].img = (uint8_t *)malloc((size_t)w * h);
+    for (int r = 0; r < h; r++) memcpy(lv[0].img + (size_t)r * w, img + (size_t)r * pitch, (size_t)w);
+    for (int l = 0; l <= VO_LK_MAXLEVEL; l++) {
+        if (l > 0) {
+            int pw = lv[l - 1].w, ph = lv[l - 1].h;
+            int nw = (pw + 1) / 2, nh = (ph + 1) / 2;
+            if (nw <= VO_LK_WIN || nh <= VO_LK_WIN) break;
+            lv[l].w = nw, lv[l].h = nh;
+            lv[l].img = (uint8_t *)malloc((size_t)nw * nh);
+            vo_pyr_down(lv[l - 1].img, (size_t)pw, pw, ph, lv[l].img, (size_t)nw);
+        }
+        lv[l].deriv = NULL;
+        if (with_deriv) {
+            lv[l].deriv = (int16_t *)malloc(sizeof(int16_t) * 2 * (size_t)lv[l].w * lv[l].h);
+            vo_scharr(lv[l].img, (size_t)lv[l].w, lv[l].w, lv[l].h, lv[l].deriv);
+        }
+        nl = l + 1;
+    }
+    return nl;
+}
+
+static void vo_free_pyramid(vo_level *lv, int nl) {
+    for (int l = 0; l < nl; l++) {
+        free(lv[l].img);
+        free(lv[l].deriv);
+    }
+}
+
+VO_API int vo_pyramid_levels(int w, int h) {
+    int nl = 1;
+    for (int l = 1; l <= VO_LK_MAXLEVEL; l++) {
+        w = (w + 1) / 2, h = (h + 1) / 2;
+        if (w <= VO_LK_WIN || h <= VO_LK_WIN) break;
+        nl++;
+    }
+    return nl;
+}
+
+static inline int vo_cvfloor(float v) { return (int)floorf(v); }
+
+static void vo_lk_point(const vo_level *I, const vo_level *J, int level, int max_level,
+                        const float *prev_pt, float *next_pt, uint8_t *status) {
+    const float half = (VO_LK_WIN - 1) * 0.5f;
+    const float lscale = (float)(1.0 / (1 << level));
+    float ppx = prev_pt[0] * lscale, ppy = prev_pt[1] * lscale;
+    float npx, npy;
+    if (level == max_level)
+        npx = ppx, npy = ppy;
+    else
+        npx = next_pt[0] * 2.0f, npy = next_pt[1] * 2.0f;
+    next_pt[0] = npx, next_pt[1] = npy;
+    ppx -= half, ppy -= half;
+    int ipx = vo_cvfloor(ppx), ipy = vo_cvfloor(ppy);
+    if (ipx < -VO_LK_WIN || ipx >= I->w || ipy < -VO_LK_WIN || ipy >= I->h) {
+        if (level == 0) *status = 0;
+        return;
+    }
+    float a = ppx - (float)ipx, b = ppy - (float)ipy;
+    const int W_BITS = 14;
+    const float FLT_SCALE = 1.0f / (1 << 20);
+    int iw00 = (int)lrintf((1.f - a) * (1.f - b) * (1 << W_BITS));
+    int iw01 = (int)lrintf(a * (1.f - b) * (1 << W_BITS));
+    int iw10 = (int)lrintf((1.f - a) * b * (1 << W_BITS));
+    int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+    int16_t Iw[VO_LK_WIN * VO_LK_WIN], Ixw[VO_LK_WIN * VO_LK_WIN], Iyw[VO_LK_WIN * VO_LK_WIN];
+    int64_t sA11 = 0, sA12 = 0, sA22 = 0;
+    for (int y = 0; y < VO_LK_WIN; y++)
+        for (int x = 0; x < VO_LK_WIN; x++) {
+            int X = ipx + x, Y = ipy + y;
+            int ival = VO_DESCALE(vo_img_at(I, X, Y) * iw00 + vo_img_at(I, X + 1, Y) * iw01 +
+                                      vo_img_at(I, X, Y + 1) * iw10 + vo_img_at(I, X + 1, Y + 1) * iw11,
+                                  W_BITS - 5);
+            int ixval = VO_DESCALE(vo_der_at(I, X, Y, 0) * iw00 + vo_der_at(I, X + 1, Y, 0) * iw01 +
+                                       vo_der_at(I, X, Y + 1, 0) * iw10 + vo_der_at(I, X + 1, Y + 1, 0) * iw11,
+                                   W_BITS);
+            int iyval = VO_DESCALE(vo_der_at(I, X, Y, 1) * iw00 + vo_der_at(I, X + 1, Y, 1) * iw01 +
+                                       vo_der_at(I, X, Y + 1, 1) * iw10 + vo_der_at(I, X + 1, Y + 1, 1) * iw11,
+                                   W_BITS);
+            Iw[y * VO_LK_WIN + x] = (int16_t)ival;
+            Ixw[y * VO_LK_WIN + x] = (int16_t)ixval;
+            Iyw[y * VO_LK_WIN + x] = (int16_t)iyval;
+            sA11 += (int64_t)ixval * ixval;
+            sA12 += (int64_t)ixval * iyval;
+            sA22 += (int64_t)iyval * iyval;
+        }
+    float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    float minEig = ((A22 + A11) - sqrtf((A11 - A22) * (A11 - A22) + (4.f * A12) * A12)) /
+                   (float)(2 * VO_LK_WIN * VO_LK_WIN);
+    if (minEig < 1e-4f || D < FLT_EPSILON) {
+        if (level == 0) *status = 0;
+        return;
+    }
+    D = 1.f / D;
+    npx -= half, npy -= half;
+    float pdx = 0, pdy = 0;
+    const double eps2 = 0.01 * 0.01;
+    for (int j = 0; j < 30; j++) {
+        int inx = vo_cvfloor(npx), iny = vo_cvfloor(npy);
+        if (inx < -VO_LK_WIN || inx >= J->w || iny < -VO_LK_WIN || iny >= J->h) {
+            if (level == 0) *status = 0;
+            break;
+        }
+        a = npx - (float)inx, b = npy - (float)iny;
+        iw00 = (int)lrintf((1.f - a) * (1.f - b) * (1 << W_BITS));
+        iw01 = (int)lrintf(a * (1.f - b) * (1 << W_BITS));
+        iw10 = (int)lrintf((1.f - a) * b * (1 << W_BITS));
+        iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        int64_t sb1 = 0, sb2 = 0;
+        for (int y = 0; y < VO_LK_WIN; y++)
+            for (int x = 0; x < VO_LK_WIN; x++) {
+                int X = inx + x, Y = iny + y;
+                int diff = VO_DESCALE(vo_img_at(J, X, Y) * iw00 + vo_img_at(J, X + 1, Y) * iw01 +
+                                          vo_img_at(J, X, Y + 1) * iw10 + vo_img_at(J, X + 1, Y + 1) * iw11,
+                                      W_BITS - 5) -
+                           Iw[y * VO_LK_WIN + x];
+                sb1 += (int64_t)diff * Ixw[y * VO_LK_WIN + x];
+                sb2 += (int64_t)diff * Iyw[y * VO_LK_WIN + x];
+            }
+        float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+        float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+        npx += dx, npy += dy;
+        next_pt[0] = npx + half, next_pt[1] = npy + half;
+        if ((double)dx * dx + (double)dy * dy <= eps2) break;
+        if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+            next_pt[0] -= dx * 0.5f, next_pt[1] -= dy * 0.5f;
+            break;
+        }
+        pdx = dx, pdy = dy;
+    }
+}
+
+/* prev_pts/next_pts: n (x,y) pairs; status: n bytes.  Returns number of pyramid levels used. */
+VO_API int vo_pyr_lk(const uint8_t *prev, size_t ppitch, const uint8_t *next, size_t npitch, int w,
+                     int h, const float *prev_pts, int n, float *next_pts, uint8_t *status) {
+    vo_level I[VO_LK_MAXLEVEL + 1], J[VO_LK_MAXLEVEL + 1];
+    int nl = vo_build_pyramid(prev, ppitch, w, h, I, 1);
+    vo_build_pyramid(next, npitch, w, h, J, 0);
+    for (int i = 0; i < n; i++) status[i] = 1;
+    for (int level = nl - 1; level >= 0; level--) {
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int i = 0; i < n; i++)
+            vo_lk_point(&I[level], &J[level], level, nl - 1, prev_pts + 2 * i, next_pts + 2 * i,
+                        status + i);
+    }
+    vo_free_pyramid(I, nl);
+    vo_free_pyramid(J, nl);
+    return nl;
+}

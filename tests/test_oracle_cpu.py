@@ -1,0 +1,221 @@
+"""CPU tests (no GPU): the oracle against the golden vectors and closed-form known answers."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return np.load(os.path.join(GOLD, "createmap_ref.npz"))
+
+
+@pytest.fixture(scope="module")
+def kat():
+    return np.load(os.path.join(GOLD, "oracle_kat.npz"))
+
+
+def _flip_rate(a, b):
+    return float((np.rint(a * 32) != np.rint(b * 32)).mean())
+
+
+def test_create_map_restatement_vs_reference_kernel_golden(ref):
+    """vo_create_map vs the reference's own createMap.cl (x86 build): identical arithmetic except
+    atan (libm atanf there, fixed polynomial here) -> <= 2.5e-3 px and rare 1/32-bucket flips."""
+    cw, ch = ref["small_size"]
+    for i in range(4):
+        mx, my = oracle.create_map(ref[f"small_params_{i}"], int(cw), int(ch))
+        gx, gy = ref[f"small_mapx_{i}"], ref[f"small_mapy_{i}"]
+        ok = np.isfinite(gx) & np.isfinite(gy)
+        assert np.array_equal(np.isnan(mx), np.isnan(gx))
+        p = ref[f"small_params_{i}"]
+        # k = atan(r)/r differs by <= ~2 ulp (relative); it multiplies the term (map - centre)
+        assert (np.abs(mx - gx)[ok] <= 3 * 2.0 ** -23 * (np.abs(gx[ok]) + abs(p[0]))).all()
+        assert (np.abs(my - gy)[ok] <= 3 * 2.0 ** -23 * (np.abs(gy[ok]) + abs(p[1]))).all()
+        assert _flip_rate(mx[ok], gx[ok]) < 0.005 and _flip_rate(my[ok], gy[ok]) < 0.005
+    cw, ch = ref["uhd_size"]
+    for i in range(3):
+        mx, my = oracle.create_map(ref[f"uhd_params_{i}"], int(cw), int(ch))
+        for c, (x, y) in enumerate(ref["uhd_crops"]):
+            gx, gy = ref[f"uhd_mapx_{i}"][c], ref[f"uhd_mapy_{i}"][c]
+            tol = 2 * np.spacing(np.float32(4096.0))
+            assert np.abs(mx[y:y + 32, x:x + 32] - gx).max() <= tol
+            assert np.abs(my[y:y + 32, x:x + 32] - gy).max() <= tol
+
+
+@pytest.mark.skipif(oracle.ref_lib() is None, reason="oracle/_ref not built (reference tree absent)")
+def test_create_map_live_reference_kernel_matches_golden(ref):
+    cw, ch = ref["small_size"]
+    for i in range(4):
+        mx, my = oracle.create_map_ref(ref[f"small_params_{i}"], int(cw), int(ch))
+        assert np.array_equal(mx, ref[f"small_mapx_{i}"], equal_nan=True)
+        assert np.array_equal(my, ref[f"small_mapy_{i}"], equal_nan=True)
+
+
+def test_atan_accuracy():
+    L = oracle.lib()
+    assert L.vo_atanf_max_ulp(0, 0x3F800000, 61) < 1.1          # [0, 1)
+    assert L.vo_atanf_max_ulp(0x3F800000, 0x7F000000, 61) < 1.5  # [1, huge)
+    x = np.array([0.0, 1.0, np.inf, np.nan], np.float32)
+    y = oracle.atanf(x)
+    assert y[0] == 0 and abs(y[1] - np.pi / 4) < 1e-7 and abs(y[2] - np.pi / 2) < 2e-7 and np.isnan(y[3])
+
+
+def test_map_identity_closed_form():
+    """Identity rotation: map = c_in + f_in * atan(r)/r * p, p = (x - c_out)/f_out (createMap.cl)."""
+    K = oracle.get_preset_camera(4, 1920, 1080)
+    Ko, (cw, ch) = oracle.get_output_camera(K, 1920, 1080)
+    mx, my = oracle.create_map(oracle.map_params(K, Ko, np.eye(3)), cw, ch)
+    ys, xs = np.mgrid[0:ch, 0:cw].astype(np.float64)
+    px, py = (xs - Ko[0, 2]) / Ko[0, 0], (ys - Ko[1, 2]) / Ko[1, 1]
+    r = np.hypot(px, py)
+    k = np.arctan(r) / r
+    assert np.nanmax(np.abs(mx - (K[0, 2] + px * k * K[0, 0]))) < 2e-3
+    assert np.nanmax(np.abs(my - (K[1, 2] + py * k * K[1, 1]))) < 2e-3
+    # get_output_camera's purpose (:112-157): the output frames every probe point of the input
+    assert np.nanmin(mx) < 1 and np.nanmax(mx) > 1918 and np.nanmin(my) < 1 and np.nanmax(my) > 1078
+
+
+def test_cvt_known_answers_and_golden(kat):
+    f = np.array([[16, 235, 16, 235], [81, 145, 41, 210], [128, 128, 128, 128]], np.uint8)  # 4x2 frame
+    bgr = oracle.cvt_nv12_bgr(f)
+    assert bgr[0, 0].tolist() == [0, 0, 0] and bgr[0, 1].tolist() == [255, 255, 255]
+    assert bgr[1, 0, 0] == bgr[1, 0, 1] == bgr[1, 0, 2]  # neutral chroma -> gray
+    red = np.array([[81, 81], [81, 81], [90, 240]], np.uint8)  # BT.601 limited-range pure red
+    b, g, r = oracle.cvt_nv12_bgr(red)[0, 0]
+    assert r >= 254 and g <= 1 and b <= 1
+    assert np.array_equal(oracle.cvt_nv12_bgr(kat["cvt_nv12"]), kat["cvt_bgr"])
+
+
+def test_remap_special_cases_golden(kat):
+    out = oracle.remap_bilinear(kat["remap_src"], kat["remap_mx"], kat["remap_my"])
+    assert np.array_equal(out, kat["remap_dst"])
+    src = kat["remap_src"]
+    assert out[0, :6].tolist() == [0] * 6            # NaN, +-inf, +-3e9, 1e30 -> constant border
+    assert out[0, 14] == src[0, 0]                   # exact integer coordinate
+    assert out[0, 6] == (int(src[0, 0]) * 256 + 512) >> 10  # (-0.5,-0.5): only tap 11 inside, weight 16*16
+    assert out[0, 11] == 0                           # X == width: fully outside
+
+
+def test_remap_identity_and_halfpixel():
+    src = synth.luma(2, 32, 20, rects=2)
+    ys, xs = np.mgrid[0:20, 0:32].astype(np.float32)
+    assert np.array_equal(oracle.remap_bilinear(src, xs, ys), src)
+    out = oracle.remap_bilinear(src, xs[:, :-1] + 0.5, ys[:, :-1])
+    exp = (src[:, :-1].astype(int) * 512 + src[:, 1:].astype(int) * 512 + 512) >> 10
+    assert np.array_equal(out, exp)
+
+
+def test_warp_golden(kat):
+    seed, w, h = kat["warp_seed"]
+    frame = synth.nv12(int(seed), int(w), int(h))
+    for i in range(4):
+        g = kat[f"warp_bgr_{i}"]
+        out = oracle.warp_nv12(frame, kat[f"warp_params_{i}"], g.shape[1], g.shape[0])
+        assert np.array_equal(out, g)
+
+
+def test_pack_nv12():
+    rng = np.random.default_rng(0)
+    ybuf = rng.integers(0, 256, (8, 24), dtype=np.uint8)
+    uvbuf = rng.integers(0, 256, (4, 20), dtype=np.uint8)
+    out = oracle.pack_nv12(ybuf[:, :16], uvbuf[:, :16])
+    assert np.array_equal(out[:8], ybuf[:, :16]) and np.array_equal(out[8:], uvbuf[:, :16])
+    with pytest.raises(ValueError):
+        oracle.pack_nv12(ybuf[:7, :16], uvbuf[:, :16])
+
+
+def test_cameras_golden_and_survey_appendix_b(kat):
+    for row in kat["cameras"]:
+        preset, w, h, sc, crop = int(row[0]), int(row[1]), int(row[2]), row[3], bool(row[4])
+        K = oracle.get_preset_camera(preset, w, h)
+        Ko, sz = oracle.get_output_camera(K, w, h, sc, crop, 1.0)
+        assert np.allclose(K.reshape(-1), row[5:14], rtol=0, atol=1e-12)
+        assert np.allclose(Ko.reshape(-1), row[14:23], rtol=0, atol=1e-12)
+        assert list(sz) == [int(row[23]), int(row[24])]
+    K = oracle.get_preset_camera(4, 3840, 2160)
+    Ko, sz = oracle.get_output_camera(K, 3840, 2160)
+    assert sz == (3524, 1999) and abs(Ko[0, 0] - 984.866) < 1e-3
+    K = oracle.get_preset_camera(4, 1920, 1080)
+    assert oracle.get_output_camera(K, 1920, 1080)[1] == (1759, 998)
+    assert oracle.get_output_camera(K, 1920, 1080, crop_borders=True)[1] == (1436, 602)
+
+
+def test_undistort_zero_distortion_closed_form():
+    K = oracle.get_preset_camera(4, 1920, 1080)
+    pts = np.array([[100.0, 50.0], [K[0, 2], K[1, 2]], [1900.0, 1000.0]])
+    out = oracle.fisheye_undistort_points(pts, K)
+    pw = (pts - [K[0, 2], K[1, 2]]) / [K[0, 0], K[1, 1]]
+    th = np.linalg.norm(pw, axis=1)
+    exp = pw * np.where(th > 1e-8, np.tan(th) / np.maximum(th, 1e-300), 0)[:, None]
+    assert np.allclose(out, exp, atol=1e-12)
+
+
+def test_sg_weights_closed_form_and_filter_golden(kat):
+    for m in (3, 5, 30):
+        i = np.arange(-m, m + 1)
+        cf = 3.0 * (3 * m * m + 3 * m - 1 - 5 * i * i) / ((2 * m - 1) * (2 * m + 1) * (2 * m + 3))
+        w = oracle.sg_weights(m)
+        assert np.abs(w - cf).max() < 1e-15 and abs(w.sum() - 1) < 1e-12
+    assert np.allclose(oracle.sg_weights(30), kat["sg_w30"], atol=1e-16)
+    filt = oracle.RotationFilter(int(kat["sg_m"][0]))
+    for R, exp in zip(kat["sg_traj"], kat["sg_filtered"]):
+        filt.add(R)
+        out = filt.filter()
+        assert np.allclose(out, exp, atol=1e-12)
+        assert np.allclose(out @ out.T, np.eye(3), atol=1e-12)
+
+
+def test_sg_constant_rotation_is_fixed_point():
+    R = oracle.rodrigues([0.1, -0.2, 0.05])
+    f = oracle.RotationFilter(4)
+    for _ in range(9):
+        f.add(R)
+    assert np.allclose(f.filter(), R, atol=1e-12)
+
+
+def test_gftt_and_lk_golden(kat):
+    seed, w, h = (int(v) for v in kat["gftt_seed"])
+    g0 = synth.luma(seed, w, h)
+    pts = oracle.good_features(g0)
+    assert np.array_equal(pts, kat["gftt_corners"])
+    d = pts[:, None, :] - pts[None, :, :]
+    d2 = (d ** 2).sum(-1) + np.eye(len(pts)) * 1e9
+    assert d2.min() >= 900                       # min distance 30 px
+    g1 = synth.shifted(g0, *kat["lk_shift"])
+    nxt, st = oracle.pyr_lk(g0, g1, pts)
+    assert np.array_equal(st, kat["lk_status"]) and np.array_equal(nxt, kat["lk_next"])
+    flow = (nxt - pts)[st > 0]
+    assert np.abs(np.median(flow, axis=0) - kat["lk_shift"]).max() < 0.05
+
+
+def test_pyr_down_and_scharr_basics():
+    flat = np.full((20, 30), 77, np.uint8)
+    assert (oracle.pyr_down(flat) == 77).all() and oracle.pyr_down(flat).shape == (10, 15)
+    assert (oracle.scharr(flat) == 0).all()
+    ramp = np.tile(np.arange(30, dtype=np.uint8) * 3, (20, 1))
+    d = oracle.scharr(ramp)
+    assert (d[:, 1:-1, 0] == 3 * 2 * 16).all() and (d[..., 1] == 0).all()   # (3+10+3) * (I[x+1]-I[x-1])
+    assert (d[:, 0, 0] == 0).all()               # REFLECT_101: I[-1] == I[1]
+
+
+def test_state_machine_output_count_and_lag():
+    """FrameSourceWarp.cpp:403-407,452-476: first frame is never emitted; n inputs -> n-1 outputs."""
+    n, r = 12, 3
+    frames = [np.full((3, 2), i, np.uint8) for i in range(n)]
+    sm = oracle.WarpStateMachine(frames, r, lambda g: np.zeros((200, 2), np.float32),
+                                 lambda a, b, c: (c, c), lambda a, b: (np.eye(3), 100),
+                                 lambda f, R: int(f[0, 0]))
+    outs = []
+    while True:
+        o = sm.pull_frame()
+        if o is None:
+            break
+        outs.append(o)
+    assert outs == list(range(1, n))
+    assert sm.frame_index == n

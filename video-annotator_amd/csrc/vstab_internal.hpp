@@ -1,0 +1,28 @@
+// vstab_internal.hpp -- host-side helpers shared by the translation units of libvstab.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <string>
+
+#include "../../include/vstab.h"
+
+namespace vstab {
+
+void set_error(const std::string &msg);
+
+inline vstab_status fail(vstab_status st, const std::string &msg) {
+    set_error(msg);
+    return st;
+}
+
+#define VSTAB_HIP_TRY(expr)                                                                     \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return ::vstab::fail(VSTAB_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+}  // namespace vstab

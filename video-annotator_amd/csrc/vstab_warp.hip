@@ -1,0 +1,348 @@
+// vstab_warp.hip -- pixel-path HIP kernels for gfx950 (MI355X): NV12 packing, NV12->BGR,
+// createMap, remap, and the fused undistort-remap kernel.  Compiled with -ffp-contract=off.
+//
+// All of this is HBM-bound byte/gather work (no MFMA): the design rules that matter are
+// coalesced wide accesses, enough workgroups to fill 256 CUs, and keeping the map in registers.
+#include "vstab_device.hpp"
+#include "vstab_internal.hpp"
+
+namespace vstab {
+
+// =============================================================================================
+// k_pack_nv12 -- replaces the two clEnqueueCopyImageToBuffer calls of
+// FrameSourceFfmpegOpenCl.cpp:64-85.  One launch copies both planes: rows [0,h) come from the
+// luma plane, rows [h, h*3/2) from the chroma plane.  16 B per lane when every pitch and base
+// is 16-B aligned, bytes otherwise.
+// =============================================================================================
+template <typename V>
+__global__ void __launch_bounds__(256) k_pack_nv12(const uint8_t *__restrict__ y, size_t pitch_y,
+                                                   const uint8_t *__restrict__ uv, size_t pitch_uv,
+                                                   int row_vecs, int h, uint8_t *__restrict__ dst,
+                                                   size_t pitch_dst) {
+    const int rows = h + h / 2;
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        const uint8_t *s = row < h ? y + (size_t)row * pitch_y : uv + (size_t)(row - h) * pitch_uv;
+        uint8_t *d = dst + (size_t)row * pitch_dst;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < row_vecs; i += gridDim.x * blockDim.x)
+            reinterpret_cast<V *>(d)[i] = reinterpret_cast<const V *>(s)[i];
+    }
+}
+
+// =============================================================================================
+// k_cvt_nv12_bgr -- cvtColor(COLOR_YUV2BGR_NV12), FrameSourceWarp.cpp:401.  Compatibility /
+// parity kernel (the fused path never materialises the BGR frame).  One thread converts an
+// 8 x 2 luma block: two 8-B luma loads, one 8-B chroma load, two 24-B BGR stores.
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_cvt_nv12_bgr(const uint8_t *__restrict__ yp, size_t pitch_y,
+                                                      const uint8_t *__restrict__ uvp, size_t pitch_uv,
+                                                      int w, int h, uint8_t *__restrict__ dst,
+                                                      size_t pitch_dst, int vec_ok) {
+    const int bx = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const int by = (blockIdx.y * blockDim.y + threadIdx.y) * 2;
+    if (bx >= w || by >= h) return;
+    const uint8_t *y0 = yp + (size_t)by * pitch_y + bx;
+    const uint8_t *y1 = y0 + pitch_y;
+    const uint8_t *uv = uvp + (size_t)(by >> 1) * pitch_uv + bx;
+    uint8_t *d0 = dst + (size_t)by * pitch_dst + (size_t)bx * 3;
+    uint8_t *d1 = d0 + pitch_dst;
+    if (vec_ok && bx + 8 <= w) {
+        const uint2 a = *reinterpret_cast<const uint2 *>(y0);
+        const uint2 b = *reinterpret_cast<const uint2 *>(y1);
+        const uint2 c = *reinterpret_cast<const uint2 *>(uv);
+        const uint32_t ya[2] = {a.x, a.y}, yb[2] = {b.x, b.y}, cc[2] = {c.x, c.y};
+        uint32_t o0[6], o1[6];
+        uint8_t t0[24], t1[24];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int pair = i >> 1;
+            const uint32_t cw = cc[pair >> 1] >> ((pair & 1) * 16);
+            const ChromaTerm ct = chroma_term(cw & 255, (cw >> 8) & 255);
+            int bb, gg, rr;
+            yuv_to_bgr((ya[i >> 2] >> ((i & 3) * 8)) & 255, ct, bb, gg, rr);
+            t0[3 * i] = bb, t0[3 * i + 1] = gg, t0[3 * i + 2] = rr;
+            yuv_to_bgr((yb[i >> 2] >> ((i & 3) * 8)) & 255, ct, bb, gg, rr);
+            t1[3 * i] = bb, t1[3 * i + 1] = gg, t1[3 * i + 2] = rr;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            o0[i] = t0[4 * i] | (t0[4 * i + 1] << 8) | (t0[4 * i + 2] << 16) | ((uint32_t)t0[4 * i + 3] << 24);
+            o1[i] = t1[4 * i] | (t1[4 * i + 1] << 8) | (t1[4 * i + 2] << 16) | ((uint32_t)t1[4 * i + 3] << 24);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            reinterpret_cast<uint2 *>(d0)[i] = make_uint2(o0[2 * i], o0[2 * i + 1]);
+            reinterpret_cast<uint2 *>(d1)[i] = make_uint2(o1[2 * i], o1[2 * i + 1]);
+        }
+    } else {
+        for (int i = 0; i < 8 && bx + i < w; i++) {
+            const ChromaTerm ct = chroma_term(uv[i & ~1], uv[(i & ~1) + 1]);
+            int bb, gg, rr;
+            yuv_to_bgr(y0[i], ct, bb, gg, rr);
+            d0[3 * i] = bb, d0[3 * i + 1] = gg, d0[3 * i + 2] = rr;
+            if (by + 1 < h) {
+                yuv_to_bgr(y1[i], ct, bb, gg, rr);
+                d1[3 * i] = bb, d1[3 * i + 1] = gg, d1[3 * i + 2] = rr;
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// k_create_map -- createMap.cl:1-51 as a stand-alone kernel (parity / un-fused mode only).
+// 16x16 threads, 4 columns per thread (one 16-B store per plane when aligned).
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_create_map(float *__restrict__ mapx, size_t pitch_x,
+                                                    float *__restrict__ mapy, size_t pitch_y,
+                                                    int cols, int rows, MapParams p, int vec_ok) {
+    const int x0 = (blockIdx.x * 16 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 16 + threadIdx.y;
+    if (x0 >= cols || y >= rows) return;
+    const RowTerm rt = row_term(p, y);
+    float mx[4], my[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) map_pixel(p, col_term(p, x0 + i), rt, mx[i], my[i]);
+    float *px = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(mapx) + (size_t)y * pitch_x) + x0;
+    float *py = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(mapy) + (size_t)y * pitch_y) + x0;
+    if (vec_ok && x0 + 4 <= cols) {
+        *reinterpret_cast<float4 *>(px) = make_float4(mx[0], mx[1], mx[2], mx[3]);
+        *reinterpret_cast<float4 *>(py) = make_float4(my[0], my[1], my[2], my[3]);
+    } else {
+        for (int i = 0; i < 4 && x0 + i < cols; i++) px[i] = mx[i], py[i] = my[i];
+    }
+}
+
+// =============================================================================================
+// k_remap_bilinear -- cv::remap(INTER_LINEAR, BORDER_CONSTANT 0), FrameSourceWarp.cpp:306-312,
+// reading float map planes (un-fused compatibility mode).  One thread per output pixel.
+// =============================================================================================
+template <int CN>
+__global__ void __launch_bounds__(256) k_remap_bilinear(const uint8_t *__restrict__ src, size_t pitch_src,
+                                                        int sw, int sh, const float *__restrict__ mapx,
+                                                        size_t pitch_x, const float *__restrict__ mapy,
+                                                        size_t pitch_y, uint8_t *__restrict__ dst,
+                                                        size_t pitch_dst, int dw, int dh) {
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    const float mx = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(mapx) + (size_t)y * pitch_x)[x];
+    const float my = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(mapy) + (size_t)y * pitch_y)[x];
+    const Tap t = quantise(mx, my);
+    uint8_t *o = dst + (size_t)y * pitch_dst + (size_t)x * CN;
+    if (t.far || t.X >= sw || t.X + 1 < 0 || t.Y >= sh || t.Y + 1 < 0) {
+#pragma unroll
+        for (int c = 0; c < CN; c++) o[c] = 0;
+        return;
+    }
+    const int w00 = (32 - t.fx) * (32 - t.fy), w01 = t.fx * (32 - t.fy), w10 = (32 - t.fx) * t.fy,
+              w11 = t.fx * t.fy;
+    const bool x0 = t.X >= 0, x1 = t.X + 1 < sw, y0 = t.Y >= 0, y1 = t.Y + 1 < sh;
+    const uint8_t *r0 = src + (size_t)max(t.Y, 0) * pitch_src, *r1 = src + (size_t)min(t.Y + 1, sh - 1) * pitch_src;
+    const size_t c0 = (size_t)max(t.X, 0) * CN, c1 = (size_t)min(t.X + 1, sw - 1) * CN;
+#pragma unroll
+    for (int c = 0; c < CN; c++) {
+        const int p00 = (x0 && y0) ? r0[c0 + c] : 0, p01 = (x1 && y0) ? r0[c1 + c] : 0;
+        const int p10 = (x0 && y1) ? r1[c0 + c] : 0, p11 = (x1 && y1) ? r1[c1 + c] : 0;
+        o[c] = (uint8_t)((p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + 512) >> 10);
+    }
+}
+
+// =============================================================================================
+// k_warp_nv12_bgr (v1, direct gather) -- the fused hot kernel:
+//   createMap.cl:13-50  ->  remap quantisation (:306-312)  ->  4 NV12 taps converted with the
+//   cvtColor arithmetic (:401)  ->  fixed-point bilinear blend  ->  BGR8.
+// Converting each tap and then blending is exactly what the reference's cvtColor-then-remap
+// sequence computes, so the output is bit-identical to the un-fused operators.
+//
+// Block = 16 x 16 threads; a thread owns 4 adjacent columns (12 output bytes = 3 dwords per
+// row) and ROWS_PER_THREAD rows 16 apart, so the column terms of the rotated ray (and their
+// divisions) are computed once per thread and the row terms once per row.
+// =============================================================================================
+constexpr int WARP_ROWS_PER_THREAD = 4;
+constexpr int WARP_TILE_W = 64, WARP_TILE_H = 16 * WARP_ROWS_PER_THREAD;
+
+struct WarpArgs {
+    const uint8_t *y;
+    const uint8_t *uv;
+    uint8_t *dst;
+    size_t pitch_y, pitch_uv, pitch_dst;
+    int sw, sh, dw, dh;
+    MapParams p;
+};
+
+__device__ __forceinline__ void fetch_tap(const WarpArgs &a, int X, int Y, int &b, int &g, int &r) {
+    if ((unsigned)X < (unsigned)a.sw && (unsigned)Y < (unsigned)a.sh) {
+        const int yv = a.y[(size_t)Y * a.pitch_y + X];
+        const uint16_t c = *reinterpret_cast<const uint16_t *>(a.uv + (size_t)(Y >> 1) * a.pitch_uv + (X & ~1));
+        yuv_to_bgr(yv, chroma_term(c & 255, c >> 8), b, g, r);
+    } else {
+        b = g = r = 0;
+    }
+}
+
+__device__ __forceinline__ uint32_t warp_pixel(const WarpArgs &a, const ColTerm &ct, const RowTerm &rt) {
+    float mx, my;
+    map_pixel(a.p, ct, rt, mx, my);
+    const Tap t = quantise(mx, my);
+    if (t.far || t.X >= a.sw || t.X + 1 < 0 || t.Y >= a.sh || t.Y + 1 < 0) return 0;
+    const int w00 = (32 - t.fx) * (32 - t.fy), w01 = t.fx * (32 - t.fy), w10 = (32 - t.fx) * t.fy,
+              w11 = t.fx * t.fy;
+    int b0, g0, r0, b1, g1, r1, b2, g2, r2, b3, g3, r3;
+    fetch_tap(a, t.X, t.Y, b0, g0, r0);
+    fetch_tap(a, t.X + 1, t.Y, b1, g1, r1);
+    fetch_tap(a, t.X, t.Y + 1, b2, g2, r2);
+    fetch_tap(a, t.X + 1, t.Y + 1, b3, g3, r3);
+    const uint32_t B = (uint32_t)(b0 * w00 + b1 * w01 + b2 * w10 + b3 * w11 + 512) >> 10;
+    const uint32_t G = (uint32_t)(g0 * w00 + g1 * w01 + g2 * w10 + g3 * w11 + 512) >> 10;
+    const uint32_t R = (uint32_t)(r0 * w00 + r1 * w01 + r2 * w10 + r3 * w11 + 512) >> 10;
+    return B | (G << 8) | (R << 16);
+}
+
+__global__ void __launch_bounds__(256) k_warp_nv12_bgr(WarpArgs a, int vec_ok) {
+    const int x0 = blockIdx.x * WARP_TILE_W + threadIdx.x * 4;
+    if (x0 >= a.dw) return;
+    ColTerm ct[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) ct[i] = col_term(a.p, x0 + i);
+#pragma unroll 1
+    for (int j = 0; j < WARP_ROWS_PER_THREAD; j++) {
+        const int y = blockIdx.y * WARP_TILE_H + j * 16 + threadIdx.y;
+        if (y >= a.dh) break;
+        const RowTerm rt = row_term(a.p, y);
+        uint32_t px[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) px[i] = warp_pixel(a, ct[i], rt);
+        uint8_t *o = a.dst + (size_t)y * a.pitch_dst + (size_t)x0 * 3;
+        if (vec_ok && x0 + 4 <= a.dw) {
+            uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
+            o32[0] = px[0] | (px[1] << 24);
+            o32[1] = (px[1] >> 8) | (px[2] << 16);
+            o32[2] = (px[2] >> 16) | (px[3] << 8);
+        } else {
+            for (int i = 0; i < 4 && x0 + i < a.dw; i++) {
+                o[3 * i] = px[i] & 255, o[3 * i + 1] = (px[i] >> 8) & 255, o[3 * i + 2] = (px[i] >> 16) & 255;
+            }
+        }
+    }
+}
+
+static MapParams to_params(const float p[17]) {
+    MapParams m;
+    m.icx = p[0], m.icy = p[1], m.ifx = p[2], m.ify = p[3];
+    m.ocx = p[4], m.ocy = p[5], m.ofx = p[6], m.ofy = p[7];
+    for (int i = 0; i < 9; i++) m.r[i] = p[8 + i];
+    return m;
+}
+
+static inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace vstab
+
+using namespace vstab;
+
+extern "C" {
+
+vstab_status vstab_pack_nv12(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width,
+                             int height, void *dst, void *stream) {
+    if (!y || !uv || !dst) return fail(VSTAB_ERR_INVALID, "vstab_pack_nv12: null pointer");
+    if (width <= 0 || height <= 0 || (width & 1) || (height & 1))
+        return fail(VSTAB_ERR_INVALID, "Mismatched image dimensions");  // FrameSourceFfmpegOpenCl.cpp:53-56
+    if (pitch_y < (size_t)width || pitch_uv < (size_t)width)
+        return fail(VSTAB_ERR_INVALID, "vstab_pack_nv12: pitch smaller than row");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool v16 = aligned(y, 16) && aligned(uv, 16) && aligned(dst, 16) && pitch_y % 16 == 0 &&
+                     pitch_uv % 16 == 0 && width % 16 == 0;
+    const int rows = height + height / 2;
+    if (v16) {
+        const int vecs = width / 16;
+        dim3 grid(div_up(vecs, 256), std::min(rows, 4096));
+        hipLaunchKernelGGL(k_pack_nv12<uint4>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y,
+                           (const uint8_t *)uv, pitch_uv, vecs, height, (uint8_t *)dst, (size_t)width);
+    } else {
+        dim3 grid(div_up(width, 256), std::min(rows, 4096));
+        hipLaunchKernelGGL(k_pack_nv12<uint8_t>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y,
+                           (const uint8_t *)uv, pitch_uv, width, height, (uint8_t *)dst, (size_t)width);
+    }
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+vstab_status vstab_cvt_nv12_bgr(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width,
+                                int height, void *dst, size_t pitch_dst, void *stream) {
+    if (!y || !uv || !dst) return fail(VSTAB_ERR_INVALID, "vstab_cvt_nv12_bgr: null pointer");
+    if (width <= 0 || height <= 0 || (width & 1) || (height & 1))
+        return fail(VSTAB_ERR_INVALID, "vstab_cvt_nv12_bgr: width and height must be even");  // OpenCV asserts
+    if (pitch_y < (size_t)width || pitch_uv < (size_t)width || pitch_dst < (size_t)width * 3)
+        return fail(VSTAB_ERR_INVALID, "vstab_cvt_nv12_bgr: pitch smaller than row");
+    const int vec_ok = aligned(y, 8) && aligned(uv, 8) && aligned(dst, 8) && pitch_y % 8 == 0 &&
+                       pitch_uv % 8 == 0 && pitch_dst % 8 == 0;
+    dim3 block(32, 8);
+    dim3 grid(div_up(div_up(width, 8), 32), div_up(div_up(height, 2), 8));
+    hipLaunchKernelGGL(k_cvt_nv12_bgr, grid, block, 0, static_cast<hipStream_t>(stream), (const uint8_t *)y,
+                       pitch_y, (const uint8_t *)uv, pitch_uv, width, height, (uint8_t *)dst, pitch_dst, vec_ok);
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+vstab_status vstab_create_map(void *map_x, size_t pitch_x, void *map_y, size_t pitch_y, int cols, int rows,
+                              const float params[17], void *stream) {
+    if (!map_x || !map_y || !params) return fail(VSTAB_ERR_INVALID, "vstab_create_map: null pointer");
+    if (cols <= 0 || rows <= 0 || cols > 32767 || rows > 32767)
+        return fail(VSTAB_ERR_INVALID, "vstab_create_map: size must be in [1, 32767] (createMap.cl:10-11)");
+    if (pitch_x < (size_t)cols * 4 || pitch_y < (size_t)cols * 4 || pitch_x % 4 || pitch_y % 4)
+        return fail(VSTAB_ERR_INVALID, "vstab_create_map: bad pitch");
+    const int vec_ok = aligned(map_x, 16) && aligned(map_y, 16) && pitch_x % 16 == 0 && pitch_y % 16 == 0;
+    dim3 grid(div_up(div_up(cols, 4), 16), div_up(rows, 16));
+    hipLaunchKernelGGL(k_create_map, grid, dim3(16, 16), 0, static_cast<hipStream_t>(stream), (float *)map_x,
+                       pitch_x, (float *)map_y, pitch_y, cols, rows, to_params(params), vec_ok);
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+vstab_status vstab_remap_bilinear(const void *src, size_t pitch_src, int sw, int sh, int channels,
+                                  const void *map_x, size_t pitch_x, const void *map_y, size_t pitch_y,
+                                  void *dst, size_t pitch_dst, int dw, int dh, void *stream) {
+    if (!src || !map_x || !map_y || !dst) return fail(VSTAB_ERR_INVALID, "vstab_remap_bilinear: null pointer");
+    if (channels != 1 && channels != 3) return fail(VSTAB_ERR_INVALID, "vstab_remap_bilinear: channels must be 1 or 3");
+    if (sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || sw > 32767 || sh > 32767)
+        return fail(VSTAB_ERR_INVALID, "vstab_remap_bilinear: bad size");
+    if (pitch_src < (size_t)sw * channels || pitch_dst < (size_t)dw * channels || pitch_x < (size_t)dw * 4 ||
+        pitch_y < (size_t)dw * 4)
+        return fail(VSTAB_ERR_INVALID, "vstab_remap_bilinear: pitch smaller than row");
+    dim3 grid(div_up(dw, 64), div_up(dh, 4));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (channels == 3)
+        hipLaunchKernelGGL(k_remap_bilinear<3>, grid, dim3(64, 4), 0, s, (const uint8_t *)src, pitch_src, sw, sh,
+                           (const float *)map_x, pitch_x, (const float *)map_y, pitch_y, (uint8_t *)dst,
+                           pitch_dst, dw, dh);
+    else
+        hipLaunchKernelGGL(k_remap_bilinear<1>, grid, dim3(64, 4), 0, s, (const uint8_t *)src, pitch_src, sw, sh,
+                           (const float *)map_x, pitch_x, (const float *)map_y, pitch_y, (uint8_t *)dst,
+                           pitch_dst, dw, dh);
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh,
+                                 const float params[17], void *dst, size_t pitch_dst, int dw, int dh,
+                                 void *stream) {
+    if (!y || !uv || !dst || !params) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_bgr: null pointer");
+    if (sw <= 0 || sh <= 0 || (sw & 1) || (sh & 1) || sw > 32767 || sh > 32767)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_bgr: source must be even-sized and <= 32767");
+    if (dw <= 0 || dh <= 0 || dw > 32767 || dh > 32767)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_bgr: output size must be in [1, 32767]");
+    if (pitch_y < (size_t)sw || pitch_uv < (size_t)sw || pitch_dst < (size_t)dw * 3)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_bgr: pitch smaller than row");
+    if (!aligned(uv, 2) || pitch_uv % 2) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_bgr: chroma plane must be 2-B aligned");
+    WarpArgs a;
+    a.y = (const uint8_t *)y, a.uv = (const uint8_t *)uv, a.dst = (uint8_t *)dst;
+    a.pitch_y = pitch_y, a.pitch_uv = pitch_uv, a.pitch_dst = pitch_dst;
+    a.sw = sw, a.sh = sh, a.dw = dw, a.dh = dh;
+    a.p = to_params(params);
+    const int vec_ok = aligned(dst, 4) && pitch_dst % 4 == 0;
+    dim3 grid(div_up(dw, WARP_TILE_W), div_up(dh, WARP_TILE_H));
+    hipLaunchKernelGGL(k_warp_nv12_bgr, grid, dim3(16, 16), 0, static_cast<hipStream_t>(stream), a, vec_ok);
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+}  // extern "C"
