@@ -21,6 +21,10 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `make -C {_HERE}` (or __graft_entry__.build()); "
         "there is no CPU fallback for the HIP path")
 
+# PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the one already mapped when libvstab.so
+# resolves the same SONAME, or the process ends up with two HIP runtimes and no visible device.
+import torch  # noqa: E402,F401  (plumbing: device memory + streams)
+
 _L = ctypes.CDLL(LIB_PATH)
 
 OK, EOF, ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_SOURCE = 0, -1, -2, -3, -4, -5

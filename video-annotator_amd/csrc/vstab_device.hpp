@@ -103,11 +103,21 @@ __device__ __forceinline__ ChromaTerm chroma_term(int U, int V) {
 }
 __device__ __forceinline__ int sat8(int v) { return min(max(v, 0), 255); }
 
+// ROCm 7.2 hipcc folds `sat8(a >> 20) | sat8(b >> 20) << 8` into gfx950's v_ashr_pk_u8_i32 and
+// then ORs further bytes into the upper half of its result, which on MI355X is not zero (observed:
+// 0xFFFF for negative inputs -> wrong bytes 2,3).  The empty asm makes the shifted value opaque so
+// the clamp stays a plain v_med3_i32.
+__device__ __forceinline__ int ashr20(int v) {
+    v >>= 20;
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ void yuv_to_bgr(int Y, const ChromaTerm &c, int &b, int &g, int &r) {
     const int y = max(Y - 16, 0) * CY;
-    b = sat8((y + c.buv) >> 20);
-    g = sat8((y + c.guv) >> 20);
-    r = sat8((y + c.ruv) >> 20);
+    b = sat8(ashr20(y + c.buv));
+    g = sat8(ashr20(y + c.guv));
+    r = sat8(ashr20(y + c.ruv));
 }
 
 }  // namespace vstab
