@@ -69,6 +69,71 @@ __device__ __forceinline__ void map_pixel(const MapParams &p, const ColTerm &c, 
     my = p.icy + (py * k) * p.ify;                      // createMap.cl:49
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Hand-scheduled IEEE-754 binary32 primitives for the hot kernel.  Each returns exactly what the
+// correctly rounded operation returns for every finite, non-denormal-scaled input the map can
+// produce (they are the LLVM AMDGPU expansions of fdiv / fsqrt minus the denormal pre-scaling;
+// degenerate inputs -- 0, inf, NaN -- end in NaN or a huge value and the pixel is black either
+// way).  tools/probe_isa.hip checks them against `/` and sqrtf on the GPU.
+// ---------------------------------------------------------------------------------------------
+// refined reciprocal: v_rcp_f32 (1 ulp) + one Newton step
+__device__ __forceinline__ float rcp_refined(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+// n / d given r = rcp_refined(d): two residual corrections (Markstein), correctly rounded
+__device__ __forceinline__ float div_with_rcp(float n, float d, float r) {
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e, r, q);
+}
+// correctly rounded sqrt: v_sqrt_f32 (1 ulp) then pick among the three neighbours by residual sign
+__device__ __forceinline__ float sqrt_rn(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __int_as_float(__float_as_int(s) - 1), su = __int_as_float(__float_as_int(s) + 1);
+    const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+    s = rd <= 0.0f ? sd : s;
+    return ru > 0.0f ? su : s;
+}
+
+// createMap.cl:13-50 with the primitives above; returns 32*map (exact power-of-two scaling folded
+// into the constants: c32 = 32*src_center, f32 = 32*src_focal), i.e. the value cv::remap rounds.
+struct MapParams32 {
+    float icx32, icy32, ifx32, ify32;
+    float r02, r12, r22;
+};
+__device__ __forceinline__ void map_pixel32(const MapParams32 &p, const ColTerm &c, const RowTerm &r,
+                                            float &ax, float &ay) {
+    const float wx = (c.a0 + r.b0) + p.r02;
+    const float wy = (c.a1 + r.b1) + p.r12;
+    const float wz = (c.a2 + r.b2) + p.r22;
+    const float rz = rcp_refined(wz);
+    const float px = div_with_rcp(wx, wz, rz), py = div_with_rcp(wy, wz, rz);
+    const float rad = sqrt_rn(px * px + py * py);
+    const float rr = rcp_refined(rad);
+    // atan_pos(rad) with 1/rad from the shared refined reciprocal
+    const bool inv = rad > 1.0f;
+    const float t = inv ? div_with_rcp(1.0f, rad, rr) : rad;
+    const float s = t * t;
+    float q = 0.0028423243202269077f;
+    q = __builtin_fmaf(q, s, -0.016053270548582077f);
+    q = __builtin_fmaf(q, s, 0.04269874095916748f);
+    q = __builtin_fmaf(q, s, -0.07508683204650879f);
+    q = __builtin_fmaf(q, s, 0.1064559817314148f);
+    q = __builtin_fmaf(q, s, -0.14205896854400635f);
+    q = __builtin_fmaf(q, s, 0.19993145763874054f);
+    q = __builtin_fmaf(q, s, -0.33333125710487366f);
+    float at = __builtin_fmaf(t * s, q, t);
+    at = inv ? (1.57079637050628662109375f - at) + (-4.37113900018624283e-8f) : at;
+    const float k = div_with_rcp(at, rad, rr);
+    ax = p.icx32 + (px * k) * p.ifx32;
+    ay = p.icy32 + (py * k) * p.ify32;
+}
+
 // ---------------------------------------------------------------------------------------------
 // cv::remap coordinate quantisation (OpenCV 4.5 CPU path): sx = cvRound(map*32),
 // X = sx >> 5, f = sx & 31.  cvRound of NaN / out-of-int-range is INT_MIN on x86, which always
@@ -103,10 +168,12 @@ __device__ __forceinline__ ChromaTerm chroma_term(int U, int V) {
 }
 __device__ __forceinline__ int sat8(int v) { return min(max(v, 0), 255); }
 
-// ROCm 7.2 hipcc folds `sat8(a >> 20) | sat8(b >> 20) << 8` into gfx950's v_ashr_pk_u8_i32 and
-// then ORs further bytes into the upper half of its result, which on MI355X is not zero (observed:
-// 0xFFFF for negative inputs -> wrong bytes 2,3).  The empty asm makes the shifted value opaque so
-// the clamp stays a plain v_med3_i32.
+// gfx950's v_ashr_pk_u8_i32 D, S0, S1, n writes {sat_u8(S0 >> n), sat_u8(S1 >> n)} into ONE 16-bit
+// half of D (low half; high half with op_sel:[0,0,0,1]) and PRESERVES the other half (measured:
+// tools/probe_isa.hip).  ROCm 7.2 hipcc pattern-matches `sat8(a >> 20) | sat8(b >> 20) << 8` into
+// it but then assumes the other half is zero -> wrong bytes 2,3.  The empty asm below makes the
+// shifted value opaque so the generic path keeps a plain v_med3_i32; the tiled kernel uses the
+// instruction deliberately (pack_bgrx).
 __device__ __forceinline__ int ashr20(int v) {
     v >>= 20;
     asm volatile("" : "+v"(v));
@@ -118,6 +185,43 @@ __device__ __forceinline__ void yuv_to_bgr(int Y, const ChromaTerm &c, int &b, i
     b = sat8(ashr20(y + c.buv));
     g = sat8(ashr20(y + c.guv));
     r = sat8(ashr20(y + c.ruv));
+}
+
+
+// Chroma terms with the luma offset folded in: channel = sat8((max(Y,16)*CY + term) >> 20), which is
+// the same integer as sat8((max(Y-16,0)*CY + (1<<19) + C*uv) >> 20).
+__device__ __forceinline__ ChromaTerm chroma_term_folded(int U, int V) {
+    const int u = U - 128, v = V - 128;
+    constexpr int K = (1 << 19) - 16 * CY;
+    return {K + CVR * v, K + CVG * v + CUG * u, K + CUB * u};
+}
+
+// One BGRx pixel (byte 3 = 0) from a luma byte and folded chroma terms: 1 max + 3 mad + 2 pack.
+__device__ __forceinline__ uint32_t pack_bgrx(int Y, const ChromaTerm &c) {
+    const int y = max(Y, 16);
+    const int b = __mul24(y, CY) + c.buv, g = __mul24(y, CY) + c.guv, r = __mul24(y, CY) + c.ruv;
+    uint32_t d;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 20" : "=v"(d) : "v"(b), "v"(g));
+    asm("v_ashr_pk_u8_i32 %0, %1, 0, 20 op_sel:[0,0,0,1]" : "+v"(d) : "v"(r));
+    return d;
+}
+
+// cv::remap fixed-point bilinear blend of four BGRx taps:
+//   out_c = (p00*(32-fx)(32-fy) + p01*fx(32-fy) + p10*(32-fx)fy + p11*fx*fy + 512) >> 10
+// evaluated as an exact two-stage integer lerp (vertical on packed (B,R) 16-bit lanes, which
+// cannot overflow: 255*32 < 65536; then horizontal per channel).  Integer arithmetic is
+// distributive, so this equals the four-product sum bit for bit.  Returns 0x00RRGGBB.
+__device__ __forceinline__ uint32_t blend_bgrx(uint32_t t00, uint32_t t01, uint32_t t10, uint32_t t11,
+                                               uint32_t fx, uint32_t fy) {
+    const uint32_t gx = 32u - fx, gy = 32u - fy;
+    const uint32_t br0 = __umul24(t00 & 0x00FF00FFu, gy) + __umul24(t10 & 0x00FF00FFu, fy);
+    const uint32_t br1 = __umul24(t01 & 0x00FF00FFu, gy) + __umul24(t11 & 0x00FF00FFu, fy);
+    const uint32_t g0 = __umul24((t00 >> 8) & 255u, gy) + __umul24((t10 >> 8) & 255u, fy);
+    const uint32_t g1 = __umul24((t01 >> 8) & 255u, gy) + __umul24((t11 >> 8) & 255u, fy);
+    const uint32_t B = (__umul24(br0 & 0xFFFFu, gx) + __umul24(br1 & 0xFFFFu, fx) + 512u) >> 10;
+    const uint32_t R = (__umul24(br0 >> 16, gx) + __umul24(br1 >> 16, fx) + 512u) >> 10;
+    const uint32_t G = (__umul24(g0, gx) + __umul24(g1, fx) + 512u) >> 10;
+    return B | (G << 8) | (R << 16);
 }
 
 }  // namespace vstab

@@ -3,6 +3,9 @@
 //
 // All of this is HBM-bound byte/gather work (no MFMA): the design rules that matter are
 // coalesced wide accesses, enough workgroups to fill 256 CUs, and keeping the map in registers.
+#include <climits>
+#include <cstdlib>
+
 #include "vstab_device.hpp"
 #include "vstab_internal.hpp"
 
@@ -225,6 +228,170 @@ __global__ void __launch_bounds__(256) k_warp_nv12_bgr(WarpArgs a, int vec_ok) {
     }
 }
 
+// =============================================================================================
+// k_warp_tiled (v2) -- the fused hot kernel with an LDS-staged, pre-converted source tile.
+//
+// Per 64 x (16*RPT) output tile (256 threads, 4 columns x RPT rows per thread):
+//   phase 1  every thread evaluates the map for its pixels (hand-scheduled IEEE arithmetic,
+//            map_pixel32) and keeps the quantised coordinates sx, sy in registers; the bounding
+//            box of all taps of "inside" pixels is reduced wave-wide and merged through LDS.
+//   phase 2  the workgroup stages the bounding box of the NV12 source into LDS as BGRx dwords:
+//            coalesced dword loads of two luma rows + one chroma row per 4x2 block, the cvtColor
+//            arithmetic applied ONCE per source pixel (not once per tap), ds_write_b128.
+//   phase 3  four ds_read per pixel, exact fixed-point blend, 12-byte store per thread and row.
+// Pixels whose 2x2 footprint crosses the source border (per-tap zeroing, rare) and tiles whose
+// bounding box exceeds the LDS budget (degenerate rotations) take the direct-gather path, which
+// computes the same integers.  HBM traffic = the NV12 frame once + the BGR frame once.
+// =============================================================================================
+struct TiledArgs {
+    WarpArgs w;
+    MapParams32 p32;
+    int lds_capacity_px;  // dwords available for the staged tile
+    int src_vec_ok;       // planes and pitches 4-B aligned -> dword loads
+    int dst_vec_ok;
+};
+
+__device__ __forceinline__ uint32_t gather_pixel(const WarpArgs &a, int sx, int sy) {
+    const int X = sx >> 5, Y = sy >> 5;
+    const uint32_t fx = sx & 31, fy = sy & 31;
+    const int w00 = (32 - fx) * (32 - fy), w01 = fx * (32 - fy), w10 = (32 - fx) * fy, w11 = fx * fy;
+    int b0, g0, r0, b1, g1, r1, b2, g2, r2, b3, g3, r3;
+    fetch_tap(a, X, Y, b0, g0, r0);
+    fetch_tap(a, X + 1, Y, b1, g1, r1);
+    fetch_tap(a, X, Y + 1, b2, g2, r2);
+    fetch_tap(a, X + 1, Y + 1, b3, g3, r3);
+    const uint32_t B = (uint32_t)(b0 * w00 + b1 * w01 + b2 * w10 + b3 * w11 + 512) >> 10;
+    const uint32_t G = (uint32_t)(g0 * w00 + g1 * w01 + g2 * w10 + g3 * w11 + 512) >> 10;
+    const uint32_t R = (uint32_t)(r0 * w00 + r1 * w01 + r2 * w10 + r3 * w11 + 512) >> 10;
+    return B | (G << 8) | (R << 16);
+}
+
+__device__ __forceinline__ uint32_t load_u32_bytes(const uint8_t *p, int valid) {
+    uint32_t v = 0;
+    for (int i = 0; i < 4; i++)
+        if (i < valid) v |= (uint32_t)p[i] << (8 * i);
+    return v;
+}
+
+template <int RPT>
+__global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    int *bbox = reinterpret_cast<int *>(smem);  // minX, minY, maxX, maxY (16 B; keeps the tile 16-B aligned)
+    uint32_t *tile = smem + 4;
+    const WarpArgs &a = ta.w;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int x0 = blockIdx.x * WARP_TILE_W + tx * 4;
+    const int ybase = blockIdx.y * (16 * RPT) + ty;
+    if (tid == 0) bbox[0] = bbox[1] = INT_MAX, bbox[2] = bbox[3] = INT_MIN;
+
+    // ---------------- phase 1: map + quantise + classify -------------------------------------
+    int sx[RPT][4], sy[RPT][4];
+    uint32_t cls = 0;  // 2 bits per pixel: 0 black / not stored, 1 inside (LDS), 2 border (gather)
+    int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
+    {
+        ColTerm ct[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) ct[i] = col_term(a.p, x0 + i);
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+            const int y = ybase + 16 * j;
+            const RowTerm rt = row_term(a.p, y);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float ax, ay;
+                map_pixel32(ta.p32, ct[i], rt, ax, ay);
+                // |32*map| >= 2^22 (or NaN) is outside any source <= 32767 wide; see quantise()
+                const bool ok = (fabsf(ax) < 4194304.0f) && (fabsf(ay) < 4194304.0f) && (x0 + i < a.dw) && (y < a.dh);
+                const int qx = (int)__builtin_rintf(ax), qy = (int)__builtin_rintf(ay);
+                const int X = qx >> 5, Y = qy >> 5;
+                const bool inside = ok && (unsigned)X < (unsigned)(a.sw - 1) && (unsigned)Y < (unsigned)(a.sh - 1);
+                const bool touches = ok && X < a.sw && X + 1 >= 0 && Y < a.sh && Y + 1 >= 0;
+                sx[j][i] = qx, sy[j][i] = qy;
+                cls |= (inside ? 1u : touches ? 2u : 0u) << (2 * (j * 4 + i));
+                if (inside) mnx = min(mnx, X), mxx = max(mxx, X), mny = min(mny, Y), mxy = max(mxy, Y);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        mnx = min(mnx, __shfl_xor(mnx, m)), mny = min(mny, __shfl_xor(mny, m));
+        mxx = max(mxx, __shfl_xor(mxx, m)), mxy = max(mxy, __shfl_xor(mxy, m));
+    }
+    __syncthreads();  // bbox initialised
+    if ((tid & 63) == 0 && mnx <= mxx) {
+        atomicMin(&bbox[0], mnx), atomicMin(&bbox[1], mny), atomicMax(&bbox[2], mxx), atomicMax(&bbox[3], mxy);
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: stage the source bounding box as BGRx --------------------------
+    const int bx0 = bbox[0] & ~3, by0 = bbox[1] & ~1;
+    const int wb = (bbox[2] + 2 - bx0 + 3) & ~3, hb = (bbox[3] + 2 - by0 + 1) & ~1;  // taps reach max+1
+    const bool have = bbox[0] <= bbox[2];
+    const bool use_lds = have && wb * hb <= ta.lds_capacity_px;
+    if (use_lds) {
+        const int ux_n = wb >> 2, units = ux_n * (hb >> 1);
+        const uint32_t magic = (1u << 18) / (uint32_t)ux_n + 1u;  // u / ux_n == (u * magic) >> 18 for u < 2048
+        for (int u = tid; u < units; u += 256) {
+            const int uy = (int)(((uint32_t)u * magic) >> 18), ux = u - uy * ux_n;
+            const int gx = bx0 + 4 * ux, gy = by0 + 2 * uy;
+            const uint8_t *py0 = a.y + (size_t)gy * a.pitch_y + gx;
+            const uint8_t *puv = a.uv + (size_t)(gy >> 1) * a.pitch_uv + gx;
+            uint32_t y0w, y1w, uvw;
+            if (ta.src_vec_ok && gx + 4 <= a.sw) {
+                y0w = *reinterpret_cast<const uint32_t *>(py0);
+                y1w = *reinterpret_cast<const uint32_t *>(py0 + a.pitch_y);
+                uvw = *reinterpret_cast<const uint32_t *>(puv);
+            } else {
+                const int valid = min(4, a.sw - gx);
+                y0w = load_u32_bytes(py0, valid), y1w = load_u32_bytes(py0 + a.pitch_y, valid), uvw = load_u32_bytes(puv, valid);
+            }
+            const ChromaTerm c0 = chroma_term_folded(uvw & 255, (uvw >> 8) & 255);
+            const ChromaTerm c1 = chroma_term_folded((uvw >> 16) & 255, uvw >> 24);
+            uint4 r0, r1;
+            r0.x = pack_bgrx(y0w & 255, c0), r0.y = pack_bgrx((y0w >> 8) & 255, c0);
+            r0.z = pack_bgrx((y0w >> 16) & 255, c1), r0.w = pack_bgrx(y0w >> 24, c1);
+            r1.x = pack_bgrx(y1w & 255, c0), r1.y = pack_bgrx((y1w >> 8) & 255, c0);
+            r1.z = pack_bgrx((y1w >> 16) & 255, c1), r1.w = pack_bgrx(y1w >> 24, c1);
+            uint32_t *d = tile + (2 * uy) * wb + 4 * ux;
+            *reinterpret_cast<uint4 *>(d) = r0;
+            *reinterpret_cast<uint4 *>(d + wb) = r1;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 3: sample, blend, store ---------------------------------------------
+    if (x0 >= a.dw) return;
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+        const int y = ybase + 16 * j;
+        if (y >= a.dh) break;
+        uint32_t px[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t c = (cls >> (2 * (j * 4 + i))) & 3u;
+            uint32_t v = 0;
+            if (c == 1u && use_lds) {
+                const int idx = ((sy[j][i] >> 5) - by0) * wb + ((sx[j][i] >> 5) - bx0);
+                v = blend_bgrx(tile[idx], tile[idx + 1], tile[idx + wb], tile[idx + wb + 1], sx[j][i] & 31, sy[j][i] & 31);
+            } else if (c != 0u) {
+                v = gather_pixel(a, sx[j][i], sy[j][i]);
+            }
+            px[i] = v;
+        }
+        uint8_t *o = a.dst + (size_t)y * a.pitch_dst + (size_t)x0 * 3;
+        if (ta.dst_vec_ok && x0 + 4 <= a.dw) {
+            uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
+            o32[0] = px[0] | (px[1] << 24);
+            o32[1] = (px[1] >> 8) | (px[2] << 16);
+            o32[2] = (px[2] >> 16) | (px[3] << 8);
+        } else {
+            for (int i = 0; i < 4 && x0 + i < a.dw; i++) {
+                o[3 * i] = px[i] & 255, o[3 * i + 1] = (px[i] >> 8) & 255, o[3 * i + 2] = (px[i] >> 16) & 255;
+            }
+        }
+    }
+}
+
 static MapParams to_params(const float p[17]) {
     MapParams m;
     m.icx = p[0], m.icy = p[1], m.ifx = p[2], m.ify = p[3];
@@ -339,8 +506,22 @@ vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const void *uv, 
     a.sw = sw, a.sh = sh, a.dw = dw, a.dh = dh;
     a.p = to_params(params);
     const int vec_ok = aligned(dst, 4) && pitch_dst % 4 == 0;
-    dim3 grid(div_up(dw, WARP_TILE_W), div_up(dh, WARP_TILE_H));
-    hipLaunchKernelGGL(k_warp_nv12_bgr, grid, dim3(16, 16), 0, static_cast<hipStream_t>(stream), a, vec_ok);
+    static const int variant = getenv("VSTAB_WARP_VARIANT") ? atoi(getenv("VSTAB_WARP_VARIANT")) : 2;
+    if (variant == 1) {  // v1 direct-gather kernel (kept as the in-kernel fallback's twin, for A/B runs)
+        dim3 grid(div_up(dw, WARP_TILE_W), div_up(dh, WARP_TILE_H));
+        hipLaunchKernelGGL(k_warp_nv12_bgr, grid, dim3(16, 16), 0, static_cast<hipStream_t>(stream), a, vec_ok);
+    } else {
+        TiledArgs ta;
+        ta.w = a;
+        ta.p32 = {params[0] * 32.0f, params[1] * 32.0f, params[2] * 32.0f, params[3] * 32.0f, params[10], params[13], params[16]};
+        ta.src_vec_ok = aligned(y, 4) && aligned(uv, 4) && pitch_y % 4 == 0 && pitch_uv % 4 == 0;
+        ta.dst_vec_ok = vec_ok;
+        constexpr int RPT = 2;
+        const size_t lds_bytes = 40 * 1024;  // 4 workgroups (16 waves) per CU
+        ta.lds_capacity_px = (int)(lds_bytes / 4) - 4;
+        dim3 grid(div_up(dw, WARP_TILE_W), div_up(dh, 16 * RPT));
+        hipLaunchKernelGGL(k_warp_tiled<RPT>, grid, dim3(256), lds_bytes, static_cast<hipStream_t>(stream), ta);
+    }
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }
