@@ -249,6 +249,7 @@ struct TiledArgs {
     int lds_capacity_px;  // dwords available for the staged tile
     int src_vec_ok;       // planes and pitches 4-B aligned -> dword loads
     int dst_vec_ok;
+    int debug_mode;       // 0 = product; >0 = timing-only ablations (VSTAB_DEBUG_MODE, outputs wrong)
 };
 
 __device__ __forceinline__ uint32_t gather_pixel(const WarpArgs &a, int sx, int sy) {
@@ -328,7 +329,8 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
     const int wb = (bbox[2] + 2 - bx0 + 3) & ~3, hb = (bbox[3] + 2 - by0 + 1) & ~1;  // taps reach max+1
     const bool have = bbox[0] <= bbox[2];
     const bool use_lds = have && wb * hb <= ta.lds_capacity_px;
-    if (use_lds) {
+    const int dbg = ta.debug_mode;
+    if (use_lds && dbg != 1 && dbg != 3) {
         const int ux_n = wb >> 2, units = ux_n * (hb >> 1);
         const uint32_t magic = (1u << 18) / (uint32_t)ux_n + 1u;  // u / ux_n == (u * magic) >> 18 for u < 2048
         for (int u = tid; u < units; u += 256) {
@@ -370,7 +372,9 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
         for (int i = 0; i < 4; i++) {
             const uint32_t c = (cls >> (2 * (j * 4 + i))) & 3u;
             uint32_t v = 0;
-            if (c == 1u && use_lds) {
+            if (dbg == 1 || dbg == 2) {
+                v = (uint32_t)(sx[j][i] ^ sy[j][i]) ^ tile[tid];
+            } else if (c == 1u && use_lds) {
                 const int idx = ((sy[j][i] >> 5) - by0) * wb + ((sx[j][i] >> 5) - bx0);
                 v = blend_bgrx(tile[idx], tile[idx + 1], tile[idx + wb], tile[idx + wb + 1], sx[j][i] & 31, sy[j][i] & 31);
             } else if (c != 0u) {
@@ -516,6 +520,8 @@ vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const void *uv, 
         ta.p32 = {params[0] * 32.0f, params[1] * 32.0f, params[2] * 32.0f, params[3] * 32.0f, params[10], params[13], params[16]};
         ta.src_vec_ok = aligned(y, 4) && aligned(uv, 4) && pitch_y % 4 == 0 && pitch_uv % 4 == 0;
         ta.dst_vec_ok = vec_ok;
+        static const int dbg = getenv("VSTAB_DEBUG_MODE") ? atoi(getenv("VSTAB_DEBUG_MODE")) : 0;
+        ta.debug_mode = dbg;
         constexpr int RPT = 2;
         const size_t lds_bytes = 40 * 1024;  // 4 workgroups (16 waves) per CU
         ta.lds_capacity_px = (int)(lds_bytes / 4) - 4;
