@@ -110,6 +110,143 @@ VSTAB_API vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const 
                                            const float params[17], void *dst_bgr, size_t pitch_dst,
                                            int dst_width, int dst_height, void *stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Tracking front-end (device images in; small point lists on the host, as in the reference where
+ * goodFeaturesToTrack / calcOpticalFlowPyrLK return std::vector<Point2f>).  These calls
+ * synchronise `stream` before returning because their outputs live in host memory.
+ * ------------------------------------------------------------------------------------------ */
+
+/* cv::pyrDown (5x5 binomial, REFLECT_101) as used for the LK pyramid; dst is ((w+1)/2, (h+1)/2). */
+VSTAB_API vstab_status vstab_pyr_down(const void *src, size_t pitch_src, int width, int height,
+                                      void *dst, size_t pitch_dst, void *stream);
+
+/* cornerMinEigenVal(blockSize 3, ksize 3): dense width x height float response (device). */
+VSTAB_API vstab_status vstab_min_eig(const void *gray, size_t pitch, int width, int height,
+                                     void *eig_f32, void *stream);
+
+/* Replaces find_corners -> goodFeaturesToTrack(gray, max_corners, quality, min_distance),
+ * FrameSourceWarp.cpp:228-240 (the reference passes 200, 0.01, 30).  xy receives up to
+ * max_corners (x,y) float pairs in acceptance order; *count the number found. */
+VSTAB_API vstab_status vstab_good_features(const void *gray, size_t pitch, int width, int height,
+                                           int max_corners, double quality, double min_distance,
+                                           float *xy, int *count, void *stream);
+
+/* Replaces calcOpticalFlowPyrLK with default parameters (win 21x21, maxLevel 3, 30 iterations,
+ * eps 0.01, minEigThreshold 1e-4), FrameSourceWarp.cpp:252.  prev/next: device gray images of the
+ * same size; prev_xy: n host (x,y) pairs; next_xy / status: host outputs (n pairs / n bytes). */
+VSTAB_API vstab_status vstab_pyr_lk(const void *prev, size_t pitch_prev, const void *next,
+                                    size_t pitch_next, int width, int height, const float *prev_xy,
+                                    int n, float *next_xy, unsigned char *status, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side motion model.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Replaces guess_camera_rotation, FrameSourceWarp.cpp:316-375: undistort both point sets, random
+ * depths (seeded PCG32 instead of the reference's un-seeded rand()), PnP-RANSAC (100 iterations,
+ * 8 px, 0.99), Rodrigues.  prev_xy/cur_xy: n (x,y) float pairs in input pixels.  R: row-major
+ * rotation since the last frame; *inliers: RANSAC inlier count (the reference's return value). */
+VSTAB_API vstab_status vstab_estimate_rotation(const float *prev_xy, const float *cur_xy, int n,
+                                               const double K_in[9], const double K_out[9],
+                                               uint64_t seed, double R[9], int *inliers);
+
+/* Savitzky-Golay weights of gram_sg::SavitzkyGolayFilterConfig(m, 0, 2, 0) (:212): 2m+1 doubles. */
+VSTAB_API vstab_status vstab_sg_weights(int m, double *weights);
+
+/* gram_sg::RotationFilter replacement (:212,444,459,471): ring of 2m+1 matrices that starts
+ * zero-filled; filter() = polar factor U*V^T of the weighted sum. */
+typedef struct vstab_rotation_filter vstab_rotation_filter;
+VSTAB_API vstab_status vstab_rotation_filter_create(int m, vstab_rotation_filter **out);
+VSTAB_API vstab_status vstab_rotation_filter_add(vstab_rotation_filter *f, const double R[9]);
+VSTAB_API vstab_status vstab_rotation_filter_filter(const vstab_rotation_filter *f, double R_out[9]);
+VSTAB_API void vstab_rotation_filter_destroy(vstab_rotation_filter *f);
+
+/* ------------------------------------------------------------------------------------------
+ * The pipeline object: drop-in for FrameSourceWarp behind the FrameSource pull interface
+ * (FrameSource.hpp:9-24, FrameSourceWarp.hpp:83-91).
+ * ------------------------------------------------------------------------------------------ */
+
+/* One NV12 frame handed over by the upstream source (what FrameSourceFfmpegOpenCl produces,
+ * FrameSourceFfmpegOpenCl.cpp:58-85).  A packed (h*3/2 x w) buffer is uv = y + pitch_y*height.
+ * The planes only need to stay valid until the callback is called again or the handle is
+ * destroyed: the library copies them into its own HBM ring before returning from pull. */
+typedef struct vstab_frame {
+    const void *y;
+    const void *uv;
+    size_t pitch_y, pitch_uv;
+    int width, height; /* luma size; both even */
+    int mem;           /* 0 = device memory, 1 = host memory */
+    int64_t pts;
+} vstab_frame;
+
+/* Upstream FrameSource (FrameSource.hpp:14,20): return 0 and fill *out, VSTAB_EOF (-1) at end of
+ * stream, any other value on failure (propagated as VSTAB_ERR_SOURCE, like a rethrown int). */
+typedef struct vstab_source {
+    int (*pull)(void *user, vstab_frame *out);
+    int (*peek)(void *user, vstab_frame *out);
+    void *user;
+} vstab_source;
+
+enum { VSTAB_SMOOTHER_SG = 0, VSTAB_SMOOTHER_KALMAN = 1, VSTAB_SMOOTHER_NONE = 2 };
+
+/* Constructor arguments of FrameSourceWarp (FrameSourceWarp.hpp:83-91) plus what the reference
+ * hard-codes.  vstab_config_default fills the reference's defaults. */
+typedef struct vstab_config {
+    int preset;          /* vstab_camera_preset */
+    double scale;        /* 1 */
+    int crop_borders;    /* 0 */
+    double zoom;         /* 1 */
+    int smooth_radius;   /* 30 */
+    int interpolation;   /* 1 = INTER_LINEAR (only mode the reference ever passes) */
+    int smoother;        /* VSTAB_SMOOTHER_SG (reference behaviour) */
+    int tracking;        /* 1; 0 = undistort only: rotations are identity (BASELINE config 1) */
+    uint64_t seed;       /* PCG32 seed replacing the reference's un-seeded rand() */
+    void *stream;        /* hipStream_t all work of this handle is enqueued on; NULL = default stream */
+} vstab_config;
+
+typedef struct vstab_handle vstab_handle;
+
+VSTAB_API void vstab_config_default(vstab_config *cfg);
+/* FrameSourceWarp::FrameSourceWarp (:199-226): peeks the first upstream frame for the size,
+ * derives both cameras, allocates the look-ahead ring in HBM. */
+VSTAB_API vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vstab_handle **out);
+VSTAB_API vstab_status vstab_get_output_info(const vstab_handle *h, int *width, int *height,
+                                             double K_in[9], double K_out[9]);
+/* FrameSourceWarp::pull_frame (:452-476): consumes upstream frames until smooth_radius+1 are
+ * buffered (or EOF), then warps the oldest buffered frame into dst (device BGR8).  Returns
+ * VSTAB_EOF when the stream is drained.  The first input frame is never emitted (:403-407).
+ * Work is enqueued on the handle's stream; dst is complete after that stream is synchronised. */
+VSTAB_API vstab_status vstab_pull_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
+/* FrameSourceWarp::peek_frame (:478-480) IS pull_frame in the reference (destructive); kept. */
+VSTAB_API vstab_status vstab_peek_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
+VSTAB_API void vstab_destroy(vstab_handle *h);
+
+/* Introspection for parity tests and profiling: what consume_frame (:397-450) decided for the
+ * index-th consumed frame that produced a rotation (index 0 = second input frame). */
+typedef struct vstab_frame_log {
+    int key_frame;       /* corners re-detected before tracking this frame (:415-419) */
+    int n_corners;       /* corners fed to the tracker */
+    int n_tracked;       /* pairs with status != 0 (:263-268) */
+    int n_inliers;       /* guess_camera_rotation's return value */
+    int fallback;        /* 1 if n_inliers < 40 and the previous rotation / identity was reused (:432-438) */
+    double R_frame[9];   /* rotation since last frame actually used */
+    double R_accum[9];   /* accumulated measured rotation (:441-442) */
+} vstab_frame_log;
+VSTAB_API int vstab_frame_log_count(const vstab_handle *h);
+VSTAB_API vstab_status vstab_get_frame_log(const vstab_handle *h, int index, vstab_frame_log *out);
+/* The rotation handed to the warp for the index-th emitted frame (rotation_correction.inv(), :475). */
+VSTAB_API vstab_status vstab_get_warp_rotation(const vstab_handle *h, int index, double R[9]);
+
+/* Utility upstream source for benchmarks and tests: cycles over n_frames caller-owned device
+ * frames (packed NV12, same size) for total_frames pulls, then reports EOF.  Plays the role of
+ * the decode chain upstream of FrameSourceWarp (DisplayImage.cpp:42-53), which is out of scope. */
+typedef struct vstab_ring_source vstab_ring_source;
+VSTAB_API vstab_status vstab_ring_source_create(const void *const *frames, int n_frames, int width, int height,
+                                                size_t pitch, long total_frames, vstab_ring_source **out,
+                                                vstab_source *as_source);
+VSTAB_API void vstab_ring_source_destroy(vstab_ring_source *s);
+
 #ifdef __cplusplus
 }
 #endif

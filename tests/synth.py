@@ -52,3 +52,63 @@ def shifted(img, dx, dy):
     f = img.astype(np.float64)
     v = (f[y0, x0] * (1 - fx) + f[y0, x0 + 1] * fx) * (1 - fy) + (f[y0 + 1, x0] * (1 - fx) + f[y0 + 1, x0 + 1] * fx) * fy
     return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic shaky clips with known camera rotations (fisheye forward model)
+# ---------------------------------------------------------------------------------------------
+def sphere_texture(seed, tw=2048, th=1024):
+    """Equirectangular luma texture: value noise + rectangles (trackable corners)."""
+    return luma(seed, tw, th, rects=260).astype(np.float32)
+
+
+def fisheye_rays(K, w, h):
+    """Unit rays of every pixel of an equidistant fisheye camera (theta = |(x-c)/f|)."""
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    px, py = (xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1]
+    th = np.hypot(px, py)
+    s = np.where(th > 1e-12, np.sin(th) / np.maximum(th, 1e-12), 1.0)
+    return np.stack([px * s, py * s, np.cos(th)], axis=-1)
+
+
+def fisheye_project(K, rays):
+    """Inverse of fisheye_rays for arbitrary rays (n,3) -> pixels (n,2)."""
+    x, y, z = rays[:, 0], rays[:, 1], rays[:, 2]
+    r = np.hypot(x, y)
+    th = np.arctan2(r, z)
+    s = np.where(r > 1e-12, th / np.maximum(r, 1e-12), 1.0)
+    return np.stack([K[0, 2] + K[0, 0] * x * s, K[1, 2] + K[1, 1] * y * s], axis=-1)
+
+
+def render_frame(tex, rays, R):
+    """Luma of the frame seen by a camera with orientation R (d_cam = R d_world)."""
+    d = rays @ R  # rows: R^T d_cam
+    lon = np.arctan2(d[..., 0], d[..., 2])
+    lat = np.arcsin(np.clip(d[..., 1], -1, 1))
+    th, tw = tex.shape
+    u = (lon / (2 * np.pi) + 0.5) * (tw - 1)
+    v = (lat / np.pi + 0.5) * (th - 1)
+    u0, v0 = np.clip(u.astype(int), 0, tw - 2), np.clip(v.astype(int), 0, th - 2)
+    fu, fv = u - u0, v - v0
+    val = (tex[v0, u0] * (1 - fu) + tex[v0, u0 + 1] * fu) * (1 - fv) + (tex[v0 + 1, u0] * (1 - fu) + tex[v0 + 1, u0 + 1] * fu) * fv
+    return np.clip(np.rint(val), 0, 255).astype(np.uint8)
+
+
+def shaky_clip(seed, K, w, h, n, sigma=0.004):
+    """n packed NV12 frames + the camera orientations R_k (random walk, sigma rad/frame/axis)."""
+    import oracle
+    rng = np.random.default_rng(seed)
+    tex = sphere_texture(seed)
+    rays = fisheye_rays(K, w, h)
+    R = np.eye(3)
+    frames, rots = [], []
+    for k in range(n):
+        if k:
+            R = oracle.rodrigues(rng.normal(0, sigma, 3)) @ R
+        f = np.empty((h * 3 // 2, w), np.uint8)
+        f[:h] = render_frame(tex, rays, R)
+        f[h:] = 128
+        f[h:, ::2] = (100 + 40 * np.sin(np.arange(w // 2) / 17.0 + k)).astype(np.uint8)[None, :]
+        frames.append(f)
+        rots.append(R.copy())
+    return frames, rots

@@ -36,6 +36,34 @@ _c = ctypes
 _vp, _sz, _i, _d = _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_double
 _dp, _fp, _ip = _c.POINTER(_c.c_double), _c.POINTER(_c.c_float), _c.POINTER(_c.c_int)
 
+_u8p, _i64, _u64 = _c.POINTER(_c.c_ubyte), _c.c_int64, _c.c_uint64
+
+
+class Frame(_c.Structure):  # vstab_frame
+    _fields_ = [("y", _vp), ("uv", _vp), ("pitch_y", _sz), ("pitch_uv", _sz), ("width", _i), ("height", _i),
+                ("mem", _i), ("pts", _i64)]
+
+
+PULL_FN = _c.CFUNCTYPE(_i, _vp, _c.POINTER(Frame))
+
+
+class Source(_c.Structure):  # vstab_source
+    _fields_ = [("pull", PULL_FN), ("peek", PULL_FN), ("user", _vp)]
+
+
+class Config(_c.Structure):  # vstab_config
+    _fields_ = [("preset", _i), ("scale", _d), ("crop_borders", _i), ("zoom", _d), ("smooth_radius", _i),
+                ("interpolation", _i), ("smoother", _i), ("tracking", _i), ("seed", _u64), ("stream", _vp)]
+
+
+class FrameLog(_c.Structure):  # vstab_frame_log
+    _fields_ = [("key_frame", _i), ("n_corners", _i), ("n_tracked", _i), ("n_inliers", _i), ("fallback", _i),
+                ("R_frame", _d * 9), ("R_accum", _d * 9)]
+
+
+SMOOTHER_SG, SMOOTHER_KALMAN, SMOOTHER_NONE = 0, 1, 2
+_pp = _c.POINTER(_vp)
+
 # name -> (restype, argtypes); mirrors include/vstab.h one to one
 SIGNATURES = {
     "vstab_last_error": (_c.c_char_p, []),
@@ -50,6 +78,27 @@ SIGNATURES = {
     "vstab_create_map": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _vp]),
     "vstab_remap_bilinear": (_i, [_vp, _sz, _i, _i, _i, _vp, _sz, _vp, _sz, _vp, _sz, _i, _i, _vp]),
     "vstab_warp_nv12_bgr": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _vp, _sz, _i, _i, _vp]),
+    "vstab_pyr_down": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp]),
+    "vstab_min_eig": (_i, [_vp, _sz, _i, _i, _vp, _vp]),
+    "vstab_good_features": (_i, [_vp, _sz, _i, _i, _i, _d, _d, _fp, _ip, _vp]),
+    "vstab_pyr_lk": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _fp, _u8p, _vp]),
+    "vstab_estimate_rotation": (_i, [_fp, _fp, _i, _dp, _dp, _u64, _dp, _ip]),
+    "vstab_sg_weights": (_i, [_i, _dp]),
+    "vstab_rotation_filter_create": (_i, [_i, _pp]),
+    "vstab_rotation_filter_add": (_i, [_vp, _dp]),
+    "vstab_rotation_filter_filter": (_i, [_vp, _dp]),
+    "vstab_rotation_filter_destroy": (None, [_vp]),
+    "vstab_config_default": (None, [_c.POINTER(Config)]),
+    "vstab_create": (_i, [_c.POINTER(Config), _c.POINTER(Source), _pp]),
+    "vstab_get_output_info": (_i, [_vp, _ip, _ip, _dp, _dp]),
+    "vstab_pull_frame": (_i, [_vp, _vp, _sz]),
+    "vstab_peek_frame": (_i, [_vp, _vp, _sz]),
+    "vstab_destroy": (None, [_vp]),
+    "vstab_frame_log_count": (_i, [_vp]),
+    "vstab_get_frame_log": (_i, [_vp, _i, _c.POINTER(FrameLog)]),
+    "vstab_get_warp_rotation": (_i, [_vp, _i, _dp]),
+    "vstab_ring_source_create": (_i, [_pp, _i, _i, _i, _sz, _c.c_long, _pp, _c.POINTER(Source)]),
+    "vstab_ring_source_destroy": (None, [_vp]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _f = getattr(_L, _name)  # AttributeError here = header/library mismatch: fail loudly
@@ -193,3 +242,187 @@ def warp_nv12_bgr(nv12, params, dw, dh, out=None):
     _check(_L.vstab_warp_nv12_bgr(yp, pitch, uvp, pitch, w, h, _fptr(p), out.data_ptr(), out.stride(0), dw, dh,
                                   _stream()), "vstab_warp_nv12_bgr")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# tracking front-end / motion model
+# ---------------------------------------------------------------------------------------------
+def pyr_down(img):
+    import torch
+    h, w = img.shape
+    out = torch.empty(((h + 1) // 2, (w + 1) // 2), dtype=torch.uint8, device=img.device)
+    _check(_L.vstab_pyr_down(img.data_ptr(), img.stride(0), w, h, out.data_ptr(), out.stride(0), _stream()), "vstab_pyr_down")
+    return out
+
+
+def min_eig(gray):
+    import torch
+    h, w = gray.shape
+    out = torch.empty((h, w), dtype=torch.float32, device=gray.device)
+    _check(_L.vstab_min_eig(gray.data_ptr(), gray.stride(0), w, h, out.data_ptr(), _stream()), "vstab_min_eig")
+    return out
+
+
+def good_features(gray, max_corners=200, quality=0.01, min_distance=30.0):
+    h, w = gray.shape
+    xy = np.zeros((max_corners, 2), np.float32)
+    n = _c.c_int()
+    _check(_L.vstab_good_features(gray.data_ptr(), gray.stride(0), w, h, max_corners, quality, min_distance, _fptr(xy),
+                                  _c.byref(n), _stream()), "vstab_good_features")
+    return xy[:n.value].copy()
+
+
+def pyr_lk(prev, nxt, pts):
+    h, w = prev.shape
+    p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    n = p.shape[0]
+    out = np.zeros((n, 2), np.float32)
+    st = np.zeros(n, np.uint8)
+    _check(_L.vstab_pyr_lk(prev.data_ptr(), prev.stride(0), nxt.data_ptr(), nxt.stride(0), w, h, _fptr(p), n, _fptr(out),
+                           st.ctypes.data_as(_u8p), _stream()), "vstab_pyr_lk")
+    return out, st
+
+
+def estimate_rotation(prev_xy, cur_xy, K_in, K_out, seed=1):
+    a = np.ascontiguousarray(prev_xy, np.float32).reshape(-1, 2)
+    b = np.ascontiguousarray(cur_xy, np.float32).reshape(-1, 2)
+    Ki = np.ascontiguousarray(K_in, np.float64).reshape(9)
+    Ko = np.ascontiguousarray(K_out, np.float64).reshape(9)
+    R = np.zeros(9)
+    inl = _c.c_int()
+    _check(_L.vstab_estimate_rotation(_fptr(a), _fptr(b), a.shape[0], _dptr(Ki), _dptr(Ko), seed, _dptr(R), _c.byref(inl)),
+           "vstab_estimate_rotation")
+    return R.reshape(3, 3), inl.value
+
+
+def sg_weights(m):
+    w = np.zeros(2 * m + 1)
+    _check(_L.vstab_sg_weights(m, _dptr(w)), "vstab_sg_weights")
+    return w
+
+
+class RotationFilter:
+    def __init__(self, m):
+        self._h = _vp()
+        _check(_L.vstab_rotation_filter_create(m, _c.byref(self._h)), "vstab_rotation_filter_create")
+
+    def add(self, R):
+        r = np.ascontiguousarray(R, np.float64).reshape(9)
+        _check(_L.vstab_rotation_filter_add(self._h, _dptr(r)), "vstab_rotation_filter_add")
+
+    def filter(self):
+        out = np.zeros(9)
+        _check(_L.vstab_rotation_filter_filter(self._h, _dptr(out)), "vstab_rotation_filter_filter")
+        return out.reshape(3, 3)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _L is not None:
+            _L.vstab_rotation_filter_destroy(self._h)
+            self._h = None
+
+
+# ---------------------------------------------------------------------------------------------
+# the pipeline object (FrameSourceWarp replacement)
+# ---------------------------------------------------------------------------------------------
+def default_config(**kw):
+    cfg = Config()
+    _L.vstab_config_default(_c.byref(cfg))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+class Stabilizer:
+    """vstab_handle wrapper.  `frames`: list of packed NV12 CUDA tensors (cycled by the C ring
+    source for `total` pulls) or a Python iterable of such tensors (python callback source)."""
+
+    def __init__(self, frames, total=None, use_torch_stream=True, **cfg_kw):
+        import torch
+        self._keep = []
+        self._src = Source()
+        self._ring = None
+        if isinstance(frames, (list, tuple)):
+            f0 = frames[0]
+            rows, w = f0.shape
+            h = rows * 2 // 3
+            ptrs = (_vp * len(frames))(*[f.data_ptr() for f in frames])
+            self._keep += [frames, ptrs]
+            self._ring = _vp()
+            _check(_L.vstab_ring_source_create(ptrs, len(frames), w, h, f0.stride(0), len(frames) if total is None else total,
+                                               _c.byref(self._ring), _c.byref(self._src)), "vstab_ring_source_create")
+        else:
+            it = iter(frames)
+            state = {"next": None, "done": False}
+
+            def fill(out, advance):
+                if state["next"] is None and not state["done"]:
+                    try:
+                        state["next"] = next(it)
+                    except StopIteration:
+                        state["done"] = True
+                if state["next"] is None:
+                    return EOF
+                f = state["next"]
+                yp, uvp, pitch, w, h = _planes(f)
+                o = out.contents
+                o.y, o.uv, o.pitch_y, o.pitch_uv, o.width, o.height, o.mem, o.pts = yp, uvp, pitch, pitch, w, h, 0, 0
+                if advance:
+                    self._keep.append(f)
+                    if len(self._keep) > 8:
+                        self._keep.pop(0)
+                    state["next"] = None
+                return 0
+            self._pull = PULL_FN(lambda user, out: fill(out, True))
+            self._peek = PULL_FN(lambda user, out: fill(out, False))
+            self._src.pull, self._src.peek, self._src.user = self._pull, self._peek, None
+        cfg = default_config(**cfg_kw)
+        if use_torch_stream:
+            cfg.stream = torch.cuda.current_stream().cuda_stream
+        self._h = _vp()
+        _check(_L.vstab_create(_c.byref(cfg), _c.byref(self._src), _c.byref(self._h)), "vstab_create")
+        ow, oh = _c.c_int(), _c.c_int()
+        Ki, Ko = np.zeros(9), np.zeros(9)
+        _check(_L.vstab_get_output_info(self._h, _c.byref(ow), _c.byref(oh), _dptr(Ki), _dptr(Ko)), "vstab_get_output_info")
+        self.out_size = (ow.value, oh.value)
+        self.K_in, self.K_out = Ki.reshape(3, 3), Ko.reshape(3, 3)
+
+    def pull_into(self, out, timing=None):
+        """Returns True, or False at end of stream (the reference throws EOF)."""
+        st = _L.vstab_pull_frame(self._h, out.data_ptr(), out.stride(0))
+        if st == EOF:
+            return False
+        _check(st, "vstab_pull_frame")
+        return True
+
+    def pull(self):
+        import torch
+        out = torch.empty((self.out_size[1], self.out_size[0], 3), dtype=torch.uint8, device="cuda")
+        return out if self.pull_into(out) else None
+
+    def frame_log(self):
+        out = []
+        for i in range(_L.vstab_frame_log_count(self._h)):
+            lg = FrameLog()
+            _check(_L.vstab_get_frame_log(self._h, i, _c.byref(lg)), "vstab_get_frame_log")
+            out.append(dict(key=bool(lg.key_frame), n_corners=lg.n_corners, n_tracked=lg.n_tracked, inliers=lg.n_inliers,
+                            fallback=bool(lg.fallback), R=np.array(lg.R_frame).reshape(3, 3),
+                            R_accum=np.array(lg.R_accum).reshape(3, 3)))
+        return out
+
+    def warp_rotation(self, i):
+        R = np.zeros(9)
+        _check(_L.vstab_get_warp_rotation(self._h, i, _dptr(R)), "vstab_get_warp_rotation")
+        return R.reshape(3, 3)
+
+    def close(self):
+        if _L is None:
+            return
+        if getattr(self, "_h", None):
+            _L.vstab_destroy(self._h)
+            self._h = None
+        if getattr(self, "_ring", None):
+            _L.vstab_ring_source_destroy(self._ring)
+            self._ring = None
+
+    def __del__(self):
+        self.close()

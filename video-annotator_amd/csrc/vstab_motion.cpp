@@ -1,0 +1,304 @@
+// vstab_motion.cpp -- rotation estimation (guess_camera_rotation, FrameSourceWarp.cpp:316-375)
+// and trajectory smoothing (gram_sg::RotationFilter, :212,444,459,471) on the host, fp64.
+// The data is <= 200 points / one 3x3 matrix per frame, exactly as small as in the reference,
+// which also runs these steps on the host.
+#include "vstab_motion.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace vstab {
+
+Mat3 rodrigues(const double rv[3]) {
+    const double th = std::sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    if (th < DBL_EPSILON) return Mat3::identity();
+    const double k[3] = {rv[0] / th, rv[1] / th, rv[2] / th};
+    const double c = std::cos(th), s = std::sin(th), c1 = 1 - c;
+    Mat3 R;
+    R(0, 0) = c + c1 * k[0] * k[0], R(0, 1) = c1 * k[0] * k[1] - s * k[2], R(0, 2) = c1 * k[0] * k[2] + s * k[1];
+    R(1, 0) = c1 * k[0] * k[1] + s * k[2], R(1, 1) = c + c1 * k[1] * k[1], R(1, 2) = c1 * k[1] * k[2] - s * k[0];
+    R(2, 0) = c1 * k[0] * k[2] - s * k[1], R(2, 1) = c1 * k[1] * k[2] + s * k[0], R(2, 2) = c + c1 * k[2] * k[2];
+    return R;
+}
+
+void rodrigues_inv(const Mat3 &R, double rv[3]) {
+    const double cs = std::min(1.0, std::max(-1.0, (R(0, 0) + R(1, 1) + R(2, 2) - 1) * 0.5));
+    const double th = std::acos(cs);
+    const double ax[3] = {R(2, 1) - R(1, 2), R(0, 2) - R(2, 0), R(1, 0) - R(0, 1)};
+    const double sn = 0.5 * std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    if (sn < 1e-12) {
+        if (cs > 0) {
+            rv[0] = rv[1] = rv[2] = 0;
+        } else {  // rotation by pi: axis from the diagonal
+            double v[3] = {std::sqrt(std::max(0.0, (R(0, 0) + 1) * 0.5)), std::sqrt(std::max(0.0, (R(1, 1) + 1) * 0.5)),
+                           std::sqrt(std::max(0.0, (R(2, 2) + 1) * 0.5))};
+            if (R(0, 1) < 0) v[1] = -v[1];
+            if (R(0, 2) < 0) v[2] = -v[2];
+            for (int i = 0; i < 3; i++) rv[i] = v[i] * th;
+        }
+        return;
+    }
+    const double f = th / (2 * sn);
+    for (int i = 0; i < 3; i++) rv[i] = ax[i] * f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Perspective-n-point by Levenberg-Marquardt on the reprojection error.  The reference calls
+// OpenCV's solvePnPRansac (EPnP on 5-point samples + SOLVEPNP_ITERATIVE refit); that library is
+// not available, and the reference's result is not reproducible anyway (un-seeded rand() feeds
+// the depths, F6), so parity for this step is by ground truth, not bitwise.  Inter-frame motion is
+// small, so identity is always a good starting point for the minimal solver.
+// ---------------------------------------------------------------------------------------------
+struct Pose {
+    Mat3 R = Mat3::identity();
+    double t[3] = {0, 0, 0};
+};
+
+static inline void project(const Pose &p, const double X[3], double f, double cx, double cy, double out[2], double Y[3]) {
+    for (int r = 0; r < 3; r++) Y[r] = p.R(r, 0) * X[0] + p.R(r, 1) * X[1] + p.R(r, 2) * X[2] + p.t[r];
+    out[0] = f * Y[0] / Y[2] + cx, out[1] = f * Y[1] / Y[2] + cy;
+}
+
+static bool solve6(double A[36], double b[6]) {  // Gaussian elimination with partial pivoting, in place
+    for (int c = 0; c < 6; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 6; r++)
+            if (std::fabs(A[r * 6 + c]) > std::fabs(A[piv * 6 + c])) piv = r;
+        if (std::fabs(A[piv * 6 + c]) < 1e-300) return false;
+        if (piv != c) {
+            for (int k = 0; k < 6; k++) std::swap(A[c * 6 + k], A[piv * 6 + k]);
+            std::swap(b[c], b[piv]);
+        }
+        for (int r = c + 1; r < 6; r++) {
+            const double m = A[r * 6 + c] / A[c * 6 + c];
+            for (int k = c; k < 6; k++) A[r * 6 + k] -= m * A[c * 6 + k];
+            b[r] -= m * b[c];
+        }
+    }
+    for (int c = 5; c >= 0; c--) {
+        for (int k = c + 1; k < 6; k++) b[c] -= A[c * 6 + k] * b[k];
+        b[c] /= A[c * 6 + c];
+    }
+    return true;
+}
+
+static double reproj_cost(const Pose &p, const double *obj, const float *img, const int *idx, int n, double f, double cx,
+                          double cy) {
+    double cost = 0;
+    for (int i = 0; i < n; i++) {
+        const int k = idx ? idx[i] : i;
+        double u[2], Y[3];
+        project(p, obj + 3 * k, f, cx, cy, u, Y);
+        const double ex = u[0] - img[2 * k], ey = u[1] - img[2 * k + 1];
+        cost += ex * ex + ey * ey;
+    }
+    return cost;
+}
+
+static bool solve_pnp_lm(const double *obj, const float *img, const int *idx, int n, double f, double cx, double cy,
+                         Pose &pose, int max_iter) {
+    double lambda = 1e-3;
+    double cost = reproj_cost(pose, obj, img, idx, n, f, cx, cy);
+    if (!std::isfinite(cost)) return false;
+    for (int it = 0; it < max_iter; it++) {
+        double JtJ[36] = {0}, Jtr[6] = {0};
+        for (int i = 0; i < n; i++) {
+            const int k = idx ? idx[i] : i;
+            double u[2], Y[3];
+            project(pose, obj + 3 * k, f, cx, cy, u, Y);
+            const double ex = u[0] - img[2 * k], ey = u[1] - img[2 * k + 1];
+            const double iz = 1.0 / Y[2];
+            const double RX[3] = {Y[0] - pose.t[0], Y[1] - pose.t[1], Y[2] - pose.t[2]};
+            // d(pi)/dY
+            const double a[2][3] = {{f * iz, 0, -f * Y[0] * iz * iz}, {0, f * iz, -f * Y[1] * iz * iz}};
+            // dY/d(omega) = -[RX]x ; dY/dt = I
+            const double S[3][3] = {{0, RX[2], -RX[1]}, {-RX[2], 0, RX[0]}, {RX[1], -RX[0], 0}};
+            double J[2][6];
+            for (int r = 0; r < 2; r++) {
+                for (int c = 0; c < 3; c++) J[r][c] = a[r][0] * S[0][c] + a[r][1] * S[1][c] + a[r][2] * S[2][c];
+                for (int c = 0; c < 3; c++) J[r][3 + c] = a[r][c];
+            }
+            const double e[2] = {ex, ey};
+            for (int r = 0; r < 2; r++)
+                for (int c = 0; c < 6; c++) {
+                    Jtr[c] += J[r][c] * e[r];
+                    for (int d = 0; d < 6; d++) JtJ[c * 6 + d] += J[r][c] * J[r][d];
+                }
+        }
+        bool improved = false;
+        for (int tries = 0; tries < 8 && !improved; tries++) {
+            double A[36], b[6];
+            std::memcpy(A, JtJ, sizeof(A));
+            for (int c = 0; c < 6; c++) A[c * 6 + c] += lambda * (JtJ[c * 6 + c] + 1e-12), b[c] = -Jtr[c];
+            if (!solve6(A, b)) {
+                lambda *= 10;
+                continue;
+            }
+            Pose cand;
+            cand.R = rodrigues(b) * pose.R;
+            for (int c = 0; c < 3; c++) cand.t[c] = pose.t[c] + b[3 + c];
+            const double c2 = reproj_cost(cand, obj, img, idx, n, f, cx, cy);
+            if (std::isfinite(c2) && c2 < cost) {
+                const double rel = (cost - c2) / std::max(cost, 1e-300);
+                pose = cand, cost = c2, lambda = std::max(lambda * 0.1, 1e-12), improved = true;
+                if (rel < 1e-12 || cost < 1e-20) return true;
+            } else {
+                lambda *= 10;
+            }
+        }
+        if (!improved) break;
+    }
+    return true;
+}
+
+// cv::RANSACUpdateNumIters (OpenCV calib3d ptsetreg.cpp)
+static int ransac_update_iters(double p, double ep, int model_points, int max_iters) {
+    p = std::min(std::max(p, 0.0), 1.0), ep = std::min(std::max(ep, 0.0), 1.0);
+    double num = std::max(1.0 - p, DBL_MIN), denom = 1.0 - std::pow(1.0 - ep, model_points);
+    if (denom < DBL_MIN) return 0;
+    num = std::log(num), denom = std::log(denom);
+    return (denom >= 0 || -num >= max_iters * (-denom)) ? max_iters : (int)std::nearbyint(num / denom);
+}
+
+int estimate_rotation(const float *prev, const float *cur, int n, const Mat3 &Kin, const Mat3 &Kout, Pcg32 &rng, Mat3 &R) {
+    R = Mat3::identity();
+    if (n < 5) return 0;  // solvePnPRansac needs >= model size; the reference maps failure to (I, 0) (:367-371)
+    std::vector<double> tmp(2 * (size_t)n), und(2 * (size_t)n);
+    std::vector<float> img(2 * (size_t)n);
+    std::vector<double> obj(3 * (size_t)n);
+    // :322-330 current points -> output-camera pixels (R = I, P = output matrix), stored as Point2f
+    for (int i = 0; i < 2 * n; i++) tmp[i] = cur[i];
+    fisheye_undistort(tmp.data(), n, Kin, Kout, und.data());
+    for (int i = 0; i < 2 * n; i++) img[i] = (float)und[i];
+    // :333-338 previous points -> normalised identity-camera coordinates, stored as Point2f
+    for (int i = 0; i < 2 * n; i++) tmp[i] = prev[i];
+    fisheye_undistort(tmp.data(), n, Kin, Mat3::identity(), und.data());
+    for (int i = 0; i < n; i++) {
+        const double s = rng.uniform();  // :345 random depth ("prevents the detection of translations")
+        const float px = (float)und[2 * i], py = (float)und[2 * i + 1];
+        obj[3 * i] = px * s, obj[3 * i + 1] = py * s, obj[3 * i + 2] = s;
+    }
+    const double f = Kout(0, 0), cx = Kout(0, 2), cy = Kout(1, 2);
+    // :354-366 solvePnPRansac(100 iterations, 8 px, 0.99), minimal sample 5
+    const int model_points = 5;
+    const double thresh2 = 8.0 * 8.0, confidence = 0.99;
+    int niters = 100, best_count = 0;
+    Pose best;
+    std::vector<uint8_t> best_mask(n, 0), mask(n, 0);
+    for (int iter = 0; iter < niters; iter++) {
+        int idx[5];
+        for (int k = 0; k < model_points;) {
+            const int c = (int)rng.below((uint32_t)n);
+            bool dup = false;
+            for (int j = 0; j < k; j++) dup |= idx[j] == c;
+            if (!dup) idx[k++] = c;
+        }
+        Pose pose;
+        if (!solve_pnp_lm(obj.data(), img.data(), idx, model_points, f, cx, cy, pose, 10)) continue;
+        int good = 0;
+        for (int i = 0; i < n; i++) {
+            double u[2], Y[3];
+            project(pose, obj.data() + 3 * i, f, cx, cy, u, Y);
+            const double ex = u[0] - img[2 * i], ey = u[1] - img[2 * i + 1];
+            const float err = (float)(ex * ex + ey * ey);
+            mask[i] = err <= (float)thresh2;  // NaN compares false
+            good += mask[i];
+        }
+        if (good > std::max(best_count, model_points - 1)) {
+            best_count = good, best = pose, best_mask = mask;
+            niters = ransac_update_iters(confidence, (double)(n - good) / n, model_points, niters);
+        }
+    }
+    if (best_count <= 0) return 0;
+    // refit on all inliers (SOLVEPNP_ITERATIVE in the reference), starting from the best sample model
+    std::vector<int> inl;
+    for (int i = 0; i < n; i++)
+        if (best_mask[i]) inl.push_back(i);
+    Pose refined = best;
+    if (solve_pnp_lm(obj.data(), img.data(), inl.data(), (int)inl.size(), f, cx, cy, refined, 20)) best = refined;
+    // :373 Rodrigues(rvec) -- re-orthonormalise through the rotation vector as the reference does
+    double rv[3];
+    rodrigues_inv(best.R, rv);
+    R = rodrigues(rv);
+    return best_count;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Savitzky-Golay rotation filter
+// ---------------------------------------------------------------------------------------------
+std::vector<double> sg_weights(int m) {
+    // closed form of Gorry's Gram-polynomial weights for n = 2, t = 0, s = 0
+    std::vector<double> w(2 * (size_t)m + 1);
+    const double den = (2.0 * m - 1) * (2.0 * m + 1) * (2.0 * m + 3);
+    for (int i = -m; i <= m; i++) w[i + m] = 3.0 * (3.0 * m * m + 3.0 * m - 1 - 5.0 * i * i) / den;
+    if (m == 0) w[0] = 1.0;
+    return w;
+}
+
+Mat3 polar_orthogonal(const Mat3 &M) {
+    // Newton iteration X <- (X + X^-T)/2 with determinant scaling converges to the orthogonal
+    // polar factor U*V^T for any non-singular M (including det < 0, where it is a reflection --
+    // exactly what JacobiSVD's U*V^T gives, "no determinant fix").
+    Mat3 X = M;
+    const double d0 = X.det();
+    if (!(std::fabs(d0) > 1e-300) || !std::isfinite(d0)) return Mat3::identity();
+    for (int it = 0; it < 100; it++) {
+        const double d = X.det();
+        if (!(std::fabs(d) > 1e-300)) break;
+        const Mat3 Xit = X.inv().t();
+        const double g = std::pow(std::fabs(d), -1.0 / 3.0);  // scaling accelerates far-from-orthogonal starts
+        Mat3 Y;
+        double diff = 0;
+        for (int i = 0; i < 9; i++) {
+            Y.m[i] = 0.5 * (g * X.m[i] + Xit.m[i] / g);
+            diff = std::max(diff, std::fabs(Y.m[i] - X.m[i]));
+        }
+        X = Y;
+        if (diff < 1e-15) break;
+    }
+    return X;
+}
+
+RotationFilterSG::RotationFilterSG(int m) : m_(m), w_(sg_weights(m)), ring_(2 * (size_t)m + 1, Mat3::zero()) {}
+
+void RotationFilterSG::add(const Mat3 &R) {
+    ring_[head_] = R;  // overwrite the oldest; the new oldest is the next slot
+    head_ = (head_ + 1) % ring_.size();
+}
+
+Mat3 RotationFilterSG::filter() const {
+    Mat3 acc = Mat3::zero();
+    for (size_t i = 0; i < ring_.size(); i++) {
+        const Mat3 &r = ring_[(head_ + i) % ring_.size()];
+        for (int k = 0; k < 9; k++) acc.m[k] += w_[i] * r.m[k];
+    }
+    return polar_orthogonal(acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kalman mode
+// ---------------------------------------------------------------------------------------------
+double RotationFilterKalman::Axis::step(double z) {
+    const double Q = 1e-5, Rn = 1e-1;
+    // predict: x = F x, P = F P F^T + Q
+    const double x0 = x[0] + x[1], x1 = x[1];
+    const double p00 = P[0] + P[1] + P[2] + P[3] + Q, p01 = P[1] + P[3], p10 = P[2] + P[3], p11 = P[3] + Q;
+    // correct with H = [1 0]
+    const double S = p00 + Rn, k0 = p00 / S, k1 = p10 / S, y = z - x0;
+    x[0] = x0 + k0 * y, x[1] = x1 + k1 * y;
+    P[0] = (1 - k0) * p00, P[1] = (1 - k0) * p01, P[2] = p10 - k1 * p00, P[3] = p11 - k1 * p01;
+    return x[0];
+}
+
+RotationFilterKalman::RotationFilterKalman() {}
+
+Mat3 RotationFilterKalman::update(const Mat3 &measured) {
+    double rv[3], out[3];
+    rodrigues_inv(measured, rv);
+    for (int i = 0; i < 3; i++) out[i] = ax_[i].step(rv[i]);
+    return rodrigues(out);
+}
+
+}  // namespace vstab

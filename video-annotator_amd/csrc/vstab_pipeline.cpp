@@ -1,0 +1,569 @@
+// vstab_pipeline.cpp -- the FrameSourceWarp replacement behind the C ABI: tracking workspace,
+// look-ahead ring in HBM, consume_frame / pull_frame state machine (FrameSourceWarp.cpp:397-476),
+// plus the stateless tracking / motion entry points.  Host C++; every pixel touches a HIP kernel.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <vector>
+
+#include "vstab_geometry.hpp"
+#include "vstab_internal.hpp"
+#include "vstab_motion.hpp"
+#include "vstab_track.hpp"
+
+namespace vstab {
+
+#define VSTAB_TRY(expr)                   \
+    do {                                  \
+        vstab_status st_ = (expr);        \
+        if (st_ != VSTAB_OK) return st_;  \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr, n = 0;
+    }
+    vstab_status ensure(size_t bytes) {
+        if (bytes <= n) return VSTAB_OK;
+        release();
+        if (hipMalloc(&p, bytes) != hipSuccess) return fail(VSTAB_ERR_NOMEM, "hipMalloc failed");
+        n = bytes;
+        return VSTAB_OK;
+    }
+    template <typename T>
+    T *as() const { return static_cast<T *>(p); }
+};
+
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t n = 0;
+    ~PinnedBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    vstab_status ensure(size_t bytes) {
+        if (bytes <= n) return VSTAB_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr, n = 0;
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return fail(VSTAB_ERR_NOMEM, "hipHostMalloc failed");
+        n = bytes;
+        return VSTAB_OK;
+    }
+    template <typename T>
+    T *as() const { return static_cast<T *>(p); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Tracker: device workspace for goodFeaturesToTrack + calcOpticalFlowPyrLK
+// ---------------------------------------------------------------------------------------------
+class Tracker {
+  public:
+    vstab_status init(int w, int h) {
+        w_ = w, h_ = h, levels_ = lk_levels(w, h);
+        int lw = w, lh = h;
+        for (int l = 1; l < levels_; l++) {
+            lw = (lw + 1) / 2, lh = (lh + 1) / 2;
+            lvl_w_[l] = lw, lvl_h_[l] = lh;
+            for (int s = 0; s < 2; s++) VSTAB_TRY(pyr_[s][l].ensure((size_t)lw * lh));
+        }
+        lvl_w_[0] = w, lvl_h_[0] = h;
+        VSTAB_TRY(small_.ensure(256));
+        VSTAB_TRY(hsmall_.ensure(256));
+        return VSTAB_OK;
+    }
+
+    // levels 1.. of the pyramid of `gray` into slot s (level 0 is the frame itself)
+    vstab_status build_pyramid(int s, const uint8_t *gray, size_t pitch, hipStream_t st) {
+        const uint8_t *src = gray;
+        size_t sp = pitch;
+        for (int l = 1; l < levels_; l++) {
+            VSTAB_TRY(launch_pyr_down(src, sp, lvl_w_[l - 1], lvl_h_[l - 1], pyr_[s][l].as<uint8_t>(), (size_t)lvl_w_[l], st));
+            src = pyr_[s][l].as<uint8_t>(), sp = (size_t)lvl_w_[l];
+        }
+        return VSTAB_OK;
+    }
+
+    LkPyramid pyramid(int s, const uint8_t *gray, size_t pitch) const {
+        LkPyramid p;
+        p.levels = levels_;
+        for (int l = 0; l < LK_MAX_LEVELS; l++) p.img[l] = nullptr, p.pitch[l] = 0, p.w[l] = p.h[l] = 0;
+        p.img[0] = gray, p.pitch[0] = pitch, p.w[0] = w_, p.h[0] = h_;
+        for (int l = 1; l < levels_; l++) p.img[l] = pyr_[s][l].as<uint8_t>(), p.pitch[l] = (size_t)lvl_w_[l], p.w[l] = lvl_w_[l], p.h[l] = lvl_h_[l];
+        return p;
+    }
+
+    // goodFeaturesToTrack(gray, max_corners, quality, min_distance); synchronises the stream
+    vstab_status good_features(const uint8_t *gray, size_t pitch, int max_corners, double quality, double min_distance,
+                               std::vector<float> &xy, hipStream_t st, float *eig_out = nullptr) {
+        xy.clear();
+        float *eig = eig_out;
+        if (!eig) {
+            VSTAB_TRY(eig_.ensure(sizeof(float) * (size_t)w_ * h_));
+            eig = eig_.as<float>();
+        }
+        int *max_bits = small_.as<int>();
+        unsigned int *count = small_.as<unsigned int>() + 4;
+        if (cap_ == 0) {
+            cap_ = 1u << 18;
+            VSTAB_TRY(keys_.ensure(sizeof(unsigned long long) * cap_));
+        }
+        VSTAB_TRY(launch_min_eig(gray, pitch, w_, h_, eig, max_bits, st));
+        unsigned int n = 0;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            VSTAB_TRY(launch_corner_candidates(eig, w_, h_, max_bits, quality, keys_.as<unsigned long long>(), count, cap_, st));
+            VSTAB_HIP_TRY(hipMemcpyAsync(hsmall_.p, count, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+            VSTAB_HIP_TRY(hipStreamSynchronize(st));
+            n = *hsmall_.as<unsigned int>();
+            if (n <= cap_) break;
+            cap_ = n;  // more local maxima than the buffer holds: grow and re-run the compaction
+            VSTAB_TRY(keys_.ensure(sizeof(unsigned long long) * cap_));
+        }
+        if (n == 0) return VSTAB_OK;
+        VSTAB_TRY(hkeys_.ensure(sizeof(unsigned long long) * n));
+        VSTAB_HIP_TRY(hipMemcpyAsync(hkeys_.p, keys_.p, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, st));
+        VSTAB_HIP_TRY(hipStreamSynchronize(st));
+        unsigned long long *k = hkeys_.as<unsigned long long>();
+        // value descending, ties -> later raster position first (greaterThanPtr in OpenCV)
+        std::sort(k, k + n, [](unsigned long long a, unsigned long long b) { return a > b; });
+        // minimum-distance grid (goodFeaturesToTrack)
+        const int cell = (int)std::nearbyint(min_distance);
+        if (cell < 1) {
+            for (unsigned int i = 0; i < n && (max_corners <= 0 || (int)(xy.size() / 2) < max_corners); i++) {
+                const unsigned int idx = (unsigned int)(k[i] & 0xffffffffu);
+                xy.push_back((float)(idx % w_)), xy.push_back((float)(idx / w_));
+            }
+            return VSTAB_OK;
+        }
+        const int gw = (w_ + cell - 1) / cell, gh = (h_ + cell - 1) / cell;
+        std::vector<std::vector<int>> grid((size_t)gw * gh);
+        const double md2 = min_distance * min_distance;
+        for (unsigned int i = 0; i < n; i++) {
+            const unsigned int idx = (unsigned int)(k[i] & 0xffffffffu);
+            const int x = (int)(idx % w_), y = (int)(idx / w_);
+            const int xc = x / cell, yc = y / cell;
+            const int x1 = std::max(0, xc - 1), y1 = std::max(0, yc - 1), x2 = std::min(gw - 1, xc + 1), y2 = std::min(gh - 1, yc + 1);
+            bool good = true;
+            for (int yy = y1; yy <= y2 && good; yy++)
+                for (int xx = x1; xx <= x2 && good; xx++)
+                    for (int j : grid[(size_t)yy * gw + xx]) {
+                        const float dx = (float)x - xy[2 * j], dy = (float)y - xy[2 * j + 1];
+                        if ((double)(dx * dx + dy * dy) < md2) {
+                            good = false;
+                            break;
+                        }
+                    }
+            if (good) {
+                grid[(size_t)yc * gw + xc].push_back((int)(xy.size() / 2));
+                xy.push_back((float)x), xy.push_back((float)y);
+                if (max_corners > 0 && (int)(xy.size() / 2) == max_corners) break;
+            }
+        }
+        return VSTAB_OK;
+    }
+
+    // calcOpticalFlowPyrLK(prev, next, pts): both pyramids must have been built; synchronises
+    vstab_status track(const LkPyramid &I, const LkPyramid &J, const std::vector<float> &prev_xy, std::vector<float> &next_xy,
+                       std::vector<uint8_t> &status, hipStream_t st) {
+        const int n = (int)(prev_xy.size() / 2);
+        next_xy.assign(prev_xy.size(), 0.f), status.assign(n, 0);
+        if (n == 0) return VSTAB_OK;
+        VSTAB_TRY(pts_.ensure((size_t)n * (2 * sizeof(float2) + 8)));
+        VSTAB_TRY(hpts_.ensure((size_t)n * (2 * sizeof(float2) + 8)));
+        float2 *d_prev = pts_.as<float2>(), *d_next = d_prev + n;
+        uint8_t *d_status = reinterpret_cast<uint8_t *>(d_next + n);
+        float2 *h_prev = hpts_.as<float2>(), *h_next = h_prev + n;
+        uint8_t *h_status = reinterpret_cast<uint8_t *>(h_next + n);
+        std::memcpy(h_prev, prev_xy.data(), sizeof(float) * prev_xy.size());
+        VSTAB_HIP_TRY(hipMemcpyAsync(d_prev, h_prev, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+        VSTAB_TRY(launch_lk(I, J, d_prev, n, d_next, d_status, st));
+        VSTAB_HIP_TRY(hipMemcpyAsync(h_next, d_next, sizeof(float2) * n + n, hipMemcpyDeviceToHost, st));
+        VSTAB_HIP_TRY(hipStreamSynchronize(st));
+        std::memcpy(next_xy.data(), h_next, sizeof(float) * next_xy.size());
+        std::memcpy(status.data(), h_status, n);
+        return VSTAB_OK;
+    }
+
+    int levels() const { return levels_; }
+
+  private:
+    int w_ = 0, h_ = 0, levels_ = 1;
+    int lvl_w_[LK_MAX_LEVELS] = {0}, lvl_h_[LK_MAX_LEVELS] = {0};
+    DevBuf pyr_[2][LK_MAX_LEVELS], eig_, keys_, small_, pts_;
+    PinnedBuf hsmall_, hkeys_, hpts_;
+    unsigned int cap_ = 0;
+};
+
+}  // namespace vstab
+
+using namespace vstab;
+
+// ---------------------------------------------------------------------------------------------
+// the pipeline handle
+// ---------------------------------------------------------------------------------------------
+struct vstab_handle {
+    vstab_config cfg;
+    vstab_source src;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int w = 0, h = 0, ow = 0, oh = 0;
+    Mat3 Kin, Kout;
+    Tracker tracker;
+
+    struct Slot {
+        DevBuf buf;  // packed NV12, pitch = w
+        bool queued = false, last = false;
+    };
+    std::vector<Slot> slots;
+    int last_slot = -1;  // m_last_input_frame
+    int cur_pyr = 0;     // pyramid slot holding the last input frame's pyramid
+
+    long frame_index = 0, last_key = -1;       // m_frame_index, m_last_key_frame_index
+    std::vector<float> corners;                // m_last_input_frame_corners
+    Mat3 measured = Mat3::identity();          // m_measured_rotation
+    bool have_last_rot = false;
+    Mat3 last_rot = Mat3::identity();          // m_last_frame_rotation
+    std::unique_ptr<RotationFilterSG> sg;      // m_rotation_filter
+    RotationFilterKalman kalman;
+    std::deque<std::pair<int, Mat3>> queue;    // m_buffered_frames + m_buffered_rotations
+    Pcg32 rng;
+    std::vector<vstab_frame_log> log;
+    std::vector<Mat3> warp_log;
+
+    int acquire_slot() {
+        for (size_t i = 0; i < slots.size(); i++)
+            if (!slots[i].queued && !slots[i].last) return (int)i;
+        return -1;
+    }
+    const uint8_t *gray(int s) const { return slots[s].buf.as<uint8_t>(); }
+};
+
+static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
+    if (f.width != H->w || f.height != H->h) return fail(VSTAB_ERR_INVALID, "frame size changed mid-stream");
+    uint8_t *dst = H->slots[slot].buf.as<uint8_t>();
+    if (f.mem == 0) return vstab_pack_nv12(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->stream);
+    VSTAB_HIP_TRY(hipMemcpy2DAsync(dst, H->w, f.y, f.pitch_y, H->w, H->h, hipMemcpyHostToDevice, H->stream));
+    VSTAB_HIP_TRY(hipMemcpy2DAsync(dst + (size_t)H->w * H->h, H->w, f.uv, f.pitch_uv, H->w, H->h / 2, hipMemcpyHostToDevice, H->stream));
+    VSTAB_HIP_TRY(hipStreamSynchronize(H->stream));  // the caller may reuse its host buffer on return
+    return VSTAB_OK;
+}
+
+// consume_frame, FrameSourceWarp.cpp:397-450
+static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
+    const int slot = H->acquire_slot();
+    if (slot < 0) return fail(VSTAB_ERR_NOMEM, "look-ahead ring exhausted");
+    VSTAB_TRY(ingest(H, f, slot));
+    const uint8_t *g = H->gray(slot);
+    const size_t pitch = (size_t)H->w;
+    if (!H->cfg.tracking) {
+        // undistort-only mode (BASELINE config 1): every frame gets the identity rotation
+        if (H->last_key == -1) {
+            H->last_key = H->frame_index;
+        } else {
+            if (H->sg) H->sg->add(H->measured);
+            H->slots[slot].queued = true;
+            H->queue.emplace_back(slot, H->measured);
+        }
+    } else if (H->last_key == -1) {
+        // :403-407 the first frame only seeds the corner set
+        H->last_key = H->frame_index;
+        VSTAB_TRY(H->tracker.good_features(g, pitch, 200, 0.01, 30.0, H->corners, H->stream));
+        VSTAB_TRY(H->tracker.build_pyramid(H->cur_pyr, g, pitch, H->stream));
+    } else {
+        vstab_frame_log lg;
+        std::memset(&lg, 0, sizeof(lg));
+        const uint8_t *pg = H->gray(H->last_slot);
+        // :415-419 key-frame rule; corners are found in the PREVIOUS gray frame
+        if (H->frame_index - H->last_key > 20 || H->corners.size() / 2 < 150) {
+            H->last_key = H->frame_index - 1;
+            VSTAB_TRY(H->tracker.good_features(pg, pitch, 200, 0.01, 30.0, H->corners, H->stream));
+            lg.key_frame = 1;
+        }
+        lg.n_corners = (int)(H->corners.size() / 2);
+        // :422-427 optical flow prev -> current; keep pairs with status != 0
+        const int prev_pyr = H->cur_pyr, next_pyr = 1 - H->cur_pyr;
+        VSTAB_TRY(H->tracker.build_pyramid(next_pyr, g, pitch, H->stream));
+        std::vector<float> nxt;
+        std::vector<uint8_t> st;
+        VSTAB_TRY(H->tracker.track(H->tracker.pyramid(prev_pyr, pg, pitch), H->tracker.pyramid(next_pyr, g, pitch), H->corners, nxt, st, H->stream));
+        std::vector<float> pp, cp;
+        for (size_t i = 0; i < st.size(); i++)
+            if (st[i]) {
+                pp.push_back(H->corners[2 * i]), pp.push_back(H->corners[2 * i + 1]);
+                cp.push_back(nxt[2 * i]), cp.push_back(nxt[2 * i + 1]);
+            }
+        H->corners = cp;
+        H->cur_pyr = next_pyr;
+        lg.n_tracked = (int)(cp.size() / 2);
+        // :429-438 rotation since the last frame, with the < 40 inlier fallback
+        Mat3 R;
+        const int inl = estimate_rotation(pp.data(), cp.data(), lg.n_tracked, H->Kin, H->Kout, H->rng, R);
+        lg.n_inliers = inl;
+        if (inl < 40) {
+            R = H->have_last_rot ? H->last_rot : Mat3::identity();
+            lg.fallback = 1;
+        }
+        H->last_rot = R, H->have_last_rot = true;
+        H->measured = R * H->measured;  // :441 left-multiplied accumulation
+        if (H->sg) H->sg->add(H->measured);
+        H->slots[slot].queued = true;
+        H->queue.emplace_back(slot, H->measured);
+        std::memcpy(lg.R_frame, R.m, sizeof(R.m));
+        std::memcpy(lg.R_accum, H->measured.m, sizeof(R.m));
+        H->log.push_back(lg);
+    }
+    if (H->last_slot >= 0) H->slots[H->last_slot].last = false;
+    H->slots[slot].last = true;
+    H->last_slot = slot;  // :448
+    ++H->frame_index;     // :449
+    return VSTAB_OK;
+}
+
+extern "C" {
+
+void vstab_config_default(vstab_config *cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->preset = VSTAB_GOPRO_H4B_WIDE169_MEASURED;
+    cfg->scale = 1, cfg->crop_borders = 0, cfg->zoom = 1, cfg->smooth_radius = 30;  // FrameSourceWarp.hpp:86-89
+    cfg->interpolation = 1, cfg->smoother = VSTAB_SMOOTHER_SG, cfg->tracking = 1, cfg->seed = 1, cfg->stream = nullptr;
+}
+
+vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vstab_handle **out) {
+    if (!cfg || !src || !out || !src->pull || !src->peek) return fail(VSTAB_ERR_INVALID, "vstab_create: null argument");
+    if (cfg->smooth_radius < 0 || cfg->smooth_radius > 10000) return fail(VSTAB_ERR_INVALID, "vstab_create: bad smooth_radius");
+    if (cfg->interpolation != 1) return fail(VSTAB_ERR_INVALID, "vstab_create: only INTER_LINEAR is implemented (the only mode the reference passes)");
+    if (!(cfg->scale > 0) || !(cfg->zoom > 0)) return fail(VSTAB_ERR_INVALID, "vstab_create: scale and zoom must be positive");
+    std::unique_ptr<vstab_handle> H(new vstab_handle);
+    H->cfg = *cfg, H->src = *src;
+    H->rng = Pcg32(cfg->seed);
+    H->stream = static_cast<hipStream_t>(cfg->stream);  // NULL = the default stream, as for the stateless operators
+    // :214-219 peek the first frame for the input size, then derive both cameras
+    vstab_frame f;
+    std::memset(&f, 0, sizeof(f));
+    const int rc = src->peek(src->user, &f);
+    if (rc == VSTAB_EOF) return fail(VSTAB_EOF, "vstab_create: upstream has no frames");
+    if (rc != 0) return fail(VSTAB_ERR_SOURCE, "vstab_create: upstream peek failed with " + std::to_string(rc));
+    if (f.width <= 0 || f.height <= 0 || (f.width & 1) || (f.height & 1) || f.width > 32767 || f.height > 32767)
+        return fail(VSTAB_ERR_INVALID, "vstab_create: frame size must be even and <= 32767");
+    H->w = f.width, H->h = f.height;
+    if (!preset_camera(cfg->preset, H->w, H->h, H->Kin)) return fail(VSTAB_ERR_INVALID, "vstab_create: unknown preset");
+    output_camera(H->Kin, H->w, H->h, cfg->scale, cfg->crop_borders != 0, cfg->zoom, H->Kout, H->ow, H->oh);
+    if (H->ow <= 0 || H->oh <= 0 || H->ow > 32767 || H->oh > 32767) return fail(VSTAB_ERR_INVALID, "vstab_create: output size out of range");
+    if (cfg->smoother == VSTAB_SMOOTHER_SG) H->sg.reset(new RotationFilterSG(cfg->smooth_radius));
+    H->slots.resize((size_t)cfg->smooth_radius + 3);
+    for (auto &s : H->slots) VSTAB_TRY(s.buf.ensure((size_t)H->w * H->h * 3 / 2));
+    if (cfg->tracking) VSTAB_TRY(H->tracker.init(H->w, H->h));
+    *out = H.release();
+    return VSTAB_OK;
+}
+
+vstab_status vstab_get_output_info(const vstab_handle *h, int *width, int *height, double K_in[9], double K_out[9]) {
+    if (!h) return fail(VSTAB_ERR_INVALID, "null handle");
+    if (width) *width = h->ow;
+    if (height) *height = h->oh;
+    if (K_in) std::memcpy(K_in, h->Kin.m, sizeof(h->Kin.m));
+    if (K_out) std::memcpy(K_out, h->Kout.m, sizeof(h->Kout.m));
+    return VSTAB_OK;
+}
+
+// FrameSourceWarp::pull_frame, :452-476
+vstab_status vstab_pull_frame(vstab_handle *H, void *dst, size_t pitch_dst) {
+    if (!H || !dst) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: null argument");
+    while (H->queue.size() <= (size_t)H->cfg.smooth_radius) {
+        vstab_frame f;
+        std::memset(&f, 0, sizeof(f));
+        const int rc = H->src.pull(H->src.user, &f);
+        if (rc == VSTAB_EOF) {
+            // :456-461 pretend the camera kept its last orientation
+            if (H->sg) H->sg->add(H->measured);
+            break;
+        }
+        if (rc != 0) return fail(VSTAB_ERR_SOURCE, "upstream pull failed with " + std::to_string(rc));
+        VSTAB_TRY(consume_frame(H, f));
+    }
+    if (H->queue.empty()) return VSTAB_EOF;  // :465-467
+    const int slot = H->queue.front().first;
+    const Mat3 measured = H->queue.front().second;
+    H->queue.pop_front();
+    Mat3 corrected;
+    if (H->cfg.smoother == VSTAB_SMOOTHER_SG)
+        corrected = H->sg->filter();  // :471
+    else if (H->cfg.smoother == VSTAB_SMOOTHER_KALMAN)
+        corrected = H->kalman.update(measured);
+    else
+        corrected = measured;
+    const Mat3 correction = corrected * measured.inv();  // :472
+    const Mat3 warp_R = correction.inv();                // :475
+    H->warp_log.push_back(warp_R);
+    float p[17];
+    map_params(H->Kin, H->Kout, warp_R, p);
+    const uint8_t *nv12 = H->slots[slot].buf.as<uint8_t>();
+    const vstab_status st = vstab_warp_nv12_bgr(nv12, (size_t)H->w, nv12 + (size_t)H->w * H->h, (size_t)H->w, H->w, H->h, p, dst,
+                                                pitch_dst, H->ow, H->oh, H->stream);
+    H->slots[slot].queued = false;  // stream order protects the slot until the warp has read it
+    return st;
+}
+
+vstab_status vstab_peek_frame(vstab_handle *h, void *dst, size_t pitch_dst) { return vstab_pull_frame(h, dst, pitch_dst); }  // :478-480
+
+void vstab_destroy(vstab_handle *h) {
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int vstab_frame_log_count(const vstab_handle *h) { return h ? (int)h->log.size() : 0; }
+
+vstab_status vstab_get_frame_log(const vstab_handle *h, int index, vstab_frame_log *out) {
+    if (!h || !out || index < 0 || index >= (int)h->log.size()) return fail(VSTAB_ERR_INVALID, "vstab_get_frame_log: bad index");
+    *out = h->log[index];
+    return VSTAB_OK;
+}
+
+vstab_status vstab_get_warp_rotation(const vstab_handle *h, int index, double R[9]) {
+    if (!h || !R || index < 0 || index >= (int)h->warp_log.size()) return fail(VSTAB_ERR_INVALID, "vstab_get_warp_rotation: bad index");
+    std::memcpy(R, h->warp_log[index].m, sizeof(double) * 9);
+    return VSTAB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ring source
+// ---------------------------------------------------------------------------------------------
+struct vstab_ring_source {
+    std::vector<const void *> frames;
+    int w, h;
+    size_t pitch;
+    long total, pos;
+};
+
+static int ring_fill(vstab_ring_source *s, vstab_frame *out) {
+    if (s->pos >= s->total) return VSTAB_EOF;
+    const uint8_t *p = static_cast<const uint8_t *>(s->frames[(size_t)(s->pos % (long)s->frames.size())]);
+    out->y = p, out->uv = p + s->pitch * s->h, out->pitch_y = out->pitch_uv = s->pitch;
+    out->width = s->w, out->height = s->h, out->mem = 0, out->pts = s->pos;
+    return 0;
+}
+static int ring_pull(void *user, vstab_frame *out) {
+    vstab_ring_source *s = static_cast<vstab_ring_source *>(user);
+    const int rc = ring_fill(s, out);
+    if (rc == 0) s->pos++;
+    return rc;
+}
+static int ring_peek(void *user, vstab_frame *out) { return ring_fill(static_cast<vstab_ring_source *>(user), out); }
+
+vstab_status vstab_ring_source_create(const void *const *frames, int n_frames, int width, int height, size_t pitch,
+                                      long total_frames, vstab_ring_source **out, vstab_source *as_source) {
+    if (!frames || n_frames <= 0 || !out || !as_source || width <= 0 || height <= 0 || pitch < (size_t)width)
+        return fail(VSTAB_ERR_INVALID, "vstab_ring_source_create: bad argument");
+    vstab_ring_source *s = new vstab_ring_source;
+    s->frames.assign(frames, frames + n_frames);
+    s->w = width, s->h = height, s->pitch = pitch, s->total = total_frames, s->pos = 0;
+    as_source->pull = ring_pull, as_source->peek = ring_peek, as_source->user = s;
+    *out = s;
+    return VSTAB_OK;
+}
+
+void vstab_ring_source_destroy(vstab_ring_source *s) { delete s; }
+
+// ---------------------------------------------------------------------------------------------
+// stateless tracking / motion entry points
+// ---------------------------------------------------------------------------------------------
+vstab_status vstab_pyr_down(const void *src, size_t pitch_src, int width, int height, void *dst, size_t pitch_dst, void *stream) {
+    if (!src || !dst || width <= 0 || height <= 0 || pitch_src < (size_t)width || pitch_dst < (size_t)((width + 1) / 2))
+        return fail(VSTAB_ERR_INVALID, "vstab_pyr_down: bad argument");
+    return launch_pyr_down((const uint8_t *)src, pitch_src, width, height, (uint8_t *)dst, pitch_dst, static_cast<hipStream_t>(stream));
+}
+
+vstab_status vstab_min_eig(const void *gray, size_t pitch, int width, int height, void *eig, void *stream) {
+    if (!gray || !eig || width <= 0 || height <= 0 || pitch < (size_t)width) return fail(VSTAB_ERR_INVALID, "vstab_min_eig: bad argument");
+    DevBuf mb;
+    VSTAB_TRY(mb.ensure(16));
+    VSTAB_TRY(launch_min_eig((const uint8_t *)gray, pitch, width, height, (float *)eig, mb.as<int>(), static_cast<hipStream_t>(stream)));
+    VSTAB_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return VSTAB_OK;
+}
+
+vstab_status vstab_good_features(const void *gray, size_t pitch, int width, int height, int max_corners, double quality,
+                                 double min_distance, float *xy, int *count, void *stream) {
+    if (!gray || !xy || !count || width < 3 || height < 3 || pitch < (size_t)width || max_corners <= 0)
+        return fail(VSTAB_ERR_INVALID, "vstab_good_features: bad argument");
+    Tracker t;
+    VSTAB_TRY(t.init(width, height));
+    std::vector<float> out;
+    VSTAB_TRY(t.good_features((const uint8_t *)gray, pitch, max_corners, quality, min_distance, out, static_cast<hipStream_t>(stream)));
+    *count = (int)(out.size() / 2);
+    std::memcpy(xy, out.data(), sizeof(float) * out.size());
+    return VSTAB_OK;
+}
+
+vstab_status vstab_pyr_lk(const void *prev, size_t pitch_prev, const void *next, size_t pitch_next, int width, int height,
+                          const float *prev_xy, int n, float *next_xy, unsigned char *status, void *stream) {
+    if (!prev || !next || (n > 0 && (!prev_xy || !next_xy || !status)) || n < 0 || width <= 0 || height <= 0 ||
+        pitch_prev < (size_t)width || pitch_next < (size_t)width)
+        return fail(VSTAB_ERR_INVALID, "vstab_pyr_lk: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Tracker t;
+    VSTAB_TRY(t.init(width, height));
+    VSTAB_TRY(t.build_pyramid(0, (const uint8_t *)prev, pitch_prev, st));
+    VSTAB_TRY(t.build_pyramid(1, (const uint8_t *)next, pitch_next, st));
+    std::vector<float> p(prev_xy, prev_xy + 2 * (size_t)n), q;
+    std::vector<uint8_t> s;
+    VSTAB_TRY(t.track(t.pyramid(0, (const uint8_t *)prev, pitch_prev), t.pyramid(1, (const uint8_t *)next, pitch_next), p, q, s, st));
+    if (n > 0) {
+        std::memcpy(next_xy, q.data(), sizeof(float) * q.size());
+        std::memcpy(status, s.data(), s.size());
+    }
+    return VSTAB_OK;
+}
+
+vstab_status vstab_estimate_rotation(const float *prev_xy, const float *cur_xy, int n, const double K_in[9], const double K_out[9],
+                                     uint64_t seed, double R[9], int *inliers) {
+    if ((n > 0 && (!prev_xy || !cur_xy)) || n < 0 || !K_in || !K_out || !R || !inliers)
+        return fail(VSTAB_ERR_INVALID, "vstab_estimate_rotation: bad argument");
+    Mat3 ki, ko, r;
+    std::memcpy(ki.m, K_in, sizeof(ki.m)), std::memcpy(ko.m, K_out, sizeof(ko.m));
+    Pcg32 rng(seed);
+    *inliers = estimate_rotation(prev_xy, cur_xy, n, ki, ko, rng, r);
+    std::memcpy(R, r.m, sizeof(r.m));
+    return VSTAB_OK;
+}
+
+vstab_status vstab_sg_weights(int m, double *weights) {
+    if (m < 0 || !weights) return fail(VSTAB_ERR_INVALID, "vstab_sg_weights: bad argument");
+    const std::vector<double> w = sg_weights(m);
+    std::memcpy(weights, w.data(), sizeof(double) * w.size());
+    return VSTAB_OK;
+}
+
+struct vstab_rotation_filter {
+    RotationFilterSG f;
+    explicit vstab_rotation_filter(int m) : f(m) {}
+};
+
+vstab_status vstab_rotation_filter_create(int m, vstab_rotation_filter **out) {
+    if (m < 0 || !out) return fail(VSTAB_ERR_INVALID, "vstab_rotation_filter_create: bad argument");
+    *out = new vstab_rotation_filter(m);
+    return VSTAB_OK;
+}
+vstab_status vstab_rotation_filter_add(vstab_rotation_filter *f, const double R[9]) {
+    if (!f || !R) return fail(VSTAB_ERR_INVALID, "vstab_rotation_filter_add: null argument");
+    Mat3 r;
+    std::memcpy(r.m, R, sizeof(r.m));
+    f->f.add(r);
+    return VSTAB_OK;
+}
+vstab_status vstab_rotation_filter_filter(const vstab_rotation_filter *f, double R_out[9]) {
+    if (!f || !R_out) return fail(VSTAB_ERR_INVALID, "vstab_rotation_filter_filter: null argument");
+    const Mat3 r = f->f.filter();
+    std::memcpy(R_out, r.m, sizeof(r.m));
+    return VSTAB_OK;
+}
+void vstab_rotation_filter_destroy(vstab_rotation_filter *f) { delete f; }
+
+}  // extern "C"

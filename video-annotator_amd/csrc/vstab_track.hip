@@ -1,0 +1,317 @@
+// vstab_track.hip -- camera-motion front-end for gfx950: image pyramid, Shi-Tomasi corner
+// response + non-maximum suppression + compaction, pyramidal Lucas-Kanade tracker.
+// Replaces the OpenCV calls at FrameSourceWarp.cpp:230 (goodFeaturesToTrack) and :252
+// (calcOpticalFlowPyrLK).  Compiled with -ffp-contract=off: float results are bit-reproducible.
+#include <climits>
+
+#include "vstab_internal.hpp"
+#include "vstab_track.hpp"
+
+namespace vstab {
+
+__device__ __forceinline__ int reflect101(int i, int n) {  // BORDER_REFLECT_101, any overshoot
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+// =============================================================================================
+// k_pyr_down -- cv::pyrDown as used by buildOpticalFlowPyramid: 5x5 binomial
+// [1 4 6 4 1]^2, integer, (sum + 128) >> 8, REFLECT_101, dst = ((w+1)/2, (h+1)/2).
+// 32 x 8 outputs per workgroup; the (2*32+3) x (2*8+3) source tile goes through LDS, the
+// horizontal pass is done once per source row (separable), the vertical pass per output.
+// =============================================================================================
+constexpr int PD_TW = 32, PD_TH = 8, PD_SW = 2 * PD_TW + 3, PD_SH = 2 * PD_TH + 3;
+
+__global__ void __launch_bounds__(256) k_pyr_down(const uint8_t *__restrict__ src, size_t spitch, int sw, int sh,
+                                                  uint8_t *__restrict__ dst, size_t dpitch, int dw, int dh) {
+    __shared__ uint8_t tile[PD_SH][PD_SW + 1];
+    __shared__ uint16_t hrow[PD_SH][PD_TW];
+    const int tid = threadIdx.y * PD_TW + threadIdx.x;
+    const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
+    for (int e = tid; e < PD_SH * PD_SW; e += 256) {
+        const int ry = e / PD_SW, rx = e - ry * PD_SW;
+        tile[ry][rx] = src[(size_t)reflect101(2 * oy - 2 + ry, sh) * spitch + reflect101(2 * ox - 2 + rx, sw)];
+    }
+    __syncthreads();
+    for (int e = tid; e < PD_SH * PD_TW; e += 256) {
+        const int ry = e / PD_TW, cx = e - ry * PD_TW;
+        const uint8_t *t = &tile[ry][2 * cx];
+        hrow[ry][cx] = (uint16_t)(t[0] + 4 * t[1] + 6 * t[2] + 4 * t[3] + t[4]);
+    }
+    __syncthreads();
+    const int x = ox + threadIdx.x, y = oy + threadIdx.y;
+    if (x < dw && y < dh) {
+        const int ry = 2 * threadIdx.y, cx = threadIdx.x;
+        const int s = hrow[ry][cx] + 4 * hrow[ry + 1][cx] + 6 * hrow[ry + 2][cx] + 4 * hrow[ry + 3][cx] + hrow[ry + 4][cx];
+        dst[(size_t)y * dpitch + x] = (uint8_t)((s + 128) >> 8);
+    }
+}
+
+// =============================================================================================
+// k_min_eig -- cornerMinEigenVal(blockSize 3, ksize 3): Sobel
+// derivatives scaled by 1/(4*3*255) in the documented operation order, products, 3x3 box sum
+// (exact in double), minimum eigenvalue in float.  16 x 16 outputs per workgroup, source tile
+// with halo 2 and derivative tile with halo 1 in LDS.  Also reduces the frame maximum.
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_min_eig(const uint8_t *__restrict__ src, size_t pitch, int w, int h,
+                                                 float *__restrict__ eig, int *__restrict__ max_bits) {
+    __shared__ float dxs[18][19], dys[18][19];
+    __shared__ int bmax;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 16 + tx;
+    const int ox = blockIdx.x * 16, oy = blockIdx.y * 16;
+    if (tid == 0) bmax = INT_MIN;
+    const float scale = (float)(1.0 / (4.0 * 3.0 * 255.0));
+    const float k0 = 2.0f * scale, k1 = scale;
+    // derivative tile: entry (ry, rx) is the derivative AT image position reflect(oy-1+ry),
+    // reflect(ox-1+rx) (the box filter's REFLECT_101 border), whose own Sobel taps reflect again
+    for (int e = tid; e < 324; e += 256) {
+        const int ry = e / 18, rx = e - ry * 18;
+        const int y = reflect101(oy - 1 + ry, h), x = reflect101(ox - 1 + rx, w);
+        const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h), xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+        const uint8_t *r0 = src + (size_t)ym * pitch, *r1 = src + (size_t)y * pitch, *r2 = src + (size_t)yp * pitch;
+        const float d0 = (float)(r0[xp] - r0[xm]), d1 = (float)(r1[xp] - r1[xm]), d2 = (float)(r2[xp] - r2[xm]);
+        dxs[ry][rx] = (d0 + d2) * k1 + d1 * k0;
+        const float s0 = (float)r0[x] * k0 + ((float)r0[xm] + (float)r0[xp]) * k1;
+        const float s2 = (float)r2[x] * k0 + ((float)r2[xm] + (float)r2[xp]) * k1;
+        dys[ry][rx] = s2 - s0;
+    }
+    __syncthreads();
+    const int x = ox + tx, y = oy + ty;
+    float e = 0.0f;
+    if (x < w && y < h) {
+        double sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const float a = dxs[ty + j][tx + i], b = dys[ty + j][tx + i];
+                sxx += (double)(a * a), sxy += (double)(a * b), syy += (double)(b * b);
+            }
+        const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+        e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+        eig[(size_t)y * w + x] = e;
+        atomicMax(&bmax, __float_as_int(e));
+    }
+    __syncthreads();
+    if (tid == 0) atomicMax(max_bits, bmax);
+}
+
+// =============================================================================================
+// k_corner_candidates -- goodFeaturesToTrack steps 4-5: threshold at
+// quality*max (THRESH_TOZERO, strict >), 3x3 dilate-compare, interior pixels only.  A candidate is
+// emitted as the 64-bit key (float bits << 32 | raster index): sorting keys descending gives
+// OpenCV's order (value descending, ties -> later raster position first).
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_corner_candidates(const float *__restrict__ eig, int w, int h,
+                                                           const int *__restrict__ max_bits, double quality,
+                                                           unsigned long long *__restrict__ keys,
+                                                           unsigned int *__restrict__ count, unsigned int cap) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) return;
+    const float thr = (float)((double)__int_as_float(*max_bits) * quality);
+    const float *p = eig + (size_t)y * w + x;
+    const float v = p[0];
+    if (!(v > thr)) return;
+    float m = v;
+    m = fmaxf(m, p[-w - 1]), m = fmaxf(m, p[-w]), m = fmaxf(m, p[-w + 1]);
+    m = fmaxf(m, p[-1]), m = fmaxf(m, p[1]);
+    m = fmaxf(m, p[w - 1]), m = fmaxf(m, p[w]), m = fmaxf(m, p[w + 1]);
+    if (v != m) return;
+    const unsigned int slot = atomicAdd(count, 1u);
+    if (slot < cap) keys[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)(y * w + x);
+}
+
+// =============================================================================================
+// k_lk_track -- LKTrackerInvoker for all pyramid levels, one wavefront per
+// feature.  Window 21x21 = 441 pixels -> 7 per lane.  Per level: the 24x24 neighbourhood of the
+// previous image goes to LDS (REFLECT_101 padding), Scharr derivatives are computed on the fly
+// for the 22x22 taps (zero outside the image, as the reference's zero-padded derivative buffer),
+// the patch (I, Ix, Iy as int16 x32 fixed point) lives in registers, and the Gauss-Newton loop
+// stages a 22x22 block of the next image per iteration.  All sums are exact integers reduced
+// with wave shuffles (order free), converted once to float; the 2x2 solve follows the reference's
+// float operation order.
+// =============================================================================================
+constexpr int LKW = 21, LKR = 24, LKT = 22;
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int lo = __shfl_xor((int)(v & 0xffffffffll), m), hi = __shfl_xor((int)(v >> 32), m);
+        v += ((long long)hi << 32) | (unsigned int)lo;
+    }
+    return v;
+}
+
+#define LK_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+
+__global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const float2 *__restrict__ prev_pts,
+                                                 int n, float2 *__restrict__ next_pts, uint8_t *__restrict__ status) {
+    __shared__ int regI[LKR * LKR];
+    __shared__ int derx[LKT * LKT], dery[LKT * LKT];
+    __shared__ int regJ[LKT * LKT];
+    const int f = blockIdx.x, lane = threadIdx.x;
+    if (f >= n) return;
+    const float2 pp = prev_pts[f];
+    float2 np = make_float2(0.f, 0.f);
+    int st = 1;
+    const float half = (LKW - 1) * 0.5f;
+    const int max_level = I.levels - 1;
+    for (int level = max_level; level >= 0; level--) {
+        const uint8_t *img = I.img[level], *jmg = J.img[level];
+        const int w = I.w[level], h = I.h[level];
+        const size_t ipitch = I.pitch[level], jpitch = J.pitch[level];
+        const float lscale = (float)(1.0 / (double)(1 << level));
+        float ppx = pp.x * lscale, ppy = pp.y * lscale;
+        float npx, npy;
+        if (level == max_level)
+            npx = ppx, npy = ppy;
+        else
+            npx = np.x * 2.0f, npy = np.y * 2.0f;
+        np = make_float2(npx, npy);
+        ppx -= half, ppy -= half;
+        const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
+        if (ipx < -LKW || ipx >= w || ipy < -LKW || ipy >= h) {
+            if (level == 0) st = 0;
+            continue;
+        }
+        float a = ppx - (float)ipx, b = ppy - (float)ipy;
+        int iw00 = (int)rintf((1.f - a) * (1.f - b) * 16384.f);
+        int iw01 = (int)rintf(a * (1.f - b) * 16384.f);
+        int iw10 = (int)rintf((1.f - a) * b * 16384.f);
+        int iw11 = 16384 - iw00 - iw01 - iw10;
+        __syncthreads();  // previous level's readers are done with LDS
+        for (int e = lane; e < LKR * LKR; e += 64) {
+            const int ry = e / LKR, rx = e - ry * LKR;
+            regI[e] = img[(size_t)reflect101(ipy - 1 + ry, h) * ipitch + reflect101(ipx - 1 + rx, w)];
+        }
+        __syncthreads();
+        for (int e = lane; e < LKT * LKT; e += 64) {
+            const int tyy = e / LKT, txx = e - tyy * LKT;
+            const int X = ipx + txx, Y = ipy + tyy;
+            int dx = 0, dy = 0;
+            if (X >= 0 && Y >= 0 && X < w && Y < h) {
+                const int *c = &regI[(tyy + 1) * LKR + (txx + 1)];
+                const int t0m = (c[-LKR - 1] + c[LKR - 1]) * 3 + c[-1] * 10, t0p = (c[-LKR + 1] + c[LKR + 1]) * 3 + c[1] * 10;
+                const int t1m = c[LKR - 1] - c[-LKR - 1], t1c = c[LKR] - c[-LKR], t1p = c[LKR + 1] - c[-LKR + 1];
+                dx = (short)(t0p - t0m), dy = (short)((t1p + t1m) * 3 + t1c * 10);
+            }
+            derx[e] = dx, dery[e] = dy;
+        }
+        __syncthreads();
+        short Iw[7], Ixw[7], Iyw[7];
+        long long sA11 = 0, sA12 = 0, sA22 = 0;
+#pragma unroll
+        for (int m = 0; m < 7; m++) {
+            const int k = lane + 64 * m;
+            Iw[m] = Ixw[m] = Iyw[m] = 0;
+            if (k < LKW * LKW) {
+                const int wy = k / LKW, wx = k - wy * LKW;
+                const int *c = &regI[(wy + 1) * LKR + (wx + 1)];
+                const int ival = LK_DESCALE(c[0] * iw00 + c[1] * iw01 + c[LKR] * iw10 + c[LKR + 1] * iw11, 9);
+                const int d = wy * LKT + wx;
+                const int ixval = LK_DESCALE(derx[d] * iw00 + derx[d + 1] * iw01 + derx[d + LKT] * iw10 + derx[d + LKT + 1] * iw11, 14);
+                const int iyval = LK_DESCALE(dery[d] * iw00 + dery[d + 1] * iw01 + dery[d + LKT] * iw10 + dery[d + LKT + 1] * iw11, 14);
+                Iw[m] = (short)ival, Ixw[m] = (short)ixval, Iyw[m] = (short)iyval;
+                sA11 += (long long)ixval * ixval, sA12 += (long long)ixval * iyval, sA22 += (long long)iyval * iyval;
+            }
+        }
+        sA11 = wave_sum_i64(sA11), sA12 = wave_sum_i64(sA12), sA22 = wave_sum_i64(sA22);
+        const float FLT_SCALE = 1.0f / (1 << 20);
+        const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = ((A22 + A11) - sqrtf((A11 - A22) * (A11 - A22) + (4.f * A12) * A12)) / (float)(2 * LKW * LKW);
+        if (minEig < 1e-4f || D < 1.1920928955078125e-7f) {
+            if (level == 0) st = 0;
+            continue;
+        }
+        D = 1.f / D;
+        npx -= half, npy -= half;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < 30; j++) {
+            const int inx = (int)floorf(npx), iny = (int)floorf(npy);
+            if (inx < -LKW || inx >= w || iny < -LKW || iny >= h) {
+                if (level == 0) st = 0;
+                break;
+            }
+            a = npx - (float)inx, b = npy - (float)iny;
+            iw00 = (int)rintf((1.f - a) * (1.f - b) * 16384.f);
+            iw01 = (int)rintf(a * (1.f - b) * 16384.f);
+            iw10 = (int)rintf((1.f - a) * b * 16384.f);
+            iw11 = 16384 - iw00 - iw01 - iw10;
+            __syncthreads();
+            for (int e = lane; e < LKT * LKT; e += 64) {
+                const int tyy = e / LKT, txx = e - tyy * LKT;
+                regJ[e] = jmg[(size_t)reflect101(iny + tyy, h) * jpitch + reflect101(inx + txx, w)];
+            }
+            __syncthreads();
+            long long sb1 = 0, sb2 = 0;
+#pragma unroll
+            for (int m = 0; m < 7; m++) {
+                const int k = lane + 64 * m;
+                if (k < LKW * LKW) {
+                    const int wy = k / LKW, wx = k - wy * LKW;
+                    const int *c = &regJ[wy * LKT + wx];
+                    const int diff = LK_DESCALE(c[0] * iw00 + c[1] * iw01 + c[LKT] * iw10 + c[LKT + 1] * iw11, 9) - Iw[m];
+                    sb1 += (long long)(diff * Ixw[m]), sb2 += (long long)(diff * Iyw[m]);
+                }
+            }
+            sb1 = wave_sum_i64(sb1), sb2 = wave_sum_i64(sb2);
+            const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+            npx += dx, npy += dy;
+            np = make_float2(npx + half, npy + half);
+            if ((double)dx * dx + (double)dy * dy <= 0.01 * 0.01) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                np.x -= dx * 0.5f, np.y -= dy * 0.5f;
+                break;
+            }
+            pdx = dx, pdy = dy;
+        }
+    }
+    if (lane == 0) {
+        next_pts[f] = np;
+        status[f] = (uint8_t)st;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *dst, size_t dpitch,
+                             hipStream_t s) {
+    const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    dim3 grid(div_up(dw, PD_TW), div_up(dh, PD_TH));
+    hipLaunchKernelGGL(k_pyr_down, grid, dim3(PD_TW, PD_TH), 0, s, src, spitch, sw, sh, dst, dpitch, dw, dh);
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+vstab_status launch_min_eig(const uint8_t *src, size_t pitch, int w, int h, float *eig, int *max_bits,
+                            hipStream_t s) {
+    VSTAB_HIP_TRY(hipMemsetAsync(max_bits, 0x80, sizeof(int), s));  // INT_MIN-ish (0x80808080): any value wins
+    dim3 grid(div_up(w, 16), div_up(h, 16));
+    hipLaunchKernelGGL(k_min_eig, grid, dim3(16, 16), 0, s, src, pitch, w, h, eig, max_bits);
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+vstab_status launch_corner_candidates(const float *eig, int w, int h, const int *max_bits, double quality,
+                                      unsigned long long *keys, unsigned int *count, unsigned int cap,
+                                      hipStream_t s) {
+    VSTAB_HIP_TRY(hipMemsetAsync(count, 0, sizeof(unsigned int), s));
+    dim3 grid(div_up(w, 64), div_up(h, 4));
+    hipLaunchKernelGGL(k_corner_candidates, grid, dim3(64, 4), 0, s, eig, w, h, max_bits, quality, keys, count, cap);
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+vstab_status launch_lk(const LkPyramid &I, const LkPyramid &J, const float2 *prev_pts, int n, float2 *next_pts,
+                       uint8_t *status, hipStream_t s) {
+    if (n <= 0) return VSTAB_OK;
+    hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(64), 0, s, I, J, prev_pts, n, next_pts, status);
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+}  // namespace vstab
