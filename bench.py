@@ -63,6 +63,54 @@ def synth_ring(torch, dev, w, h, n, seed):
     return frames
 
 
+def shaky_ring(torch, dev, w, h, K, n, seed):
+    """n NV12 frames of a static spherical scene seen through the equidistant fisheye camera K while
+    the camera orientation follows a smooth PERIODIC shake (period n, so the ring can be cycled
+    without a jump): about 0.2 degrees per frame per axis.  Rendered on
+    the GPU with torch (harness only).  Returns (frames, rotations)."""
+    g = torch.Generator(device=dev).manual_seed(1234 + seed)
+    th, tw = 4096, 8192
+    tex = torch.zeros((th, tw), device=dev)
+    for cell, amp in ((16, 0.5), (48, 0.3), (160, 0.2)):
+        base = torch.rand((th // cell + 2, tw // cell + 2), device=dev, generator=g)
+        tex += amp * torch.nn.functional.interpolate(base[None, None], size=(th, tw), mode="bilinear", align_corners=False)[0, 0]
+    tex = 40 + 120 * tex
+    rs = np.random.default_rng(1234 + seed)
+    for _ in range(6000):  # bright / dark rectangles: trackable corners everywhere on the sphere
+        rw, rh = rs.integers(20, 90), rs.integers(20, 90)
+        x, y = rs.integers(0, tw - rw), rs.integers(0, th - rh)
+        tex[y:y + rh, x:x + rw] = float(rs.choice([225.0, 30.0, 200.0]))
+    ys, xs = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32), torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
+    px, py = (xs - float(K[0, 2])) / float(K[0, 0]), (ys - float(K[1, 2])) / float(K[1, 1])
+    ang = torch.sqrt(px * px + py * py)
+    sc = torch.where(ang > 1e-9, torch.sin(ang) / ang.clamp_min(1e-9), torch.ones_like(ang))
+    rays = torch.stack([px * sc, py * sc, torch.cos(ang)], dim=-1)  # d_cam
+    cu = (128 + 50 * torch.sin(xs[::2, ::2] / w * 6.0)).to(torch.uint8)
+    cv = (128 + 50 * torch.cos(ys[::2, ::2] / h * 5.0)).to(torch.uint8)
+    uv = torch.stack([cu, cv], dim=-1).reshape(h // 2, w)
+    amp = rs.uniform(0.008, 0.02, (3, 3))
+    ph = rs.uniform(0, 2 * np.pi, (3, 3))
+    frames, rots = [], []
+    for k in range(n):
+        a = [sum(amp[ax, j] * np.sin(2 * np.pi * (j + 1) * k / n + ph[ax, j]) for j in range(3)) for ax in range(3)]
+        t = float(np.linalg.norm(a))
+        kk = np.array(a) / t if t > 0 else np.zeros(3)
+        Kx = np.array([[0, -kk[2], kk[1]], [kk[2], 0, -kk[0]], [-kk[1], kk[0], 0]])
+        R = np.cos(t) * np.eye(3) + (1 - np.cos(t)) * np.outer(kk, kk) + np.sin(t) * Kx
+        d = rays @ torch.tensor(R, dtype=torch.float32, device=dev)  # rows: R^T d_cam = d_world
+        lon, lat = torch.atan2(d[..., 0], d[..., 2]), torch.asin(d[..., 1].clamp(-1, 1))
+        u, v = (lon / (2 * np.pi) + 0.5) * (tw - 1), (lat / np.pi + 0.5) * (th - 1)
+        u0, v0 = u.long().clamp(0, tw - 2), v.long().clamp(0, th - 2)
+        fu, fv = u - u0, v - v0
+        val = (tex[v0, u0] * (1 - fu) + tex[v0, u0 + 1] * fu) * (1 - fv) + (tex[v0 + 1, u0] * (1 - fu) + tex[v0 + 1, u0 + 1] * fu) * fv
+        f = torch.empty((h * 3 // 2, w), dtype=torch.uint8, device=dev)
+        f[:h] = val.round().clamp(0, 255).to(torch.uint8)
+        f[h:] = uv
+        frames.append(f)
+        rots.append(R)
+    return frames, rots
+
+
 def cpu_baseline(w, h, K, Ko, cw, ch, budget_s=12.0):
     """The reference's CPU path (cvtColor -> createMap -> remap, FrameSourceWarp.cpp:401,272-314)
     as restated in oracle/vstab_oracle.c, timed on this host on a bounded sample of frames."""
@@ -137,11 +185,16 @@ def main():
                 kernel_events.append((e0, e1))
         workload = f"{args.workload} NV12 {w}x{h} -> BGR {cw}x{ch}, fused undistort-remap (createMap+cvtColor+remap), per-frame rotation, tracking/smoothing NOT included"
     else:
-        stab = vs.Stabilizer.synthetic_clip(dev, w, h, preset=preset, seed=1234 + rank, ring=args.ring,
-                                            frames=args.warmup + args.steps + 64)
+        clip, _ = shaky_ring(torch, dev, w, h, K, args.ring, seed=rank)
+        stab = vs.Stabilizer(clip, total=args.warmup + args.steps + 1000, preset=preset, smooth_radius=30, seed=1234 + rank)
+        assert stab.out_size == (cw, ch)
 
         def step(i, timed):
-            stab.pull_into(outs[i % args.ring], timing=kernel_events if timed else None)
+            if timed and i == args.warmup:
+                stab.profile()               # fold + discard the warm-up stages
+                stab._prof0 = stab.profile()
+            assert stab.pull_into(outs[i % args.ring])
+        stab.enable_profiling(True)
         workload = f"{args.workload} NV12 {w}x{h} -> BGR {cw}x{ch}, full pipeline: NV12 ingest, corner detect, pyramidal LK, rotation estimate, SG smoothing (r=30), fused undistort-remap"
 
     for i in range(args.warmup):
@@ -166,6 +219,14 @@ def main():
     if rank == 0:
         kms = [a.elapsed_time(b) for a, b in kernel_events]
         avg_ms = float(np.mean(kms)) if kms else None
+        stages = None
+        if mode == "pipeline":
+            p1, p0 = stab.profile(), stab._prof0
+            d = {k: p1[k] - p0[k] for k in p1}
+            avg_ms = d["gpu_warp_ms"] / max(1, d["warp_launches"])  # HIP events around each warp launch, library stream
+            stages = {k: round(v / max(1, d["frames_emitted"]) * 1e3, 2) for k, v in d.items() if k.endswith("_ms")}
+            stages = {k.replace("_ms", "_us_per_frame"): v for k, v in stages.items()}
+            stages["key_frames"] = int(d["key_frames"])
         alg_bytes = w * h * 1.5 + cw * ch * 3  # NV12 read once + BGR8 written once
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms else None
         traffic = None
@@ -187,6 +248,8 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
                          "avg_launch_us": round(avg_ms * 1e3, 2) if avg_ms else None},
         }
+        if stages:
+            line["stages"] = stages
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, h, K, Ko, cw, ch)
         print(json.dumps(line), flush=True)

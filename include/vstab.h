@@ -238,6 +238,20 @@ VSTAB_API vstab_status vstab_get_frame_log(const vstab_handle *h, int index, vst
 /* The rotation handed to the warp for the index-th emitted frame (rotation_correction.inv(), :475). */
 VSTAB_API vstab_status vstab_get_warp_rotation(const vstab_handle *h, int index, double R[9]);
 
+/* Per-stage profiler: the role of the reference's Profiler / FrameSourceProfile decorators
+ * (Profiler.cpp:14-35), with GPU stages timed by HIP events on the handle's stream (microsecond
+ * resolution instead of the reference's whole-millisecond truncation).
+ * GPU stages exclude host waits; host stages are steady_clock wall time. */
+typedef struct vstab_profile {
+    long frames_consumed, frames_emitted, key_frames;
+    double gpu_ingest_ms, gpu_pyramid_ms, gpu_corners_ms, gpu_lk_ms, gpu_warp_ms; /* sums of kernel time */
+    double host_corners_ms, host_track_wait_ms, host_estimate_ms, host_smooth_ms;  /* sums of wall time */
+    long warp_launches;
+} vstab_profile;
+VSTAB_API vstab_status vstab_enable_profiling(vstab_handle *h, int enable);
+/* Synchronises the stream, folds all pending event pairs into the sums and returns them. */
+VSTAB_API vstab_status vstab_get_profile(vstab_handle *h, vstab_profile *out);
+
 /* Utility upstream source for benchmarks and tests: cycles over n_frames caller-owned device
  * frames (packed NV12, same size) for total_frames pulls, then reports EOF.  Plays the role of
  * the decode chain upstream of FrameSourceWarp (DisplayImage.cpp:42-53), which is out of scope. */

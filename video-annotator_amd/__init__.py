@@ -61,6 +61,13 @@ class FrameLog(_c.Structure):  # vstab_frame_log
                 ("R_frame", _d * 9), ("R_accum", _d * 9)]
 
 
+class Profile(_c.Structure):  # vstab_profile
+    _fields_ = [("frames_consumed", _c.c_long), ("frames_emitted", _c.c_long), ("key_frames", _c.c_long),
+                ("gpu_ingest_ms", _d), ("gpu_pyramid_ms", _d), ("gpu_corners_ms", _d), ("gpu_lk_ms", _d), ("gpu_warp_ms", _d),
+                ("host_corners_ms", _d), ("host_track_wait_ms", _d), ("host_estimate_ms", _d), ("host_smooth_ms", _d),
+                ("warp_launches", _c.c_long)]
+
+
 SMOOTHER_SG, SMOOTHER_KALMAN, SMOOTHER_NONE = 0, 1, 2
 _pp = _c.POINTER(_vp)
 
@@ -97,6 +104,8 @@ SIGNATURES = {
     "vstab_frame_log_count": (_i, [_vp]),
     "vstab_get_frame_log": (_i, [_vp, _i, _c.POINTER(FrameLog)]),
     "vstab_get_warp_rotation": (_i, [_vp, _i, _dp]),
+    "vstab_enable_profiling": (_i, [_vp, _i]),
+    "vstab_get_profile": (_i, [_vp, _c.POINTER(Profile)]),
     "vstab_ring_source_create": (_i, [_pp, _i, _i, _i, _sz, _c.c_long, _pp, _c.POINTER(Source)]),
     "vstab_ring_source_destroy": (None, [_vp]),
 }
@@ -408,6 +417,14 @@ class Stabilizer:
                             fallback=bool(lg.fallback), R=np.array(lg.R_frame).reshape(3, 3),
                             R_accum=np.array(lg.R_accum).reshape(3, 3)))
         return out
+
+    def enable_profiling(self, on=True):
+        _check(_L.vstab_enable_profiling(self._h, int(on)), "vstab_enable_profiling")
+
+    def profile(self):
+        p = Profile()
+        _check(_L.vstab_get_profile(self._h, _c.byref(p)), "vstab_get_profile")
+        return {k: getattr(p, k) for k, _ in Profile._fields_}
 
     def warp_rotation(self, i):
         R = np.zeros(9)

@@ -2,6 +2,7 @@
 // look-ahead ring in HBM, consume_frame / pull_frame state machine (FrameSourceWarp.cpp:397-476),
 // plus the stateless tracking / motion entry points.  Host C++; every pixel touches a HIP kernel.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <deque>
@@ -168,7 +169,7 @@ class Tracker {
 
     // calcOpticalFlowPyrLK(prev, next, pts): both pyramids must have been built; synchronises
     vstab_status track(const LkPyramid &I, const LkPyramid &J, const std::vector<float> &prev_xy, std::vector<float> &next_xy,
-                       std::vector<uint8_t> &status, hipStream_t st) {
+                       std::vector<uint8_t> &status, hipStream_t st, double *gpu_ms = nullptr) {
         const int n = (int)(prev_xy.size() / 2);
         next_xy.assign(prev_xy.size(), 0.f), status.assign(n, 0);
         if (n == 0) return VSTAB_OK;
@@ -180,9 +181,16 @@ class Tracker {
         uint8_t *h_status = reinterpret_cast<uint8_t *>(h_next + n);
         std::memcpy(h_prev, prev_xy.data(), sizeof(float) * prev_xy.size());
         VSTAB_HIP_TRY(hipMemcpyAsync(d_prev, h_prev, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+        if (gpu_ms && !ev_a_) (void)hipEventCreate(&ev_a_), (void)hipEventCreate(&ev_b_);
+        if (gpu_ms) (void)hipEventRecord(ev_a_, st);
         VSTAB_TRY(launch_lk(I, J, d_prev, n, d_next, d_status, st));
+        if (gpu_ms) (void)hipEventRecord(ev_b_, st);
         VSTAB_HIP_TRY(hipMemcpyAsync(h_next, d_next, sizeof(float2) * n + n, hipMemcpyDeviceToHost, st));
         VSTAB_HIP_TRY(hipStreamSynchronize(st));
+        if (gpu_ms) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev_a_, ev_b_) == hipSuccess) *gpu_ms += ms;
+        }
         std::memcpy(next_xy.data(), h_next, sizeof(float) * next_xy.size());
         std::memcpy(status.data(), h_status, n);
         return VSTAB_OK;
@@ -196,6 +204,7 @@ class Tracker {
     DevBuf pyr_[2][LK_MAX_LEVELS], eig_, keys_, small_, pts_;
     PinnedBuf hsmall_, hkeys_, hpts_;
     unsigned int cap_ = 0;
+    hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
 };
 
 }  // namespace vstab
@@ -234,6 +243,37 @@ struct vstab_handle {
     std::vector<vstab_frame_log> log;
     std::vector<Mat3> warp_log;
 
+    // profiler
+    bool profiling = false;
+    vstab_profile prof{};
+    enum Stage { ST_INGEST, ST_PYRAMID, ST_CORNERS, ST_LK, ST_WARP, ST_COUNT };
+    struct Pending {
+        hipEvent_t a, b;
+        int stage;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+    hipEvent_t get_event() {
+        if (!event_pool.empty()) {
+            hipEvent_t e = event_pool.back();
+            event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void fold_pending() {
+        (void)hipStreamSynchronize(stream);
+        double *sums[ST_COUNT] = {&prof.gpu_ingest_ms, &prof.gpu_pyramid_ms, &prof.gpu_corners_ms, &prof.gpu_lk_ms, &prof.gpu_warp_ms};
+        for (auto &p : pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) *sums[p.stage] += ms;
+            event_pool.push_back(p.a), event_pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+
     int acquire_slot() {
         for (size_t i = 0; i < slots.size(); i++)
             if (!slots[i].queued && !slots[i].last) return (int)i;
@@ -242,7 +282,34 @@ struct vstab_handle {
     const uint8_t *gray(int s) const { return slots[s].buf.as<uint8_t>(); }
 };
 
+struct GpuStage {  // records an event pair around a stage when profiling is on
+    vstab_handle *H;
+    hipEvent_t a = nullptr;
+    int stage;
+    GpuStage(vstab_handle *h, int st) : H(h), stage(st) {
+        if (H->profiling) {
+            a = H->get_event();
+            (void)hipEventRecord(a, H->stream);
+        }
+    }
+    ~GpuStage() {
+        if (a) {
+            hipEvent_t b = H->get_event();
+            (void)hipEventRecord(b, H->stream);
+            H->pending.push_back({a, b, stage});
+            if (H->pending.size() > 4096) H->fold_pending();
+        }
+    }
+};
+struct HostStage {
+    double *sum;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostStage(double *s) : sum(s), t0(std::chrono::steady_clock::now()) {}
+    ~HostStage() { *sum += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
+    GpuStage gs(H, vstab_handle::ST_INGEST);
     if (f.width != H->w || f.height != H->h) return fail(VSTAB_ERR_INVALID, "frame size changed mid-stream");
     uint8_t *dst = H->slots[slot].buf.as<uint8_t>();
     if (f.mem == 0) return vstab_pack_nv12(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->stream);
@@ -271,7 +338,12 @@ static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
     } else if (H->last_key == -1) {
         // :403-407 the first frame only seeds the corner set
         H->last_key = H->frame_index;
-        VSTAB_TRY(H->tracker.good_features(g, pitch, 200, 0.01, 30.0, H->corners, H->stream));
+        {
+            HostStage hs(&H->prof.host_corners_ms);
+            VSTAB_TRY(H->tracker.good_features(g, pitch, 200, 0.01, 30.0, H->corners, H->stream));
+        }
+        H->prof.key_frames++;
+        GpuStage gs(H, vstab_handle::ST_PYRAMID);
         VSTAB_TRY(H->tracker.build_pyramid(H->cur_pyr, g, pitch, H->stream));
     } else {
         vstab_frame_log lg;
@@ -280,16 +352,25 @@ static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
         // :415-419 key-frame rule; corners are found in the PREVIOUS gray frame
         if (H->frame_index - H->last_key > 20 || H->corners.size() / 2 < 150) {
             H->last_key = H->frame_index - 1;
+            HostStage hs(&H->prof.host_corners_ms);
             VSTAB_TRY(H->tracker.good_features(pg, pitch, 200, 0.01, 30.0, H->corners, H->stream));
             lg.key_frame = 1;
+            H->prof.key_frames++;
         }
         lg.n_corners = (int)(H->corners.size() / 2);
         // :422-427 optical flow prev -> current; keep pairs with status != 0
         const int prev_pyr = H->cur_pyr, next_pyr = 1 - H->cur_pyr;
-        VSTAB_TRY(H->tracker.build_pyramid(next_pyr, g, pitch, H->stream));
+        {
+            GpuStage gs(H, vstab_handle::ST_PYRAMID);
+            VSTAB_TRY(H->tracker.build_pyramid(next_pyr, g, pitch, H->stream));
+        }
         std::vector<float> nxt;
         std::vector<uint8_t> st;
-        VSTAB_TRY(H->tracker.track(H->tracker.pyramid(prev_pyr, pg, pitch), H->tracker.pyramid(next_pyr, g, pitch), H->corners, nxt, st, H->stream));
+        {
+            HostStage hs(&H->prof.host_track_wait_ms);
+            VSTAB_TRY(H->tracker.track(H->tracker.pyramid(prev_pyr, pg, pitch), H->tracker.pyramid(next_pyr, g, pitch), H->corners, nxt, st, H->stream,
+                                       H->profiling ? &H->prof.gpu_lk_ms : nullptr));
+        }
         std::vector<float> pp, cp;
         for (size_t i = 0; i < st.size(); i++)
             if (st[i]) {
@@ -301,7 +382,11 @@ static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
         lg.n_tracked = (int)(cp.size() / 2);
         // :429-438 rotation since the last frame, with the < 40 inlier fallback
         Mat3 R;
-        const int inl = estimate_rotation(pp.data(), cp.data(), lg.n_tracked, H->Kin, H->Kout, H->rng, R);
+        int inl;
+        {
+            HostStage hs(&H->prof.host_estimate_ms);
+            inl = estimate_rotation(pp.data(), cp.data(), lg.n_tracked, H->Kin, H->Kout, H->rng, R);
+        }
         lg.n_inliers = inl;
         if (inl < 40) {
             R = H->have_last_rot ? H->last_rot : Mat3::identity();
@@ -316,6 +401,7 @@ static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
         std::memcpy(lg.R_accum, H->measured.m, sizeof(R.m));
         H->log.push_back(lg);
     }
+    H->prof.frames_consumed++;
     if (H->last_slot >= 0) H->slots[H->last_slot].last = false;
     H->slots[slot].last = true;
     H->last_slot = slot;  // :448
@@ -390,16 +476,21 @@ vstab_status vstab_pull_frame(vstab_handle *H, void *dst, size_t pitch_dst) {
     const int slot = H->queue.front().first;
     const Mat3 measured = H->queue.front().second;
     H->queue.pop_front();
-    Mat3 corrected;
-    if (H->cfg.smoother == VSTAB_SMOOTHER_SG)
-        corrected = H->sg->filter();  // :471
-    else if (H->cfg.smoother == VSTAB_SMOOTHER_KALMAN)
-        corrected = H->kalman.update(measured);
-    else
-        corrected = measured;
-    const Mat3 correction = corrected * measured.inv();  // :472
-    const Mat3 warp_R = correction.inv();                // :475
+    Mat3 corrected, warp_R;
+    {
+        HostStage hs(&H->prof.host_smooth_ms);
+        if (H->cfg.smoother == VSTAB_SMOOTHER_SG)
+            corrected = H->sg->filter();  // :471
+        else if (H->cfg.smoother == VSTAB_SMOOTHER_KALMAN)
+            corrected = H->kalman.update(measured);
+        else
+            corrected = measured;
+        const Mat3 correction = corrected * measured.inv();  // :472
+        warp_R = correction.inv();                           // :475
+    }
     H->warp_log.push_back(warp_R);
+    H->prof.frames_emitted++, H->prof.warp_launches++;
+    GpuStage gs(H, vstab_handle::ST_WARP);
     float p[17];
     map_params(H->Kin, H->Kout, warp_R, p);
     const uint8_t *nv12 = H->slots[slot].buf.as<uint8_t>();
@@ -411,9 +502,24 @@ vstab_status vstab_pull_frame(vstab_handle *H, void *dst, size_t pitch_dst) {
 
 vstab_status vstab_peek_frame(vstab_handle *h, void *dst, size_t pitch_dst) { return vstab_pull_frame(h, dst, pitch_dst); }  // :478-480
 
+vstab_status vstab_enable_profiling(vstab_handle *h, int enable) {
+    if (!h) return fail(VSTAB_ERR_INVALID, "null handle");
+    h->profiling = enable != 0;
+    return VSTAB_OK;
+}
+
+vstab_status vstab_get_profile(vstab_handle *h, vstab_profile *out) {
+    if (!h || !out) return fail(VSTAB_ERR_INVALID, "vstab_get_profile: null argument");
+    h->fold_pending();
+    *out = h->prof;
+    return VSTAB_OK;
+}
+
 void vstab_destroy(vstab_handle *h) {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
+    h->fold_pending();
+    for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
