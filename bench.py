@@ -216,6 +216,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    # end-of-run record exchange: the run's only collective (RCCL all-gather over xGMI when N > 1),
+    # then rank 0 writes the stitch list (concat.sh / join.ts format)
+    shard = importlib.import_module("video-annotator_amd.shard")
+    last = outs[(args.warmup + args.steps - 1) % args.ring]
+    rec = dict(rank=rank, clip=rank, frames=args.steps, elapsed_ns=int(el * 1e9), crc=shard.crc_of(last[:64].cpu().numpy()))
+    records = shard.gather_records([rec], device=dev)
+    if rank == 0 and world > 1:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", f"concat_list_{world}gpu.txt"), "w") as fh:
+            fh.write(shard.concat_list([f"clip_{r['clip']:02d}_stabilised.mp4" for r in records]))
+
     if rank == 0:
         kms = [a.elapsed_time(b) for a, b in kernel_events]
         avg_ms = float(np.mean(kms)) if kms else None
@@ -241,7 +252,7 @@ def main():
             "value": round(world * args.steps / el, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 pixels / f32 map / f64 rotations", "data": "synthetic",
-            "config": {"workload": workload, "mode": mode, "clips": world, "ring_frames": args.ring,
+            "config": {"workload": workload, "mode": mode, "clips": len(records), "ring_frames": args.ring,
                        "preset": "GOPRO_H4B_WIDE169_MEASURED", "parallelism": f"clip-per-gpu x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_warp_tiled", "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,

@@ -1,0 +1,73 @@
+"""CPU tests of the multi-GPU path: clip -> rank assignment and the end-of-run record exchange
+over a world_size-2 gloo group (the same code runs over RCCL on GPUs)."""
+import importlib
+import os
+import socket
+
+import numpy as np
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_clips, q):
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    shard = importlib.import_module("video-annotator_amd.shard")
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard.assign_clips(n_clips, world)[rank]
+    recs = [dict(rank=rank, clip=c, frames=100 + c, elapsed_ns=1000 * (c + 1), crc=shard.crc_of(np.full(16, c, np.uint8)))
+            for c in mine]
+    allrec = shard.gather_records(recs)
+    q.put((rank, allrec))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_assign_clips_round_robin():
+    shard = importlib.import_module("video-annotator_amd.shard")
+    assert shard.assign_clips(8, 8) == [[i] for i in range(8)]
+    assert shard.assign_clips(5, 2) == [[0, 2, 4], [1, 3]]
+    assert shard.assign_clips(1, 4) == [[0], [], [], []]
+    flat = sorted(c for r in shard.assign_clips(11, 3) for c in r)
+    assert flat == list(range(11))
+
+
+def test_concat_list_format():
+    shard = importlib.import_module("video-annotator_amd.shard")
+    assert shard.concat_list(["a.mp4", "dir/b c.mp4"]) == "file 'a.mp4'\nfile 'dir/b c.mp4'\n"   # join.ts:51-53
+    assert shard.concat_list(["it's.mp4"]) == "file 'it'\\''s.mp4'\n"
+
+
+def test_gather_records_world2_gloo():
+    import torch.multiprocessing as mp
+    shard = importlib.import_module("video-annotator_amd.shard")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    n_clips = 5   # uneven: rank 0 gets 3 clips, rank 1 gets 2
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]                                  # every rank holds the same clip-ordered list
+    assert [r["clip"] for r in res[0]] == list(range(n_clips))
+    assert [r["rank"] for r in res[0]] == [0, 1, 0, 1, 0]
+    assert res[0][3]["frames"] == 103 and res[0][3]["crc"] == shard.crc_of(np.full(16, 3, np.uint8))
+
+
+def test_gather_records_single_process():
+    shard = importlib.import_module("video-annotator_amd.shard")
+    recs = [dict(rank=0, clip=1, frames=2, elapsed_ns=3, crc=4), dict(rank=0, clip=0, frames=5, elapsed_ns=6, crc=7)]
+    assert [r["clip"] for r in shard.gather_records(recs)] == [0, 1]
