@@ -1,0 +1,110 @@
+// vstab_frame_source.hpp -- header-only C++ mirror of the reference's FrameSource interface
+// (opencv/FrameSource.hpp:9-24) and FrameSourceWarp class (opencv/FrameSourceWarp.hpp:40-96) on top
+// of the C ABI in vstab.h: same class names, constructor arguments, pull/peek semantics and error
+// behaviour (errors and end-of-stream travel as thrown `int`, EOF == -1).
+//
+// Frames are plain descriptors of DEVICE memory instead of cv::UMat, so this header needs neither
+// OpenCV nor OpenCL.  A maintainer wiring it into the reference's DisplayImage.cpp wraps
+// cv::UMat <-> vstab::NV12Frame / BGRFrame (INTEGRATION.md shows the ten lines).
+#pragma once
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+
+#include "vstab.h"
+
+namespace vstab {
+
+// What FrameSourceFfmpegOpenCl yields: one packed or two-plane NV12 frame in device memory.
+struct NV12Frame {
+    const void *y = nullptr, *uv = nullptr;
+    size_t pitch_y = 0, pitch_uv = 0;
+    int width = 0, height = 0;
+    bool host = false;
+};
+
+// What FrameSourceWarp yields: BGR8 in device memory (cv::UMat CV_8UC3 in the reference).
+struct BGRFrame {
+    void *data = nullptr;
+    size_t pitch = 0;
+    int width = 0, height = 0;
+};
+
+// opencv/FrameSource.hpp:9-24 -- "Raises an exception if no frames are ready"
+template <typename FrameT>
+class FrameSourceT {
+  public:
+    virtual FrameT pull_frame() = 0;
+    virtual FrameT peek_frame() = 0;
+    virtual ~FrameSourceT() = default;
+};
+using NV12FrameSource = FrameSourceT<NV12Frame>;
+using FrameSource = FrameSourceT<BGRFrame>;
+
+using CameraPreset = vstab_camera_preset;  // same enumerators with a VSTAB_ prefix
+
+// opencv/FrameSourceWarp.hpp:40-96.  `out` is caller-provided device storage for the frame returned
+// by pull_frame (the reference allocates a fresh UMat per frame; ownership rules: INTEGRATION.md).
+class FrameSourceWarp : public FrameSource {
+  public:
+    FrameSourceWarp(std::shared_ptr<NV12FrameSource> source, CameraPreset input_camera, double scale = 1,
+                    bool crop_borders = false, double zoom = 1, int smooth_radius = 30,
+                    int interpolation = 1 /* cv::INTER_LINEAR */, void *hip_stream = nullptr)
+        : m_source(std::move(source)) {
+        vstab_config cfg;
+        vstab_config_default(&cfg);
+        cfg.preset = input_camera, cfg.scale = scale, cfg.crop_borders = crop_borders, cfg.zoom = zoom;
+        cfg.smooth_radius = smooth_radius, cfg.interpolation = interpolation, cfg.stream = hip_stream;
+        vstab_source src{&FrameSourceWarp::pull_cb, &FrameSourceWarp::peek_cb, this};
+        const vstab_status st = vstab_create(&cfg, &src, &m_handle);
+        if (st != VSTAB_OK) {
+            std::fprintf(stderr, "FrameSourceWarp: %s\n", vstab_last_error());
+            throw m_pending_error ? m_pending_error : (int)st;  // the reference rethrows the upstream int (:462)
+        }
+        vstab_get_output_info(m_handle, &m_out_w, &m_out_h, nullptr, nullptr);
+    }
+    ~FrameSourceWarp() override { vstab_destroy(m_handle); }
+    FrameSourceWarp(const FrameSourceWarp &) = delete;
+    FrameSourceWarp &operator=(const FrameSourceWarp &) = delete;
+
+    int output_width() const { return m_out_w; }
+    int output_height() const { return m_out_h; }
+    // storage for the next returned frame: width*3 <= pitch, output_height() rows, device memory
+    void set_output(void *device_bgr, size_t pitch) { m_out = device_bgr, m_pitch = pitch; }
+
+    BGRFrame pull_frame() override {  // FrameSourceWarp.cpp:452-476
+        if (!m_out) throw -1;
+        const vstab_status st = vstab_pull_frame(m_handle, m_out, m_pitch);
+        if (st == VSTAB_EOF) throw (int)EOF;                           // :466
+        if (st == VSTAB_ERR_SOURCE && m_pending_error) throw m_pending_error;  // :462 `throw err`
+        if (st != VSTAB_OK) {
+            std::fprintf(stderr, "FrameSourceWarp: %s\n", vstab_last_error());
+            throw (int)st;
+        }
+        return BGRFrame{m_out, m_pitch, m_out_w, m_out_h};
+    }
+    BGRFrame peek_frame() override { return pull_frame(); }  // :478-480 (destructive in the reference too)
+
+  private:
+    static int fill(FrameSourceWarp *self, vstab_frame *out, bool advance) {
+        try {
+            const NV12Frame f = advance ? self->m_source->pull_frame() : self->m_source->peek_frame();
+            out->y = f.y, out->uv = f.uv, out->pitch_y = f.pitch_y, out->pitch_uv = f.pitch_uv;
+            out->width = f.width, out->height = f.height, out->mem = f.host ? 1 : 0, out->pts = 0;
+            return 0;
+        } catch (int err) {  // upstream errors are thrown ints (AvFrameSourceFileVaapi.cpp:141)
+            if (err != EOF) self->m_pending_error = err;
+            return err == EOF ? (int)VSTAB_EOF : (err ? err : 1);
+        }
+    }
+    static int pull_cb(void *user, vstab_frame *out) { return fill(static_cast<FrameSourceWarp *>(user), out, true); }
+    static int peek_cb(void *user, vstab_frame *out) { return fill(static_cast<FrameSourceWarp *>(user), out, false); }
+
+    std::shared_ptr<NV12FrameSource> m_source;
+    vstab_handle *m_handle = nullptr;
+    void *m_out = nullptr;
+    size_t m_pitch = 0;
+    int m_out_w = 0, m_out_h = 0, m_pending_error = 0;
+};
+
+}  // namespace vstab
