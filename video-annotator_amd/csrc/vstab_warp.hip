@@ -284,42 +284,57 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
     const int x0 = blockIdx.x * WARP_TILE_W + tx * 4;
     const int ybase = blockIdx.y * (16 * RPT) + ty;
     if (tid == 0) bbox[0] = bbox[1] = INT_MAX, bbox[2] = bbox[3] = INT_MIN;
+    __syncthreads();
 
     // ---------------- phase 1: map + quantise + classify -------------------------------------
     int sx[RPT][4], sy[RPT][4];
-    uint32_t cls = 0;  // 2 bits per pixel: 0 black / not stored, 1 inside (LDS), 2 border (gather)
+    uint32_t in_bits = 0, border_bits = 0;  // bit (j*4+i): pixel samples fully inside / crosses the source border
     int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
     {
+        // column / row terms with ONE refined reciprocal per axis (createMap.cl:16-17 divisions)
+        const float rfx = rcp_refined(a.p.ofx), rfy = rcp_refined(a.p.ofy);
         ColTerm ct[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) ct[i] = col_term(a.p, x0 + i);
+        for (int i = 0; i < 4; i++) {
+            const float vx = div_with_rcp((float)(x0 + i) - a.p.ocx, a.p.ofx, rfx);
+            ct[i] = {a.p.r[0] * vx, a.p.r[3] * vx, a.p.r[6] * vx};
+        }
+        const uint32_t sw1 = (uint32_t)(a.sw - 1), sh1 = (uint32_t)(a.sh - 1);
 #pragma unroll
         for (int j = 0; j < RPT; j++) {
             const int y = ybase + 16 * j;
-            const RowTerm rt = row_term(a.p, y);
+            const float vy = div_with_rcp((float)y - a.p.ocy, a.p.ofy, rfy);
+            const RowTerm rt = {a.p.r[1] * vy, a.p.r[4] * vy, a.p.r[7] * vy};
+            const bool row_ok = y < a.dh;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float ax, ay;
                 map_pixel32(ta.p32, ct[i], rt, ax, ay);
                 // |32*map| >= 2^22 (or NaN) is outside any source <= 32767 wide; see quantise()
-                const bool ok = (fabsf(ax) < 4194304.0f) && (fabsf(ay) < 4194304.0f) && (x0 + i < a.dw) && (y < a.dh);
+                const bool ok = (fabsf(ax) < 4194304.0f) && (fabsf(ay) < 4194304.0f) && row_ok && (x0 + i < a.dw);
                 const int qx = (int)__builtin_rintf(ax), qy = (int)__builtin_rintf(ay);
                 const int X = qx >> 5, Y = qy >> 5;
-                const bool inside = ok && (unsigned)X < (unsigned)(a.sw - 1) && (unsigned)Y < (unsigned)(a.sh - 1);
-                const bool touches = ok && X < a.sw && X + 1 >= 0 && Y < a.sh && Y + 1 >= 0;
                 sx[j][i] = qx, sy[j][i] = qy;
-                cls |= (inside ? 1u : touches ? 2u : 0u) << (2 * (j * 4 + i));
-                if (inside) mnx = min(mnx, X), mxx = max(mxx, X), mny = min(mny, Y), mxy = max(mxy, Y);
+                const bool inside = ok && (uint32_t)X < sw1 && (uint32_t)Y < sh1;
+                if (inside) {
+                    in_bits |= 1u << (j * 4 + i);
+                    mnx = min(mnx, X), mxx = max(mxx, X), mny = min(mny, Y), mxy = max(mxy, Y);
+                } else if (ok && X < a.sw && X + 1 >= 0 && Y < a.sh && Y + 1 >= 0) {
+                    border_bits |= 1u << (j * 4 + i);
+                }
             }
         }
     }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        mnx = min(mnx, __shfl_xor(mnx, m)), mny = min(mny, __shfl_xor(mny, m));
-        mxx = max(mxx, __shfl_xor(mxx, m)), mxy = max(mxy, __shfl_xor(mxy, m));
-    }
-    __syncthreads();  // bbox initialised
-    if ((tid & 63) == 0 && mnx <= mxx) {
+    // bounding box: DPP reduction inside each 16-lane row (4 steps), then one LDS atomic per row.
+    // (same-address LDS atomics from all 64 lanes serialise badly; shuffles cost 6 steps + bpermutes)
+#define VSTAB_ROW_STEP(n)                                                                       \
+    mnx = min(mnx, __builtin_amdgcn_update_dpp(INT_MAX, mnx, 0x110 + n, 0xf, 0xf, false));       \
+    mny = min(mny, __builtin_amdgcn_update_dpp(INT_MAX, mny, 0x110 + n, 0xf, 0xf, false));       \
+    mxx = max(mxx, __builtin_amdgcn_update_dpp(INT_MIN, mxx, 0x110 + n, 0xf, 0xf, false));       \
+    mxy = max(mxy, __builtin_amdgcn_update_dpp(INT_MIN, mxy, 0x110 + n, 0xf, 0xf, false));
+    VSTAB_ROW_STEP(1) VSTAB_ROW_STEP(2) VSTAB_ROW_STEP(4) VSTAB_ROW_STEP(8)
+#undef VSTAB_ROW_STEP
+    if (tx == 15 && mnx <= mxx) {  // lane 15 of each row holds the row's bounds
         atomicMin(&bbox[0], mnx), atomicMin(&bbox[1], mny), atomicMax(&bbox[2], mxx), atomicMax(&bbox[3], mxy);
     }
     __syncthreads();
@@ -333,19 +348,20 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
     if (use_lds && dbg != 1 && dbg != 3) {
         const int ux_n = wb >> 2, units = ux_n * (hb >> 1);
         const uint32_t magic = (1u << 18) / (uint32_t)ux_n + 1u;  // u / ux_n == (u * magic) >> 18 for u < 2048
+        const uint32_t pitch_y = (uint32_t)a.pitch_y, pitch_uv = (uint32_t)a.pitch_uv;  // < 2^24 (host check)
         for (int u = tid; u < units; u += 256) {
-            const int uy = (int)(((uint32_t)u * magic) >> 18), ux = u - uy * ux_n;
-            const int gx = bx0 + 4 * ux, gy = by0 + 2 * uy;
-            const uint8_t *py0 = a.y + (size_t)gy * a.pitch_y + gx;
-            const uint8_t *puv = a.uv + (size_t)(gy >> 1) * a.pitch_uv + gx;
+            const uint32_t uy = ((uint32_t)u * magic) >> 18, ux = (uint32_t)u - __umul24(uy, (uint32_t)ux_n);
+            const uint32_t gx = (uint32_t)bx0 + 4u * ux, gy = (uint32_t)by0 + 2u * uy;
+            const uint32_t oy = __umul24(gy, pitch_y) + gx, ouv = __umul24(gy >> 1, pitch_uv) + gx;  // frame < 4 GiB
             uint32_t y0w, y1w, uvw;
-            if (ta.src_vec_ok && gx + 4 <= a.sw) {
-                y0w = *reinterpret_cast<const uint32_t *>(py0);
-                y1w = *reinterpret_cast<const uint32_t *>(py0 + a.pitch_y);
-                uvw = *reinterpret_cast<const uint32_t *>(puv);
+            if (ta.src_vec_ok && (int)gx + 4 <= a.sw) {
+                y0w = *reinterpret_cast<const uint32_t *>(a.y + oy);
+                y1w = *reinterpret_cast<const uint32_t *>(a.y + oy + pitch_y);
+                uvw = *reinterpret_cast<const uint32_t *>(a.uv + ouv);
             } else {
-                const int valid = min(4, a.sw - gx);
-                y0w = load_u32_bytes(py0, valid), y1w = load_u32_bytes(py0 + a.pitch_y, valid), uvw = load_u32_bytes(puv, valid);
+                const int valid = min(4, a.sw - (int)gx);
+                y0w = load_u32_bytes(a.y + oy, valid), y1w = load_u32_bytes(a.y + oy + pitch_y, valid);
+                uvw = load_u32_bytes(a.uv + ouv, valid);
             }
             const ChromaTerm c0 = chroma_term_folded(uvw & 255, (uvw >> 8) & 255);
             const ChromaTerm c1 = chroma_term_folded((uvw >> 16) & 255, uvw >> 24);
@@ -354,7 +370,7 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
             r0.z = pack_bgrx((y0w >> 16) & 255, c1), r0.w = pack_bgrx(y0w >> 24, c1);
             r1.x = pack_bgrx(y1w & 255, c0), r1.y = pack_bgrx((y1w >> 8) & 255, c0);
             r1.z = pack_bgrx((y1w >> 16) & 255, c1), r1.w = pack_bgrx(y1w >> 24, c1);
-            uint32_t *d = tile + (2 * uy) * wb + 4 * ux;
+            uint32_t *d = tile + __umul24(2u * uy, (uint32_t)wb) + 4u * ux;
             *reinterpret_cast<uint4 *>(d) = r0;
             *reinterpret_cast<uint4 *>(d + wb) = r1;
         }
@@ -363,6 +379,7 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
 
     // ---------------- phase 3: sample, blend, store ---------------------------------------------
     if (x0 >= a.dw) return;
+    const int lds_origin = by0 * wb + bx0;
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
         const int y = ybase + 16 * j;
@@ -370,19 +387,19 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
         uint32_t px[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t c = (cls >> (2 * (j * 4 + i))) & 3u;
+            const uint32_t bit = 1u << (j * 4 + i);
             uint32_t v = 0;
             if (dbg == 1 || dbg == 2) {
                 v = (uint32_t)(sx[j][i] ^ sy[j][i]) ^ tile[tid];
-            } else if (c == 1u && use_lds) {
-                const int idx = ((sy[j][i] >> 5) - by0) * wb + ((sx[j][i] >> 5) - bx0);
-                v = blend_bgrx(tile[idx], tile[idx + 1], tile[idx + wb], tile[idx + wb + 1], sx[j][i] & 31, sy[j][i] & 31);
-            } else if (c != 0u) {
+            } else if ((in_bits & bit) && use_lds) {
+                const uint32_t *t = tile + (__mul24(sy[j][i] >> 5, wb) + (sx[j][i] >> 5) - lds_origin);
+                v = blend_bgrx(t[0], t[1], t[wb], t[wb + 1], sx[j][i] & 31, sy[j][i] & 31);
+            } else if ((in_bits | border_bits) & bit) {
                 v = gather_pixel(a, sx[j][i], sy[j][i]);
             }
             px[i] = v;
         }
-        uint8_t *o = a.dst + (size_t)y * a.pitch_dst + (size_t)x0 * 3;
+        uint8_t *o = a.dst + ((size_t)(uint32_t)y * a.pitch_dst + (uint32_t)x0 * 3u);
         if (ta.dst_vec_ok && x0 + 4 <= a.dw) {
             uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
             o32[0] = px[0] | (px[1] << 24);
@@ -511,7 +528,8 @@ vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const void *uv, 
     a.p = to_params(params);
     const int vec_ok = aligned(dst, 4) && pitch_dst % 4 == 0;
     static const int variant = getenv("VSTAB_WARP_VARIANT") ? atoi(getenv("VSTAB_WARP_VARIANT")) : 2;
-    if (variant == 1) {  // v1 direct-gather kernel (kept as the in-kernel fallback's twin, for A/B runs)
+    const bool small_pitch = pitch_y < (1u << 24) && pitch_uv < (1u << 24) && (uint64_t)pitch_y * sh < (1ull << 32);
+    if (variant == 1 || !small_pitch) {  // v1 direct-gather kernel (kept as the in-kernel fallback's twin, for A/B runs)
         dim3 grid(div_up(dw, WARP_TILE_W), div_up(dh, WARP_TILE_H));
         hipLaunchKernelGGL(k_warp_nv12_bgr, grid, dim3(16, 16), 0, static_cast<hipStream_t>(stream), a, vec_ok);
     } else {
@@ -522,11 +540,17 @@ vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const void *uv, 
         ta.dst_vec_ok = vec_ok;
         static const int dbg = getenv("VSTAB_DEBUG_MODE") ? atoi(getenv("VSTAB_DEBUG_MODE")) : 0;
         ta.debug_mode = dbg;
-        constexpr int RPT = 2;
-        const size_t lds_bytes = 40 * 1024;  // 4 workgroups (16 waves) per CU
+        static const int rpt = getenv("VSTAB_RPT") ? atoi(getenv("VSTAB_RPT")) : 2;
+        static const int lds_kb = getenv("VSTAB_LDS_KB") ? atoi(getenv("VSTAB_LDS_KB")) : 40;
+        const size_t lds_bytes = (size_t)lds_kb * 1024;  // 40 KB -> 4 workgroups (16 waves) per CU
         ta.lds_capacity_px = (int)(lds_bytes / 4) - 4;
-        dim3 grid(div_up(dw, WARP_TILE_W), div_up(dh, 16 * RPT));
-        hipLaunchKernelGGL(k_warp_tiled<RPT>, grid, dim3(256), lds_bytes, static_cast<hipStream_t>(stream), ta);
+        dim3 grid(div_up(dw, WARP_TILE_W), div_up(dh, 16 * rpt));
+        if (rpt == 1)
+            hipLaunchKernelGGL(k_warp_tiled<1>, grid, dim3(256), lds_bytes, static_cast<hipStream_t>(stream), ta);
+        else if (rpt == 4)
+            hipLaunchKernelGGL(k_warp_tiled<4>, grid, dim3(256), lds_bytes, static_cast<hipStream_t>(stream), ta);
+        else
+            hipLaunchKernelGGL(k_warp_tiled<2>, grid, dim3(256), lds_bytes, static_cast<hipStream_t>(stream), ta);
     }
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
