@@ -202,7 +202,8 @@ typedef struct vstab_config {
     int smoother;        /* VSTAB_SMOOTHER_SG (reference behaviour) */
     int tracking;        /* 1; 0 = undistort only: rotations are identity (BASELINE config 1) */
     uint64_t seed;       /* PCG32 seed replacing the reference's un-seeded rand() */
-    void *stream;        /* hipStream_t all work of this handle is enqueued on; NULL = default stream */
+    void *stream;        /* hipStream_t the warp (and so dst) is enqueued on; NULL = default stream.  Ingest and
+                            tracking run on an internal stream that overlaps it; ordering is by events. */
 } vstab_config;
 
 typedef struct vstab_handle vstab_handle;
@@ -216,7 +217,8 @@ VSTAB_API vstab_status vstab_get_output_info(const vstab_handle *h, int *width, 
 /* FrameSourceWarp::pull_frame (:452-476): consumes upstream frames until smooth_radius+1 are
  * buffered (or EOF), then warps the oldest buffered frame into dst (device BGR8).  Returns
  * VSTAB_EOF when the stream is drained.  The first input frame is never emitted (:403-407).
- * Work is enqueued on the handle's stream; dst is complete after that stream is synchronised. */
+ * dst is complete once vstab_config.stream is synchronised.  Upstream frames handed to the callbacks
+ * must already be complete in memory when the callback returns (they are read on an internal stream). */
 VSTAB_API vstab_status vstab_pull_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
 /* FrameSourceWarp::peek_frame (:478-480) IS pull_frame in the reference (destructive); kept. */
 VSTAB_API vstab_status vstab_peek_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);

@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage (on the GPU box): bash tools/prof_bench.sh <tag>
+# kernel-trace stats + separate PMC passes (FETCH_SIZE / WRITE_SIZE each alone) of the default bench
+# command, plus the PMC calibration kernels.  Output: gpurun_out/prof_<tag>/
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+TAG=${1:-bench}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+ARGS="$R/bench.py --steps 300 --warmup 64 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -- python3 $R/tools/calib_traffic.py > $OUT/cal_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -- python3 $R/tools/calib_traffic.py > $OUT/cal_write.log 2>&1
+python3 $R/tools/summarize_bench_prof.py $OUT

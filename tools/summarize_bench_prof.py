@@ -1,0 +1,45 @@
+"""Summarise tools/prof_bench.sh output: per-kernel stats, PMC means per launch, calibrated HBM bytes."""
+import csv, glob, json, os, sys, collections
+out = sys.argv[1]
+lines = []
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "vstab::" in r["Name"]:
+            lines.append(f"stats: {r['Name'][:70]:70s} calls={r['Calls']:>5s} avg_ns={float(r['AverageNs']):10.1f} min={r['MinNs']} max={r['MaxNs']} pct={r['Percentage']}")
+def pmc(dirname):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(out, dirname, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "vstab::" in r["Kernel_Name"]:
+                acc[(r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+res = {}
+for d in ("pmc_fetch", "pmc_write", "cal_fetch", "cal_write"):
+    for (k, c), v in sorted(pmc(d).items()):
+        lines.append(f"pmc[{d}]: {k:42s} {c:12s} mean_per_launch={v:.5g} (KB)")
+        res[(d, k, c)] = v
+def find(d, frag, c):
+    for (dd, k, cc), v in res.items():
+        if dd == d and frag in k and cc == c:
+            return v
+    return None
+known = 3840 * 2160 * 1.5
+cal16 = find("cal_fetch", "uint4", "FETCH_SIZE") or find("cal_fetch", "HIP_vector_type", "FETCH_SIZE")
+cal4 = find("cal_fetch", "k_pack_nv12<unsigned int>", "FETCH_SIZE")
+calw16 = find("cal_write", "uint4", "WRITE_SIZE") or find("cal_write", "HIP_vector_type", "WRITE_SIZE")
+wf, ww = find("pmc_fetch", "k_warp_tiled", "FETCH_SIZE"), find("pmc_write", "k_warp_tiled", "WRITE_SIZE")
+summary = {"known_copy_bytes": known}
+if cal16: summary["fetch_factor_16B_per_lane"] = known / (cal16 * 1024)
+if cal4: summary["fetch_factor_4B_per_lane"] = known / (cal4 * 1024)
+if calw16: summary["write_factor_16B_per_lane"] = known / (calw16 * 1024)
+if wf and ww:
+    ff = summary.get("fetch_factor_4B_per_lane", 1.0)   # the warp kernel stages with 4 B/lane loads
+    summary["warp_fetch_bytes_raw"] = wf * 1024
+    summary["warp_write_bytes_raw"] = ww * 1024
+    summary["warp_fetch_bytes_corrected"] = wf * 1024 * ff
+    summary["hbm_bytes_per_launch"] = wf * 1024 * ff + ww * 1024
+    summary["algorithmic_bytes_per_launch"] = 3840 * 2160 * 1.5 + 3524 * 1999 * 3
+lines.append("traffic: " + json.dumps(summary))
+open(os.path.join(out, "summary.txt"), "w").write("\n".join(lines) + "\n")
+json.dump(summary, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+print("\n".join(lines))

@@ -217,8 +217,8 @@ using namespace vstab;
 struct vstab_handle {
     vstab_config cfg;
     vstab_source src;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
+    hipStream_t stream = nullptr;   // caller-visible stream: the warp runs here, dst is complete when it drains
+    hipStream_t tstream = nullptr;  // internal stream: ingest, pyramids, corner detection, LK (overlaps the warp)
     int w = 0, h = 0, ow = 0, oh = 0;
     Mat3 Kin, Kout;
     Tracker tracker;
@@ -226,7 +226,12 @@ struct vstab_handle {
     struct Slot {
         DevBuf buf;  // packed NV12, pitch = w
         bool queued = false, last = false;
+        long freed_at = 0;               // FIFO reuse: the slot idle the longest is taken first
+        hipEvent_t ingested = nullptr;   // recorded on tstream after the copy into the slot
+        hipEvent_t warped = nullptr;     // recorded on stream after the warp that read the slot
+        bool warp_pending = false;
     };
+    long free_counter = 0;
     std::vector<Slot> slots;
     int last_slot = -1;  // m_last_input_frame
     int cur_pyr = 0;     // pyramid slot holding the last input frame's pyramid
@@ -264,6 +269,7 @@ struct vstab_handle {
         return e;
     }
     void fold_pending() {
+        (void)hipStreamSynchronize(tstream);
         (void)hipStreamSynchronize(stream);
         double *sums[ST_COUNT] = {&prof.gpu_ingest_ms, &prof.gpu_pyramid_ms, &prof.gpu_corners_ms, &prof.gpu_lk_ms, &prof.gpu_warp_ms};
         for (auto &p : pending) {
@@ -275,9 +281,10 @@ struct vstab_handle {
     }
 
     int acquire_slot() {
+        int best = -1;
         for (size_t i = 0; i < slots.size(); i++)
-            if (!slots[i].queued && !slots[i].last) return (int)i;
-        return -1;
+            if (!slots[i].queued && !slots[i].last && (best < 0 || slots[i].freed_at < slots[best].freed_at)) best = (int)i;
+        return best;
     }
     const uint8_t *gray(int s) const { return slots[s].buf.as<uint8_t>(); }
 };
@@ -286,16 +293,17 @@ struct GpuStage {  // records an event pair around a stage when profiling is on
     vstab_handle *H;
     hipEvent_t a = nullptr;
     int stage;
-    GpuStage(vstab_handle *h, int st) : H(h), stage(st) {
+    hipStream_t s;
+    GpuStage(vstab_handle *h, int st) : H(h), stage(st), s(st == vstab_handle::ST_WARP ? h->stream : h->tstream) {
         if (H->profiling) {
             a = H->get_event();
-            (void)hipEventRecord(a, H->stream);
+            (void)hipEventRecord(a, s);
         }
     }
     ~GpuStage() {
         if (a) {
             hipEvent_t b = H->get_event();
-            (void)hipEventRecord(b, H->stream);
+            (void)hipEventRecord(b, s);
             H->pending.push_back({a, b, stage});
             if (H->pending.size() > 4096) H->fold_pending();
         }
@@ -311,11 +319,20 @@ struct HostStage {
 static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
     GpuStage gs(H, vstab_handle::ST_INGEST);
     if (f.width != H->w || f.height != H->h) return fail(VSTAB_ERR_INVALID, "frame size changed mid-stream");
-    uint8_t *dst = H->slots[slot].buf.as<uint8_t>();
-    if (f.mem == 0) return vstab_pack_nv12(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->stream);
-    VSTAB_HIP_TRY(hipMemcpy2DAsync(dst, H->w, f.y, f.pitch_y, H->w, H->h, hipMemcpyHostToDevice, H->stream));
-    VSTAB_HIP_TRY(hipMemcpy2DAsync(dst + (size_t)H->w * H->h, H->w, f.uv, f.pitch_uv, H->w, H->h / 2, hipMemcpyHostToDevice, H->stream));
-    VSTAB_HIP_TRY(hipStreamSynchronize(H->stream));  // the caller may reuse its host buffer on return
+    vstab_handle::Slot &S = H->slots[slot];
+    uint8_t *dst = S.buf.as<uint8_t>();
+    if (S.warp_pending) {  // the warp that last read this slot runs on the other stream
+        VSTAB_HIP_TRY(hipStreamWaitEvent(H->tstream, S.warped, 0));
+        S.warp_pending = false;
+    }
+    if (f.mem == 0) {
+        VSTAB_TRY(vstab_pack_nv12(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->tstream));
+    } else {
+        VSTAB_HIP_TRY(hipMemcpy2DAsync(dst, H->w, f.y, f.pitch_y, H->w, H->h, hipMemcpyHostToDevice, H->tstream));
+        VSTAB_HIP_TRY(hipMemcpy2DAsync(dst + (size_t)H->w * H->h, H->w, f.uv, f.pitch_uv, H->w, H->h / 2, hipMemcpyHostToDevice, H->tstream));
+        VSTAB_HIP_TRY(hipStreamSynchronize(H->tstream));  // the caller may reuse its host buffer on return
+    }
+    VSTAB_HIP_TRY(hipEventRecord(S.ingested, H->tstream));
     return VSTAB_OK;
 }
 
@@ -340,11 +357,11 @@ static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
         H->last_key = H->frame_index;
         {
             HostStage hs(&H->prof.host_corners_ms);
-            VSTAB_TRY(H->tracker.good_features(g, pitch, 200, 0.01, 30.0, H->corners, H->stream));
+            VSTAB_TRY(H->tracker.good_features(g, pitch, 200, 0.01, 30.0, H->corners, H->tstream));
         }
         H->prof.key_frames++;
         GpuStage gs(H, vstab_handle::ST_PYRAMID);
-        VSTAB_TRY(H->tracker.build_pyramid(H->cur_pyr, g, pitch, H->stream));
+        VSTAB_TRY(H->tracker.build_pyramid(H->cur_pyr, g, pitch, H->tstream));
     } else {
         vstab_frame_log lg;
         std::memset(&lg, 0, sizeof(lg));
@@ -353,7 +370,7 @@ static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
         if (H->frame_index - H->last_key > 20 || H->corners.size() / 2 < 150) {
             H->last_key = H->frame_index - 1;
             HostStage hs(&H->prof.host_corners_ms);
-            VSTAB_TRY(H->tracker.good_features(pg, pitch, 200, 0.01, 30.0, H->corners, H->stream));
+            VSTAB_TRY(H->tracker.good_features(pg, pitch, 200, 0.01, 30.0, H->corners, H->tstream));
             lg.key_frame = 1;
             H->prof.key_frames++;
         }
@@ -362,13 +379,13 @@ static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
         const int prev_pyr = H->cur_pyr, next_pyr = 1 - H->cur_pyr;
         {
             GpuStage gs(H, vstab_handle::ST_PYRAMID);
-            VSTAB_TRY(H->tracker.build_pyramid(next_pyr, g, pitch, H->stream));
+            VSTAB_TRY(H->tracker.build_pyramid(next_pyr, g, pitch, H->tstream));
         }
         std::vector<float> nxt;
         std::vector<uint8_t> st;
         {
             HostStage hs(&H->prof.host_track_wait_ms);
-            VSTAB_TRY(H->tracker.track(H->tracker.pyramid(prev_pyr, pg, pitch), H->tracker.pyramid(next_pyr, g, pitch), H->corners, nxt, st, H->stream,
+            VSTAB_TRY(H->tracker.track(H->tracker.pyramid(prev_pyr, pg, pitch), H->tracker.pyramid(next_pyr, g, pitch), H->corners, nxt, st, H->tstream,
                                        H->profiling ? &H->prof.gpu_lk_ms : nullptr));
         }
         std::vector<float> pp, cp;
@@ -402,7 +419,10 @@ static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
         H->log.push_back(lg);
     }
     H->prof.frames_consumed++;
-    if (H->last_slot >= 0) H->slots[H->last_slot].last = false;
+    if (H->last_slot >= 0) {
+        H->slots[H->last_slot].last = false;
+        if (!H->slots[H->last_slot].queued) H->slots[H->last_slot].freed_at = ++H->free_counter;
+    }
     H->slots[slot].last = true;
     H->last_slot = slot;  // :448
     ++H->frame_index;     // :449
@@ -428,6 +448,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     H->cfg = *cfg, H->src = *src;
     H->rng = Pcg32(cfg->seed);
     H->stream = static_cast<hipStream_t>(cfg->stream);  // NULL = the default stream, as for the stateless operators
+    VSTAB_HIP_TRY(hipStreamCreateWithFlags(&H->tstream, hipStreamNonBlocking));
     // :214-219 peek the first frame for the input size, then derive both cameras
     vstab_frame f;
     std::memset(&f, 0, sizeof(f));
@@ -441,8 +462,12 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     output_camera(H->Kin, H->w, H->h, cfg->scale, cfg->crop_borders != 0, cfg->zoom, H->Kout, H->ow, H->oh);
     if (H->ow <= 0 || H->oh <= 0 || H->ow > 32767 || H->oh > 32767) return fail(VSTAB_ERR_INVALID, "vstab_create: output size out of range");
     if (cfg->smoother == VSTAB_SMOOTHER_SG) H->sg.reset(new RotationFilterSG(cfg->smooth_radius));
-    H->slots.resize((size_t)cfg->smooth_radius + 3);
-    for (auto &s : H->slots) VSTAB_TRY(s.buf.ensure((size_t)H->w * H->h * 3 / 2));
+    H->slots.resize((size_t)cfg->smooth_radius + 5);  // queue (r+1) + incoming + last gray + 2 spare for stream overlap
+    for (auto &s : H->slots) {
+        VSTAB_TRY(s.buf.ensure((size_t)H->w * H->h * 3 / 2));
+        VSTAB_HIP_TRY(hipEventCreateWithFlags(&s.ingested, hipEventDisableTiming));
+        VSTAB_HIP_TRY(hipEventCreateWithFlags(&s.warped, hipEventDisableTiming));
+    }
     if (cfg->tracking) VSTAB_TRY(H->tracker.init(H->w, H->h));
     *out = H.release();
     return VSTAB_OK;
@@ -493,10 +518,13 @@ vstab_status vstab_pull_frame(vstab_handle *H, void *dst, size_t pitch_dst) {
     GpuStage gs(H, vstab_handle::ST_WARP);
     float p[17];
     map_params(H->Kin, H->Kout, warp_R, p);
-    const uint8_t *nv12 = H->slots[slot].buf.as<uint8_t>();
+    vstab_handle::Slot &S = H->slots[slot];
+    const uint8_t *nv12 = S.buf.as<uint8_t>();
+    VSTAB_HIP_TRY(hipStreamWaitEvent(H->stream, S.ingested, 0));  // the slot was filled on the tracking stream
     const vstab_status st = vstab_warp_nv12_bgr(nv12, (size_t)H->w, nv12 + (size_t)H->w * H->h, (size_t)H->w, H->w, H->h, p, dst,
                                                 pitch_dst, H->ow, H->oh, H->stream);
-    H->slots[slot].queued = false;  // stream order protects the slot until the warp has read it
+    VSTAB_HIP_TRY(hipEventRecord(S.warped, H->stream));  // the next ingest into this slot waits for it
+    S.warp_pending = true, S.queued = false, S.freed_at = ++H->free_counter;
     return st;
 }
 
@@ -517,10 +545,13 @@ vstab_status vstab_get_profile(vstab_handle *h, vstab_profile *out) {
 
 void vstab_destroy(vstab_handle *h) {
     if (!h) return;
-    (void)hipStreamSynchronize(h->stream);
-    h->fold_pending();
+    h->fold_pending();  // drains both streams
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
-    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    for (auto &s : h->slots) {
+        if (s.ingested) (void)hipEventDestroy(s.ingested);
+        if (s.warped) (void)hipEventDestroy(s.warped);
+    }
+    if (h->tstream) (void)hipStreamDestroy(h->tstream);
     delete h;
 }
 

@@ -133,14 +133,30 @@ __global__ void __launch_bounds__(256) k_corner_candidates(const float *__restri
 // float operation order.
 // =============================================================================================
 constexpr int LKW = 21, LKR = 24, LKT = 22;
+constexpr int LKJM = 5, LKJR = LKT + 2 * LKJM;  // next-image region: 22x22 taps + 5 px of slack each side
 
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const int lo = __shfl_xor((int)(v & 0xffffffffll), m), hi = __shfl_xor((int)(v >> 32), m);
-        v += ((long long)hi << 32) | (unsigned int)lo;
-    }
-    return v;
+// Full-wave integer sum by DPP (row_shr 1,2,4,8 then row_bcast 15/31); the total is read from
+// lane 63 and broadcast through an SGPR.  Integer addition is associative, so the order is free.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// per-lane |v| < 2^31: split into a signed high part and a 16-bit low part so that both partial
+// sums over 64 lanes stay inside int32, then recombine exactly
+__device__ __forceinline__ long long wave_sum_split(int v) {
+    const int hi = wave_sum_i32(v >> 16), lo = wave_sum_i32(v & 0xffff);
+    return ((long long)hi << 16) + lo;
+}
+// the same total as a float: hi*65536 + lo is exact in double (|.| < 2^53), and double -> float
+// rounds the exact integer once, i.e. equals (float)(int64 sum)
+__device__ __forceinline__ float wave_sum_split_f32(int v) {
+    const int hi = wave_sum_i32(v >> 16), lo = wave_sum_i32(v & 0xffff);
+    return (float)__builtin_fma((double)hi, 65536.0, (double)lo);
 }
 
 #define LK_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
@@ -149,7 +165,7 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
                                                  int n, float2 *__restrict__ next_pts, uint8_t *__restrict__ status) {
     __shared__ int regI[LKR * LKR];
     __shared__ int derx[LKT * LKT], dery[LKT * LKT];
-    __shared__ int regJ[LKT * LKT];
+    __shared__ int regJ[LKJR * LKJR];
     const int f = blockIdx.x, lane = threadIdx.x;
     if (f >= n) return;
     const float2 pp = prev_pts[f];
@@ -157,10 +173,18 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
     int st = 1;
     const float half = (LKW - 1) * 0.5f;
     const int max_level = I.levels - 1;
+    // window pixel -> (wy, wx) of this lane's up to 7 pixels, fixed for the whole kernel
+    int woff[7];
+#pragma unroll
+    for (int m = 0; m < 7; m++) {
+        const int k = lane + 64 * m;
+        const int wy = k / LKW, wx = k - wy * LKW;
+        woff[m] = k < LKW * LKW ? (wy << 8) | wx : -1;
+    }
     for (int level = max_level; level >= 0; level--) {
         const uint8_t *img = I.img[level], *jmg = J.img[level];
         const int w = I.w[level], h = I.h[level];
-        const size_t ipitch = I.pitch[level], jpitch = J.pitch[level];
+        const uint32_t ipitch = (uint32_t)I.pitch[level], jpitch = (uint32_t)J.pitch[level];
         const float lscale = (float)(1.0 / (double)(1 << level));
         float ppx = pp.x * lscale, ppy = pp.y * lscale;
         float npx, npy;
@@ -181,9 +205,14 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
         int iw10 = (int)rintf((1.f - a) * b * 16384.f);
         int iw11 = 16384 - iw00 - iw01 - iw10;
         __syncthreads();  // previous level's readers are done with LDS
-        for (int e = lane; e < LKR * LKR; e += 64) {
-            const int ry = e / LKR, rx = e - ry * LKR;
-            regI[e] = img[(size_t)reflect101(ipy - 1 + ry, h) * ipitch + reflect101(ipx - 1 + rx, w)];
+        {
+            const bool interior = ipx >= 1 && ipy >= 1 && ipx + LKR - 1 <= w && ipy + LKR - 1 <= h;
+            for (int e = lane; e < LKR * LKR; e += 64) {
+                const int ry = e / LKR, rx = e - ry * LKR;
+                const int Y = ipy - 1 + ry, X = ipx - 1 + rx;
+                regI[e] = interior ? img[(uint32_t)Y * ipitch + (uint32_t)X]
+                                   : img[(uint32_t)reflect101(Y, h) * ipitch + (uint32_t)reflect101(X, w)];
+            }
         }
         __syncthreads();
         for (int e = lane; e < LKT * LKT; e += 64) {
@@ -200,25 +229,24 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
         }
         __syncthreads();
         short Iw[7], Ixw[7], Iyw[7];
-        long long sA11 = 0, sA12 = 0, sA22 = 0;
+        int pA11 = 0, pA12 = 0, pA22 = 0;  // per-lane partial sums: 7 * 4080^2 < 2^27
 #pragma unroll
         for (int m = 0; m < 7; m++) {
-            const int k = lane + 64 * m;
             Iw[m] = Ixw[m] = Iyw[m] = 0;
-            if (k < LKW * LKW) {
-                const int wy = k / LKW, wx = k - wy * LKW;
+            if (woff[m] >= 0) {
+                const int wy = woff[m] >> 8, wx = woff[m] & 255;
                 const int *c = &regI[(wy + 1) * LKR + (wx + 1)];
                 const int ival = LK_DESCALE(c[0] * iw00 + c[1] * iw01 + c[LKR] * iw10 + c[LKR + 1] * iw11, 9);
                 const int d = wy * LKT + wx;
                 const int ixval = LK_DESCALE(derx[d] * iw00 + derx[d + 1] * iw01 + derx[d + LKT] * iw10 + derx[d + LKT + 1] * iw11, 14);
                 const int iyval = LK_DESCALE(dery[d] * iw00 + dery[d + 1] * iw01 + dery[d + LKT] * iw10 + dery[d + LKT + 1] * iw11, 14);
                 Iw[m] = (short)ival, Ixw[m] = (short)ixval, Iyw[m] = (short)iyval;
-                sA11 += (long long)ixval * ixval, sA12 += (long long)ixval * iyval, sA22 += (long long)iyval * iyval;
+                pA11 += ixval * ixval, pA12 += ixval * iyval, pA22 += iyval * iyval;
             }
         }
-        sA11 = wave_sum_i64(sA11), sA12 = wave_sum_i64(sA12), sA22 = wave_sum_i64(sA22);
         const float FLT_SCALE = 1.0f / (1 << 20);
-        const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        const float A11 = wave_sum_split_f32(pA11) * FLT_SCALE, A12 = wave_sum_split_f32(pA12) * FLT_SCALE,
+                    A22 = wave_sum_split_f32(pA22) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = ((A22 + A11) - sqrtf((A11 - A22) * (A11 - A22) + (4.f * A12) * A12)) / (float)(2 * LKW * LKW);
         if (minEig < 1e-4f || D < 1.1920928955078125e-7f) {
@@ -228,6 +256,7 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
         D = 1.f / D;
         npx -= half, npy -= half;
         float pdx = 0.f, pdy = 0.f;
+        int jx0 = INT_MIN / 2, jy0 = INT_MIN / 2;  // origin of the staged next-image region (none yet)
         for (int j = 0; j < 30; j++) {
             const int inx = (int)floorf(npx), iny = (int)floorf(npy);
             if (inx < -LKW || inx >= w || iny < -LKW || iny >= h) {
@@ -239,25 +268,29 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
             iw01 = (int)rintf(a * (1.f - b) * 16384.f);
             iw10 = (int)rintf((1.f - a) * b * 16384.f);
             iw11 = 16384 - iw00 - iw01 - iw10;
-            __syncthreads();
-            for (int e = lane; e < LKT * LKT; e += 64) {
-                const int tyy = e / LKT, txx = e - tyy * LKT;
-                regJ[e] = jmg[(size_t)reflect101(iny + tyy, h) * jpitch + reflect101(inx + txx, w)];
+            if (inx < jx0 || iny < jy0 || inx + LKT > jx0 + LKJR || iny + LKT > jy0 + LKJR) {
+                // (re)stage a 32x32 block of the next image centred on the window; wave-uniform branch
+                jx0 = inx - LKJM, jy0 = iny - LKJM;
+                const bool interior = jx0 >= 0 && jy0 >= 0 && jx0 + LKJR <= w && jy0 + LKJR <= h;
+                __syncthreads();
+                for (int e = lane; e < LKJR * LKJR; e += 64) {
+                    const int ry = e / LKJR, rx = e - ry * LKJR;
+                    regJ[e] = interior ? jmg[(uint32_t)(jy0 + ry) * jpitch + (uint32_t)(jx0 + rx)]
+                                       : jmg[(uint32_t)reflect101(jy0 + ry, h) * jpitch + (uint32_t)reflect101(jx0 + rx, w)];
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            long long sb1 = 0, sb2 = 0;
+            const int jbase = (iny - jy0) * LKJR + (inx - jx0);
+            int pb1 = 0, pb2 = 0;  // per-lane partial sums: 7 * 16320 * 4080 < 2^29
 #pragma unroll
             for (int m = 0; m < 7; m++) {
-                const int k = lane + 64 * m;
-                if (k < LKW * LKW) {
-                    const int wy = k / LKW, wx = k - wy * LKW;
-                    const int *c = &regJ[wy * LKT + wx];
-                    const int diff = LK_DESCALE(c[0] * iw00 + c[1] * iw01 + c[LKT] * iw10 + c[LKT + 1] * iw11, 9) - Iw[m];
-                    sb1 += (long long)(diff * Ixw[m]), sb2 += (long long)(diff * Iyw[m]);
+                if (woff[m] >= 0) {
+                    const int *c = &regJ[jbase + (woff[m] >> 8) * LKJR + (woff[m] & 255)];
+                    const int diff = LK_DESCALE(c[0] * iw00 + c[1] * iw01 + c[LKJR] * iw10 + c[LKJR + 1] * iw11, 9) - Iw[m];
+                    pb1 += diff * Ixw[m], pb2 += diff * Iyw[m];
                 }
             }
-            sb1 = wave_sum_i64(sb1), sb2 = wave_sum_i64(sb2);
-            const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            const float b1 = wave_sum_split_f32(pb1) * FLT_SCALE, b2 = wave_sum_split_f32(pb2) * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
             npx += dx, npy += dy;
             np = make_float2(npx + half, npy + half);

@@ -22,12 +22,15 @@ __global__ void __launch_bounds__(256) k_pack_nv12(const uint8_t *__restrict__ y
                                                    const uint8_t *__restrict__ uv, size_t pitch_uv,
                                                    int row_vecs, int h, uint8_t *__restrict__ dst,
                                                    size_t pitch_dst) {
+    // flat grid-stride loop over (row, vector) pairs: a small persistent grid keeps the copy from
+    // taking wave slots away from kernels running beside it on other streams
     const int rows = h + h / 2;
-    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+    const long total = (long)rows * row_vecs;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(e / row_vecs), i = (int)(e - (long)row * row_vecs);
         const uint8_t *s = row < h ? y + (size_t)row * pitch_y : uv + (size_t)(row - h) * pitch_uv;
         uint8_t *d = dst + (size_t)row * pitch_dst;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < row_vecs; i += gridDim.x * blockDim.x)
-            reinterpret_cast<V *>(d)[i] = reinterpret_cast<const V *>(s)[i];
+        reinterpret_cast<V *>(d)[i] = reinterpret_cast<const V *>(s)[i];
     }
 }
 
@@ -250,6 +253,7 @@ struct TiledArgs {
     int src_vec_ok;       // planes and pitches 4-B aligned -> dword loads
     int dst_vec_ok;
     int debug_mode;       // 0 = product; >0 = timing-only ablations (VSTAB_DEBUG_MODE, outputs wrong)
+    int tiles_x, tiles_y;
 };
 
 __device__ __forceinline__ uint32_t gather_pixel(const WarpArgs &a, int sx, int sy) {
@@ -281,8 +285,17 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
     uint32_t *tile = smem + 4;
     const WarpArgs &a = ta.w;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int x0 = blockIdx.x * WARP_TILE_W + tx * 4;
-    const int ybase = blockIdx.y * (16 * RPT) + ty;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8),
+    // so give every XCD one contiguous band of tiles in raster order.  Horizontally adjacent tiles
+    // then share an L2: the 128-B lines their source rows and output rows straddle are fetched /
+    // written back once instead of once per XCD.  Placement only affects speed, never results.
+    const int ntiles = ta.tiles_x * ta.tiles_y;
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int tile_id = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    if (tile_id >= ntiles) return;  // uniform for the workgroup (before any barrier)
+    const int tile_y = tile_id / ta.tiles_x, tile_x = tile_id - tile_y * ta.tiles_x;
+    const int x0 = tile_x * WARP_TILE_W + tx * 4;
+    const int ybase = tile_y * (16 * RPT) + ty;
     if (tid == 0) bbox[0] = bbox[1] = INT_MAX, bbox[2] = bbox[3] = INT_MIN;
     __syncthreads();
 
@@ -442,11 +455,16 @@ vstab_status vstab_pack_nv12(const void *y, size_t pitch_y, const void *uv, size
     const int rows = height + height / 2;
     if (v16) {
         const int vecs = width / 16;
-        dim3 grid(div_up(vecs, 256), std::min(rows, 4096));
+        dim3 grid(std::min<unsigned>(div_up((unsigned)((long)vecs * rows), 256), 1024));
         hipLaunchKernelGGL(k_pack_nv12<uint4>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y,
                            (const uint8_t *)uv, pitch_uv, vecs, height, (uint8_t *)dst, (size_t)width);
+    } else if (aligned(y, 4) && aligned(uv, 4) && aligned(dst, 4) && pitch_y % 4 == 0 && pitch_uv % 4 == 0 && width % 4 == 0) {
+        const int vecs = width / 4;
+        dim3 grid(std::min<unsigned>(div_up((unsigned)((long)vecs * rows), 256), 1024));
+        hipLaunchKernelGGL(k_pack_nv12<uint32_t>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y,
+                           (const uint8_t *)uv, pitch_uv, vecs, height, (uint8_t *)dst, (size_t)width);
     } else {
-        dim3 grid(div_up(width, 256), std::min(rows, 4096));
+        dim3 grid(std::min<unsigned>(div_up((unsigned)((long)width * rows), 256), 1024));
         hipLaunchKernelGGL(k_pack_nv12<uint8_t>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y,
                            (const uint8_t *)uv, pitch_uv, width, height, (uint8_t *)dst, (size_t)width);
     }
@@ -544,7 +562,8 @@ vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const void *uv, 
         static const int lds_kb = getenv("VSTAB_LDS_KB") ? atoi(getenv("VSTAB_LDS_KB")) : 40;
         const size_t lds_bytes = (size_t)lds_kb * 1024;  // 40 KB -> 4 workgroups (16 waves) per CU
         ta.lds_capacity_px = (int)(lds_bytes / 4) - 4;
-        dim3 grid(div_up(dw, WARP_TILE_W), div_up(dh, 16 * rpt));
+        ta.tiles_x = (int)div_up(dw, WARP_TILE_W), ta.tiles_y = (int)div_up(dh, 16 * rpt);
+        dim3 grid(8 * div_up((unsigned)(ta.tiles_x * ta.tiles_y), 8));
         if (rpt == 1)
             hipLaunchKernelGGL(k_warp_tiled<1>, grid, dim3(256), lds_bytes, static_cast<hipStream_t>(stream), ta);
         else if (rpt == 4)
