@@ -15,84 +15,160 @@ __device__ __forceinline__ int reflect101(int i, int n) {  // BORDER_REFLECT_101
     return i;
 }
 
+// One dword of a REFLECT_101-padded u8 image at (gx .. gx+3, gy), gx a multiple of 4.  Dwords that lie
+// inside the row are one aligned load (also on border tiles); only dwords straddling the left /
+// right image edge are assembled from bytes.
+__device__ __forceinline__ uint32_t load4_reflect(const uint8_t *__restrict__ src, uint32_t pitch, int w, int h, int gx,
+                                                  int gy, bool vec_ok) {
+    const uint8_t *row = src + (uint32_t)reflect101(gy, h) * pitch;
+    if (vec_ok && gx >= 0 && gx + 4 <= w) return *reinterpret_cast<const uint32_t *>(row + gx);
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v |= (uint32_t)row[reflect101(gx + i, w)] << (8 * i);
+    return v;
+}
+
 // =============================================================================================
 // k_pyr_down -- cv::pyrDown as used by buildOpticalFlowPyramid: 5x5 binomial
 // [1 4 6 4 1]^2, integer, (sum + 128) >> 8, REFLECT_101, dst = ((w+1)/2, (h+1)/2).
-// 32 x 8 outputs per workgroup; the (2*32+3) x (2*8+3) source tile goes through LDS, the
-// horizontal pass is done once per source row (separable), the vertical pass per output.
+// 128 x 8 outputs per workgroup.  The 264 x 19 byte source tile is loaded with coalesced dword
+// loads (interior tiles) into LDS, the horizontal pass runs once per source row (4 outputs per
+// thread from one 12-byte LDS read), the vertical pass produces 4 outputs = one dword store.
 // =============================================================================================
-constexpr int PD_TW = 32, PD_TH = 8, PD_SW = 2 * PD_TW + 3, PD_SH = 2 * PD_TH + 3;
+constexpr int PD_TW = 128, PD_TH = 8, PD_SW = 2 * PD_TW + 8, PD_SH = 2 * PD_TH + 3;  // tile starts at 2*ox - 4
 
 __global__ void __launch_bounds__(256) k_pyr_down(const uint8_t *__restrict__ src, size_t spitch, int sw, int sh,
-                                                  uint8_t *__restrict__ dst, size_t dpitch, int dw, int dh) {
-    __shared__ uint8_t tile[PD_SH][PD_SW + 1];
-    __shared__ uint16_t hrow[PD_SH][PD_TW];
-    const int tid = threadIdx.y * PD_TW + threadIdx.x;
+                                                  uint8_t *__restrict__ dst, size_t dpitch, int dw, int dh, int vec_ok) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[PD_SH][PD_SW];
+    __shared__ __attribute__((aligned(16))) uint16_t hrow[PD_SH][PD_TW];
+    const int tid = threadIdx.x;
     const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
-    for (int e = tid; e < PD_SH * PD_SW; e += 256) {
-        const int ry = e / PD_SW, rx = e - ry * PD_SW;
-        tile[ry][rx] = src[(size_t)reflect101(2 * oy - 2 + ry, sh) * spitch + reflect101(2 * ox - 2 + rx, sw)];
+    const int sx0 = 2 * ox - 4, sy0 = 2 * oy - 2;
+    for (int e = tid; e < PD_SH * (PD_SW / 4); e += 256) {
+        const int ry = e / (PD_SW / 4), rd = e - ry * (PD_SW / 4);
+        reinterpret_cast<uint32_t *>(&tile[ry][0])[rd] = load4_reflect(src, (uint32_t)spitch, sw, sh, sx0 + 4 * rd, sy0 + ry, vec_ok != 0);
     }
     __syncthreads();
-    for (int e = tid; e < PD_SH * PD_TW; e += 256) {
-        const int ry = e / PD_TW, cx = e - ry * PD_TW;
-        const uint8_t *t = &tile[ry][2 * cx];
-        hrow[ry][cx] = (uint16_t)(t[0] + 4 * t[1] + 6 * t[2] + 4 * t[3] + t[4]);
+    for (int e = tid; e < PD_SH * (PD_TW / 4); e += 256) {
+        const int ry = e / (PD_TW / 4), q = e - ry * (PD_TW / 4);  // outputs 4q .. 4q+3 of this row
+        // taps of output c start at tile byte 2c + 2: bytes [8q + 2, 8q + 12]
+        const uint32_t *t32 = reinterpret_cast<const uint32_t *>(&tile[ry][8 * q]);
+        const uint32_t d0 = t32[0], d1 = t32[1], d2 = t32[2], d3 = t32[3];
+        const uint32_t b[16] = {d0 & 255, (d0 >> 8) & 255, (d0 >> 16) & 255, d0 >> 24, d1 & 255, (d1 >> 8) & 255, (d1 >> 16) & 255, d1 >> 24,
+                                d2 & 255, (d2 >> 8) & 255, (d2 >> 16) & 255, d2 >> 24, d3 & 255, (d3 >> 8) & 255, (d3 >> 16) & 255, d3 >> 24};
+        uint32_t o[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t *t = &b[2 * c + 2];
+            o[c] = t[0] + 4 * t[1] + 6 * t[2] + 4 * t[3] + t[4];
+        }
+        *reinterpret_cast<uint2 *>(&hrow[ry][4 * q]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
     }
     __syncthreads();
-    const int x = ox + threadIdx.x, y = oy + threadIdx.y;
+    const int q = tid & 31, ty = tid >> 5;
+    const int x = ox + 4 * q, y = oy + ty;
     if (x < dw && y < dh) {
-        const int ry = 2 * threadIdx.y, cx = threadIdx.x;
-        const int s = hrow[ry][cx] + 4 * hrow[ry + 1][cx] + 6 * hrow[ry + 2][cx] + 4 * hrow[ry + 3][cx] + hrow[ry + 4][cx];
-        dst[(size_t)y * dpitch + x] = (uint8_t)((s + 128) >> 8);
+        uint32_t acc[4] = {0, 0, 0, 0};
+        const int kk[5] = {1, 4, 6, 4, 1};
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(&hrow[2 * ty + j][4 * q]);
+            acc[0] += kk[j] * (v.x & 0xffff), acc[1] += kk[j] * (v.x >> 16), acc[2] += kk[j] * (v.y & 0xffff), acc[3] += kk[j] * (v.y >> 16);
+        }
+        uint8_t *o = dst + (size_t)y * dpitch + x;
+        const uint32_t r0 = (acc[0] + 128) >> 8, r1 = (acc[1] + 128) >> 8, r2 = (acc[2] + 128) >> 8, r3 = (acc[3] + 128) >> 8;
+        if (vec_ok && x + 4 <= dw) {
+            *reinterpret_cast<uint32_t *>(o) = r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
+        } else {
+            const uint32_t r[4] = {r0, r1, r2, r3};
+            for (int c = 0; c < 4 && x + c < dw; c++) o[c] = (uint8_t)r[c];
+        }
     }
 }
 
 // =============================================================================================
 // k_min_eig -- cornerMinEigenVal(blockSize 3, ksize 3): Sobel
 // derivatives scaled by 1/(4*3*255) in the documented operation order, products, 3x3 box sum
-// (exact in double), minimum eigenvalue in float.  16 x 16 outputs per workgroup, source tile
-// with halo 2 and derivative tile with halo 1 in LDS.  Also reduces the frame maximum.
+// (exact in double), minimum eigenvalue in float; also reduces the frame maximum.
+// 64 x 16 outputs per workgroup (4 per thread).  Source tile (halo 2, REFLECT_101) and derivative
+// tile (halo 1) live in LDS.  The derivative the box filter needs at a position reflected across
+// the image border is the derivative AT the mirrored position; computed from the mirrored tile it
+// comes out with the sign of the mirrored axis flipped, so dx (dy) is negated for entries whose
+// column (row) lies outside the image -- negation is exact, so the floats equal the direct form.
 // =============================================================================================
+constexpr int ME_TW = 64, ME_TH = 16, ME_SW = ME_TW + 8, ME_SH = ME_TH + 4;  // tile starts at ox - 4 (dword aligned)
+
 __global__ void __launch_bounds__(256) k_min_eig(const uint8_t *__restrict__ src, size_t pitch, int w, int h,
-                                                 float *__restrict__ eig, int *__restrict__ max_bits) {
-    __shared__ float dxs[18][19], dys[18][19];
+                                                 float *__restrict__ eig, int *__restrict__ max_bits, int vec_ok) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[ME_SH][ME_SW];
+    __shared__ float dxs[ME_TH + 2][ME_TW + 2 + 1], dys[ME_TH + 2][ME_TW + 2 + 1];
     __shared__ int bmax;
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 16 + tx;
-    const int ox = blockIdx.x * 16, oy = blockIdx.y * 16;
+    const int tid = threadIdx.x;
+    const int ox = blockIdx.x * ME_TW, oy = blockIdx.y * ME_TH;
+    const int sx0 = ox - 4, sy0 = oy - 2;
     if (tid == 0) bmax = INT_MIN;
-    const float scale = (float)(1.0 / (4.0 * 3.0 * 255.0));
-    const float k0 = 2.0f * scale, k1 = scale;
-    // derivative tile: entry (ry, rx) is the derivative AT image position reflect(oy-1+ry),
-    // reflect(ox-1+rx) (the box filter's REFLECT_101 border), whose own Sobel taps reflect again
-    for (int e = tid; e < 324; e += 256) {
-        const int ry = e / 18, rx = e - ry * 18;
-        const int y = reflect101(oy - 1 + ry, h), x = reflect101(ox - 1 + rx, w);
-        const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h), xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
-        const uint8_t *r0 = src + (size_t)ym * pitch, *r1 = src + (size_t)y * pitch, *r2 = src + (size_t)yp * pitch;
-        const float d0 = (float)(r0[xp] - r0[xm]), d1 = (float)(r1[xp] - r1[xm]), d2 = (float)(r2[xp] - r2[xm]);
-        dxs[ry][rx] = (d0 + d2) * k1 + d1 * k0;
-        const float s0 = (float)r0[x] * k0 + ((float)r0[xm] + (float)r0[xp]) * k1;
-        const float s2 = (float)r2[x] * k0 + ((float)r2[xm] + (float)r2[xp]) * k1;
-        dys[ry][rx] = s2 - s0;
+    for (int e = tid; e < ME_SH * (ME_SW / 4); e += 256) {
+        const int ry = e / (ME_SW / 4), rd = e - ry * (ME_SW / 4);
+        reinterpret_cast<uint32_t *>(&tile[ry][0])[rd] = load4_reflect(src, (uint32_t)pitch, w, h, sx0 + 4 * rd, sy0 + ry, vec_ok != 0);
     }
     __syncthreads();
-    const int x = ox + tx, y = oy + ty;
-    float e = 0.0f;
+    const float scale = (float)(1.0 / (4.0 * 3.0 * 255.0));
+    const float k0 = 2.0f * scale, k1 = scale;
+    // derivative entry (ry, rx) <-> image coordinate (oy - 1 + ry, ox - 1 + rx) <-> tile[ry + 1][rx + 3]
+    for (int e = tid; e < (ME_TH + 2) * (ME_TW + 2); e += 256) {
+        const int ry = e / (ME_TW + 2), rx = e - ry * (ME_TW + 2);
+        const uint8_t *c = &tile[ry + 1][rx + 3];
+        const int a00 = c[-ME_SW - 1], a01 = c[-ME_SW], a02 = c[-ME_SW + 1];
+        const int a10 = c[-1], a12 = c[1];
+        const int a20 = c[ME_SW - 1], a21 = c[ME_SW], a22 = c[ME_SW + 1];
+        const float d0 = (float)(a02 - a00), d1 = (float)(a12 - a10), d2 = (float)(a22 - a20);
+        float dx = (d0 + d2) * k1 + d1 * k0;
+        const float s0 = (float)a01 * k0 + ((float)a00 + (float)a02) * k1;
+        const float s2 = (float)a21 * k0 + ((float)a20 + (float)a22) * k1;
+        float dy = s2 - s0;
+        const int gx = ox - 1 + rx, gy = oy - 1 + ry;
+        if (gx < 0 || gx >= w) dx = -dx;
+        if (gy < 0 || gy >= h) dy = -dy;
+        dxs[ry][rx] = dx, dys[ry][rx] = dy;
+    }
+    __syncthreads();
+    const int q = tid & 15, ty = tid >> 4;
+    const int x = ox + 4 * q, y = oy + ty;
+    int best = INT_MIN;
     if (x < w && y < h) {
-        double sxx = 0, sxy = 0, syy = 0;
+        float a_[3][6], b_[3][6];
 #pragma unroll
         for (int j = 0; j < 3; j++)
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const float a = dxs[ty + j][tx + i], b = dys[ty + j][tx + i];
-                sxx += (double)(a * a), sxy += (double)(a * b), syy += (double)(b * b);
-            }
-        const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
-        e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-        eig[(size_t)y * w + x] = e;
-        atomicMax(&bmax, __float_as_int(e));
+            for (int i = 0; i < 6; i++) a_[j][i] = dxs[ty + j][4 * q + i], b_[j][i] = dys[ty + j][4 * q + i];
+        float ev[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            double sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const float a = a_[j][c + i], b = b_[j][c + i];
+                    sxx += (double)(a * a), sxy += (double)(a * b), syy += (double)(b * b);
+                }
+            const float a = (float)sxx * 0.5f, b = (float)sxy, cc = (float)syy * 0.5f;
+            ev[c] = (a + cc) - sqrtf((a - cc) * (a - cc) + b * b);
+            if (x + c < w) best = max(best, __float_as_int(ev[c]));
+        }
+        float *o = eig + (size_t)y * w + x;
+        if (vec_ok && (w & 3) == 0 && x + 4 <= w) {
+            *reinterpret_cast<float4 *>(o) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+        } else {
+            for (int c = 0; c < 4 && x + c < w; c++) o[c] = ev[c];
+        }
     }
+    // frame maximum: DPP max inside each 16-lane row, one LDS atomic per row, one global atomic per block
+    best = max(best, __builtin_amdgcn_update_dpp(INT_MIN, best, 0x111, 0xf, 0xf, false));
+    best = max(best, __builtin_amdgcn_update_dpp(INT_MIN, best, 0x112, 0xf, 0xf, false));
+    best = max(best, __builtin_amdgcn_update_dpp(INT_MIN, best, 0x114, 0xf, 0xf, false));
+    best = max(best, __builtin_amdgcn_update_dpp(INT_MIN, best, 0x118, 0xf, 0xf, false));
+    if (q == 15) atomicMax(&bmax, best);
     __syncthreads();
     if (tid == 0) atomicMax(max_bits, bmax);
 }
@@ -314,8 +390,9 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
 vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *dst, size_t dpitch,
                              hipStream_t s) {
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    const int vec_ok = reinterpret_cast<uintptr_t>(src) % 4 == 0 && spitch % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && dpitch % 4 == 0;
     dim3 grid(div_up(dw, PD_TW), div_up(dh, PD_TH));
-    hipLaunchKernelGGL(k_pyr_down, grid, dim3(PD_TW, PD_TH), 0, s, src, spitch, sw, sh, dst, dpitch, dw, dh);
+    hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, src, spitch, sw, sh, dst, dpitch, dw, dh, vec_ok);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }
@@ -323,8 +400,9 @@ vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, 
 vstab_status launch_min_eig(const uint8_t *src, size_t pitch, int w, int h, float *eig, int *max_bits,
                             hipStream_t s) {
     VSTAB_HIP_TRY(hipMemsetAsync(max_bits, 0x80, sizeof(int), s));  // INT_MIN-ish (0x80808080): any value wins
-    dim3 grid(div_up(w, 16), div_up(h, 16));
-    hipLaunchKernelGGL(k_min_eig, grid, dim3(16, 16), 0, s, src, pitch, w, h, eig, max_bits);
+    const int vec_ok = reinterpret_cast<uintptr_t>(src) % 4 == 0 && pitch % 4 == 0 && reinterpret_cast<uintptr_t>(eig) % 16 == 0;
+    dim3 grid(div_up(w, ME_TW), div_up(h, ME_TH));
+    hipLaunchKernelGGL(k_min_eig, grid, dim3(256), 0, s, src, pitch, w, h, eig, max_bits, vec_ok);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }
