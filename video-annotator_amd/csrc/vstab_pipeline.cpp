@@ -41,9 +41,13 @@ struct DevBuf {
     T *as() const { return static_cast<T *>(p); }
 };
 
-struct PinnedBuf {
+struct PinnedBuf {  // host memory the device can read and write directly (mapped, coherent)
     void *p = nullptr;
     size_t n = 0;
+    void *dev() const {
+        void *d = nullptr;
+        return hipHostGetDevicePointer(&d, p, 0) == hipSuccess ? d : nullptr;
+    }
     ~PinnedBuf() {
         if (p) (void)hipHostFree(p);
     }
@@ -51,7 +55,7 @@ struct PinnedBuf {
         if (bytes <= n) return VSTAB_OK;
         if (p) (void)hipHostFree(p);
         p = nullptr, n = 0;
-        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return fail(VSTAB_ERR_NOMEM, "hipHostMalloc failed");
+        if (hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return fail(VSTAB_ERR_NOMEM, "hipHostMalloc failed");
         n = bytes;
         return VSTAB_OK;
     }
@@ -167,33 +171,59 @@ class Tracker {
         return VSTAB_OK;
     }
 
-    // calcOpticalFlowPyrLK(prev, next, pts): both pyramids must have been built; synchronises
+    // calcOpticalFlowPyrLK(prev, next, pts), split in two so the caller can enqueue more work behind the
+    // kernel before blocking.  Points travel through mapped host memory: the kernel reads prev_pts and
+    // writes next_pts / status over the link directly (a few KB), and the host waits on a completion
+    // counter the kernel bumps per feature instead of paying a copy launch + stream-sync round trip.
+    vstab_status track_launch(const LkPyramid &I, const LkPyramid &J, const std::vector<float> &prev_xy, hipStream_t st,
+                              bool timed) {
+        pending_n_ = (int)(prev_xy.size() / 2);
+        pending_timed_ = timed;
+        const int n = pending_n_;
+        if (n == 0) return VSTAB_OK;
+        VSTAB_TRY(hpts_.ensure((size_t)n * (sizeof(float2) + 16)));
+        uint8_t *dbase = static_cast<uint8_t *>(hpts_.dev());
+        if (!dbase) return fail(VSTAB_ERR_DEVICE, "hipHostGetDevicePointer failed");
+        // layout: n records of 16 B, then n input points
+        std::memcpy(hpts_.as<uint8_t>() + 16 * (size_t)n, prev_xy.data(), sizeof(float) * prev_xy.size());
+        ++seq_;
+        if (timed && !ev_a_) (void)hipEventCreate(&ev_a_), (void)hipEventCreate(&ev_b_);
+        if (timed) (void)hipEventRecord(ev_a_, st);
+        VSTAB_TRY(launch_lk(I, J, reinterpret_cast<const float2 *>(dbase + 16 * (size_t)n), n, nullptr, nullptr, dbase, seq_, st));
+        if (timed) (void)hipEventRecord(ev_b_, st);
+        return VSTAB_OK;
+    }
+
+    vstab_status track_wait(std::vector<float> &next_xy, std::vector<uint8_t> &status, hipStream_t st, double *gpu_ms) {
+        const int n = pending_n_;
+        next_xy.assign(2 * (size_t)n, 0.f), status.assign(n, 0);
+        if (n == 0) return VSTAB_OK;
+        const volatile uint32_t *rec = hpts_.as<uint32_t>();
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned long spins = 0;
+        for (int i = 0; i < n; i++) {
+            while (__atomic_load_n(&rec[4 * i + 3], __ATOMIC_ACQUIRE) != seq_) {
+                __builtin_ia32_pause();
+                if ((++spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                    VSTAB_HIP_TRY(hipStreamSynchronize(st));  // surfaces a launch / execution error if there is one
+                    if (__atomic_load_n(&rec[4 * i + 3], __ATOMIC_ACQUIRE) != seq_) return fail(VSTAB_ERR_DEVICE, "LK kernel did not complete");
+                }
+            }
+            uint32_t x = rec[4 * i], y = rec[4 * i + 1];
+            std::memcpy(&next_xy[2 * i], &x, 4), std::memcpy(&next_xy[2 * i + 1], &y, 4);
+            status[i] = (uint8_t)rec[4 * i + 2];
+        }
+        if (pending_timed_ && gpu_ms) {
+            float ms = 0;
+            if (hipEventSynchronize(ev_b_) == hipSuccess && hipEventElapsedTime(&ms, ev_a_, ev_b_) == hipSuccess) *gpu_ms += ms;
+        }
+        return VSTAB_OK;
+    }
+
     vstab_status track(const LkPyramid &I, const LkPyramid &J, const std::vector<float> &prev_xy, std::vector<float> &next_xy,
                        std::vector<uint8_t> &status, hipStream_t st, double *gpu_ms = nullptr) {
-        const int n = (int)(prev_xy.size() / 2);
-        next_xy.assign(prev_xy.size(), 0.f), status.assign(n, 0);
-        if (n == 0) return VSTAB_OK;
-        VSTAB_TRY(pts_.ensure((size_t)n * (2 * sizeof(float2) + 8)));
-        VSTAB_TRY(hpts_.ensure((size_t)n * (2 * sizeof(float2) + 8)));
-        float2 *d_prev = pts_.as<float2>(), *d_next = d_prev + n;
-        uint8_t *d_status = reinterpret_cast<uint8_t *>(d_next + n);
-        float2 *h_prev = hpts_.as<float2>(), *h_next = h_prev + n;
-        uint8_t *h_status = reinterpret_cast<uint8_t *>(h_next + n);
-        std::memcpy(h_prev, prev_xy.data(), sizeof(float) * prev_xy.size());
-        VSTAB_HIP_TRY(hipMemcpyAsync(d_prev, h_prev, sizeof(float2) * n, hipMemcpyHostToDevice, st));
-        if (gpu_ms && !ev_a_) (void)hipEventCreate(&ev_a_), (void)hipEventCreate(&ev_b_);
-        if (gpu_ms) (void)hipEventRecord(ev_a_, st);
-        VSTAB_TRY(launch_lk(I, J, d_prev, n, d_next, d_status, st));
-        if (gpu_ms) (void)hipEventRecord(ev_b_, st);
-        VSTAB_HIP_TRY(hipMemcpyAsync(h_next, d_next, sizeof(float2) * n + n, hipMemcpyDeviceToHost, st));
-        VSTAB_HIP_TRY(hipStreamSynchronize(st));
-        if (gpu_ms) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, ev_a_, ev_b_) == hipSuccess) *gpu_ms += ms;
-        }
-        std::memcpy(next_xy.data(), h_next, sizeof(float) * next_xy.size());
-        std::memcpy(status.data(), h_status, n);
-        return VSTAB_OK;
+        VSTAB_TRY(track_launch(I, J, prev_xy, st, gpu_ms != nullptr));
+        return track_wait(next_xy, status, st, gpu_ms);
     }
 
     int levels() const { return levels_; }
@@ -201,10 +231,13 @@ class Tracker {
   private:
     int w_ = 0, h_ = 0, levels_ = 1;
     int lvl_w_[LK_MAX_LEVELS] = {0}, lvl_h_[LK_MAX_LEVELS] = {0};
-    DevBuf pyr_[2][LK_MAX_LEVELS], eig_, keys_, small_, pts_;
+    DevBuf pyr_[2][LK_MAX_LEVELS], eig_, keys_, small_;
     PinnedBuf hsmall_, hkeys_, hpts_;
     unsigned int cap_ = 0;
     hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
+    int pending_n_ = 0;
+    bool pending_timed_ = false;
+    uint32_t seq_ = 0;
 };
 
 }  // namespace vstab
@@ -340,9 +373,14 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
 static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
     const int slot = H->acquire_slot();
     if (slot < 0) return fail(VSTAB_ERR_NOMEM, "look-ahead ring exhausted");
-    VSTAB_TRY(ingest(H, f, slot));
-    const uint8_t *g = H->gray(slot);
-    const size_t pitch = (size_t)H->w;
+    // Device-resident frames are tracked straight from the upstream planes (valid until the next
+    // callback); the copy into the ring is enqueued BEHIND the LK kernel, off the critical path.
+    const bool direct = f.mem == 0 && H->cfg.tracking && H->last_key != -1;
+    if (!direct) VSTAB_TRY(ingest(H, f, slot));
+    const uint8_t *g = direct ? static_cast<const uint8_t *>(f.y) : H->gray(slot);
+    const size_t pitch = direct ? f.pitch_y : (size_t)H->w;
+    const size_t ring_pitch = (size_t)H->w;
+    if (direct && (f.width != H->w || f.height != H->h)) return fail(VSTAB_ERR_INVALID, "frame size changed mid-stream");
     if (!H->cfg.tracking) {
         // undistort-only mode (BASELINE config 1): every frame gets the identity rotation
         if (H->last_key == -1) {
@@ -370,7 +408,7 @@ static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
         if (H->frame_index - H->last_key > 20 || H->corners.size() / 2 < 150) {
             H->last_key = H->frame_index - 1;
             HostStage hs(&H->prof.host_corners_ms);
-            VSTAB_TRY(H->tracker.good_features(pg, pitch, 200, 0.01, 30.0, H->corners, H->tstream));
+            VSTAB_TRY(H->tracker.good_features(pg, ring_pitch, 200, 0.01, 30.0, H->corners, H->tstream));
             lg.key_frame = 1;
             H->prof.key_frames++;
         }
@@ -383,10 +421,12 @@ static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
         }
         std::vector<float> nxt;
         std::vector<uint8_t> st;
+        VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(prev_pyr, pg, ring_pitch), H->tracker.pyramid(next_pyr, g, pitch), H->corners,
+                                          H->tstream, H->profiling));
+        if (direct) VSTAB_TRY(ingest(H, f, slot));  // runs behind LK while the host estimates the rotation
         {
             HostStage hs(&H->prof.host_track_wait_ms);
-            VSTAB_TRY(H->tracker.track(H->tracker.pyramid(prev_pyr, pg, pitch), H->tracker.pyramid(next_pyr, g, pitch), H->corners, nxt, st, H->tstream,
-                                       H->profiling ? &H->prof.gpu_lk_ms : nullptr));
+            VSTAB_TRY(H->tracker.track_wait(nxt, st, H->tstream, H->profiling ? &H->prof.gpu_lk_ms : nullptr));
         }
         std::vector<float> pp, cp;
         for (size_t i = 0; i < st.size(); i++)
@@ -448,7 +488,13 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     H->cfg = *cfg, H->src = *src;
     H->rng = Pcg32(cfg->seed);
     H->stream = static_cast<hipStream_t>(cfg->stream);  // NULL = the default stream, as for the stateless operators
-    VSTAB_HIP_TRY(hipStreamCreateWithFlags(&H->tstream, hipStreamNonBlocking));
+    {
+        // the tracking chain is the per-frame critical path; the warp only has to finish before the
+        // caller looks at dst, so the tracking stream gets the highest priority the device offers
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->tstream, hipStreamNonBlocking, hi));
+    }
     // :214-219 peek the first frame for the input size, then derive both cameras
     vstab_frame f;
     std::memset(&f, 0, sizeof(f));
@@ -488,6 +534,9 @@ vstab_status vstab_pull_frame(vstab_handle *H, void *dst, size_t pitch_dst) {
     while (H->queue.size() <= (size_t)H->cfg.smooth_radius) {
         vstab_frame f;
         std::memset(&f, 0, sizeof(f));
+        // the previous frame's copy into the ring may still be in flight on the tracking stream; upstream
+        // is allowed to recycle that frame's memory as soon as it is called again
+        if (H->last_slot >= 0) VSTAB_HIP_TRY(hipEventSynchronize(H->slots[H->last_slot].ingested));
         const int rc = H->src.pull(H->src.user, &f);
         if (rc == VSTAB_EOF) {
             // :456-461 pretend the camera kept its last orientation

@@ -238,7 +238,8 @@ __device__ __forceinline__ float wave_sum_split_f32(int v) {
 #define LK_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
 __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const float2 *__restrict__ prev_pts,
-                                                 int n, float2 *__restrict__ next_pts, uint8_t *__restrict__ status) {
+                                                 int n, float2 *__restrict__ next_pts, uint8_t *__restrict__ status,
+                                                 uint4 *__restrict__ host_rec, unsigned int seq) {
     __shared__ int regI[LKR * LKR];
     __shared__ int derx[LKT * LKT], dery[LKT * LKT];
     __shared__ int regJ[LKJR * LKJR];
@@ -379,8 +380,15 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
         }
     }
     if (lane == 0) {
-        next_pts[f] = np;
-        status[f] = (uint8_t)st;
+        if (host_rec) {
+            // one self-validating 16-byte record per feature in coherent (uncached) host memory: data and
+            // sequence tag leave in a single store, so no fence or counter is needed and the host simply
+            // polls the tags
+            host_rec[f] = make_uint4(__float_as_uint(np.x), __float_as_uint(np.y), (unsigned int)st, seq);
+        } else {
+            next_pts[f] = np;
+            status[f] = (uint8_t)st;
+        }
     }
 }
 
@@ -418,9 +426,9 @@ vstab_status launch_corner_candidates(const float *eig, int w, int h, const int 
 }
 
 vstab_status launch_lk(const LkPyramid &I, const LkPyramid &J, const float2 *prev_pts, int n, float2 *next_pts,
-                       uint8_t *status, hipStream_t s) {
+                       uint8_t *status, void *host_records, unsigned int seq, hipStream_t s) {
     if (n <= 0) return VSTAB_OK;
-    hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(64), 0, s, I, J, prev_pts, n, next_pts, status);
+    hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(64), 0, s, I, J, prev_pts, n, next_pts, status, static_cast<uint4 *>(host_records), seq);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }

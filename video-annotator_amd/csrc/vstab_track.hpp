@@ -32,7 +32,9 @@ vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, 
 vstab_status launch_min_eig(const uint8_t *src, size_t pitch, int w, int h, float *eig, int *max_bits, hipStream_t s);
 vstab_status launch_corner_candidates(const float *eig, int w, int h, const int *max_bits, double quality,
                                       unsigned long long *keys, unsigned int *count, unsigned int cap, hipStream_t s);
+// host_records (may be NULL): n 16-byte records {x, y, status, seq} in mapped host memory, written instead
+// of next_pts / status so the host can poll for completion without a stream synchronisation
 vstab_status launch_lk(const LkPyramid &I, const LkPyramid &J, const float2 *prev_pts, int n, float2 *next_pts,
-                       uint8_t *status, hipStream_t s);
+                       uint8_t *status, void *host_records, unsigned int seq, hipStream_t s);
 
 }  // namespace vstab
