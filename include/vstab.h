@@ -250,7 +250,8 @@ typedef struct vstab_profile {
     double host_corners_ms, host_track_wait_ms, host_estimate_ms, host_smooth_ms;  /* sums of wall time */
     long warp_launches;
 } vstab_profile;
-VSTAB_API vstab_status vstab_enable_profiling(vstab_handle *h, int enable);
+/* level 0 = off, 1 = time the warp launches only (two event records per frame), 2 = every GPU stage */
+VSTAB_API vstab_status vstab_enable_profiling(vstab_handle *h, int level);
 /* Synchronises the stream, folds all pending event pairs into the sums and returns them. */
 VSTAB_API vstab_status vstab_get_profile(vstab_handle *h, vstab_profile *out);
 

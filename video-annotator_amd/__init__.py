@@ -418,8 +418,8 @@ class Stabilizer:
                             R_accum=np.array(lg.R_accum).reshape(3, 3)))
         return out
 
-    def enable_profiling(self, on=True):
-        _check(_L.vstab_enable_profiling(self._h, int(on)), "vstab_enable_profiling")
+    def enable_profiling(self, level=2):
+        _check(_L.vstab_enable_profiling(self._h, int(level)), "vstab_enable_profiling")
 
     def profile(self):
         p = Profile()

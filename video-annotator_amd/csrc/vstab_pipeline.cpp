@@ -282,7 +282,7 @@ struct vstab_handle {
     std::vector<Mat3> warp_log;
 
     // profiler
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 warp launches only (cheap), 2 every GPU stage
     vstab_profile prof{};
     enum Stage { ST_INGEST, ST_PYRAMID, ST_CORNERS, ST_LK, ST_WARP, ST_COUNT };
     struct Pending {
@@ -313,6 +313,15 @@ struct vstab_handle {
         pending.clear();
     }
 
+    // a frame whose tracking has been launched (inflight) / whose LK results have been read (ready)
+    struct Tracked {
+        int slot = -1;
+        vstab_frame_log lg{};
+        std::vector<float> prev, pp, cp;
+    };
+    Tracked inflight, ready;
+    bool have_inflight = false, have_ready = false, src_eof = false;
+
     int acquire_slot() {
         int best = -1;
         for (size_t i = 0; i < slots.size(); i++)
@@ -328,7 +337,7 @@ struct GpuStage {  // records an event pair around a stage when profiling is on
     int stage;
     hipStream_t s;
     GpuStage(vstab_handle *h, int st) : H(h), stage(st), s(st == vstab_handle::ST_WARP ? h->stream : h->tstream) {
-        if (H->profiling) {
+        if (H->profiling >= 2 || (H->profiling == 1 && st == vstab_handle::ST_WARP)) {
             a = H->get_event();
             (void)hipEventRecord(a, s);
         }
@@ -369,10 +378,30 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
     return VSTAB_OK;
 }
 
-// consume_frame, FrameSourceWarp.cpp:397-450
-static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
+// ---------------------------------------------------------------------------------------------
+// consume_frame (FrameSourceWarp.cpp:397-450) split into three steps so that the GPU tracking of
+// frame k+1 overlaps the host rotation estimate of frame k (one frame of upstream read-ahead):
+//   begin_next       pull the next upstream frame, key-frame rule (:415-419), pyramid, LK launch
+//   finish_wait      LK results -> surviving pairs (:422-427)
+//   finish_estimate  rotation + fallback + accumulation + filter.add + queue push (:429-446)
+// Every step runs in frame order, so every decision, random draw and queue entry is the one the
+// reference makes; only WHEN the upstream callback is called moves (one frame earlier).
+// ---------------------------------------------------------------------------------------------
+static vstab_status begin_next(vstab_handle *H) {
+    vstab_frame f;
+    std::memset(&f, 0, sizeof(f));
+    // the previous frame's copy into the ring may still be in flight on the tracking stream; upstream
+    // is allowed to recycle that frame's memory as soon as it is called again
+    if (H->last_slot >= 0) VSTAB_HIP_TRY(hipEventSynchronize(H->slots[H->last_slot].ingested));
+    const int rc = H->src.pull(H->src.user, &f);
+    if (rc == VSTAB_EOF) {
+        H->src_eof = true;
+        return VSTAB_EOF;
+    }
+    if (rc != 0) return fail(VSTAB_ERR_SOURCE, "upstream pull failed with " + std::to_string(rc));
     const int slot = H->acquire_slot();
     if (slot < 0) return fail(VSTAB_ERR_NOMEM, "look-ahead ring exhausted");
+    if (f.width != H->w || f.height != H->h) return fail(VSTAB_ERR_INVALID, "frame size changed mid-stream");
     // Device-resident frames are tracked straight from the upstream planes (valid until the next
     // callback); the copy into the ring is enqueued BEHIND the LK kernel, off the critical path.
     const bool direct = f.mem == 0 && H->cfg.tracking && H->last_key != -1;
@@ -380,7 +409,6 @@ static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
     const uint8_t *g = direct ? static_cast<const uint8_t *>(f.y) : H->gray(slot);
     const size_t pitch = direct ? f.pitch_y : (size_t)H->w;
     const size_t ring_pitch = (size_t)H->w;
-    if (direct && (f.width != H->w || f.height != H->h)) return fail(VSTAB_ERR_INVALID, "frame size changed mid-stream");
     if (!H->cfg.tracking) {
         // undistort-only mode (BASELINE config 1): every frame gets the identity rotation
         if (H->last_key == -1) {
@@ -401,62 +429,31 @@ static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
         GpuStage gs(H, vstab_handle::ST_PYRAMID);
         VSTAB_TRY(H->tracker.build_pyramid(H->cur_pyr, g, pitch, H->tstream));
     } else {
-        vstab_frame_log lg;
-        std::memset(&lg, 0, sizeof(lg));
+        vstab_handle::Tracked &T = H->inflight;
+        T = vstab_handle::Tracked();
+        T.slot = slot;
         const uint8_t *pg = H->gray(H->last_slot);
         // :415-419 key-frame rule; corners are found in the PREVIOUS gray frame
         if (H->frame_index - H->last_key > 20 || H->corners.size() / 2 < 150) {
             H->last_key = H->frame_index - 1;
             HostStage hs(&H->prof.host_corners_ms);
             VSTAB_TRY(H->tracker.good_features(pg, ring_pitch, 200, 0.01, 30.0, H->corners, H->tstream));
-            lg.key_frame = 1;
+            T.lg.key_frame = 1;
             H->prof.key_frames++;
         }
-        lg.n_corners = (int)(H->corners.size() / 2);
-        // :422-427 optical flow prev -> current; keep pairs with status != 0
+        T.lg.n_corners = (int)(H->corners.size() / 2);
+        T.prev = H->corners;
         const int prev_pyr = H->cur_pyr, next_pyr = 1 - H->cur_pyr;
         {
             GpuStage gs(H, vstab_handle::ST_PYRAMID);
             VSTAB_TRY(H->tracker.build_pyramid(next_pyr, g, pitch, H->tstream));
         }
-        std::vector<float> nxt;
-        std::vector<uint8_t> st;
         VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(prev_pyr, pg, ring_pitch), H->tracker.pyramid(next_pyr, g, pitch), H->corners,
-                                          H->tstream, H->profiling));
-        if (direct) VSTAB_TRY(ingest(H, f, slot));  // runs behind LK while the host estimates the rotation
-        {
-            HostStage hs(&H->prof.host_track_wait_ms);
-            VSTAB_TRY(H->tracker.track_wait(nxt, st, H->tstream, H->profiling ? &H->prof.gpu_lk_ms : nullptr));
-        }
-        std::vector<float> pp, cp;
-        for (size_t i = 0; i < st.size(); i++)
-            if (st[i]) {
-                pp.push_back(H->corners[2 * i]), pp.push_back(H->corners[2 * i + 1]);
-                cp.push_back(nxt[2 * i]), cp.push_back(nxt[2 * i + 1]);
-            }
-        H->corners = cp;
+                                          H->tstream, H->profiling >= 2));
+        if (direct) VSTAB_TRY(ingest(H, f, slot));  // runs behind LK
         H->cur_pyr = next_pyr;
-        lg.n_tracked = (int)(cp.size() / 2);
-        // :429-438 rotation since the last frame, with the < 40 inlier fallback
-        Mat3 R;
-        int inl;
-        {
-            HostStage hs(&H->prof.host_estimate_ms);
-            inl = estimate_rotation(pp.data(), cp.data(), lg.n_tracked, H->Kin, H->Kout, H->rng, R);
-        }
-        lg.n_inliers = inl;
-        if (inl < 40) {
-            R = H->have_last_rot ? H->last_rot : Mat3::identity();
-            lg.fallback = 1;
-        }
-        H->last_rot = R, H->have_last_rot = true;
-        H->measured = R * H->measured;  // :441 left-multiplied accumulation
-        if (H->sg) H->sg->add(H->measured);
-        H->slots[slot].queued = true;
-        H->queue.emplace_back(slot, H->measured);
-        std::memcpy(lg.R_frame, R.m, sizeof(R.m));
-        std::memcpy(lg.R_accum, H->measured.m, sizeof(R.m));
-        H->log.push_back(lg);
+        H->slots[slot].queued = true;  // reserved: it will enter the queue in finish_estimate
+        H->have_inflight = true;
     }
     H->prof.frames_consumed++;
     if (H->last_slot >= 0) {
@@ -467,6 +464,54 @@ static vstab_status consume_frame(vstab_handle *H, const vstab_frame &f) {
     H->last_slot = slot;  // :448
     ++H->frame_index;     // :449
     return VSTAB_OK;
+}
+
+static vstab_status finish_wait(vstab_handle *H) {
+    if (!H->have_inflight) return VSTAB_OK;
+    vstab_handle::Tracked &T = H->inflight;
+    std::vector<float> nxt;
+    std::vector<uint8_t> st;
+    {
+        HostStage hs(&H->prof.host_track_wait_ms);
+        VSTAB_TRY(H->tracker.track_wait(nxt, st, H->tstream, H->profiling >= 2 ? &H->prof.gpu_lk_ms : nullptr));
+    }
+    // :261-268 keep pairs with status != 0
+    for (size_t i = 0; i < st.size(); i++)
+        if (st[i]) {
+            T.pp.push_back(T.prev[2 * i]), T.pp.push_back(T.prev[2 * i + 1]);
+            T.cp.push_back(nxt[2 * i]), T.cp.push_back(nxt[2 * i + 1]);
+        }
+    H->corners = T.cp;  // :427
+    T.lg.n_tracked = (int)(T.cp.size() / 2);
+    H->ready = std::move(T);
+    H->have_ready = true, H->have_inflight = false;
+    return VSTAB_OK;
+}
+
+static void finish_estimate(vstab_handle *H) {
+    if (!H->have_ready) return;
+    vstab_handle::Tracked &T = H->ready;
+    vstab_frame_log &lg = T.lg;
+    // :429-438 rotation since the last frame, with the < 40 inlier fallback
+    Mat3 R;
+    int inl;
+    {
+        HostStage hs(&H->prof.host_estimate_ms);
+        inl = estimate_rotation(T.pp.data(), T.cp.data(), lg.n_tracked, H->Kin, H->Kout, H->rng, R);
+    }
+    lg.n_inliers = inl;
+    if (inl < 40) {
+        R = H->have_last_rot ? H->last_rot : Mat3::identity();
+        lg.fallback = 1;
+    }
+    H->last_rot = R, H->have_last_rot = true;
+    H->measured = R * H->measured;  // :441 left-multiplied accumulation
+    if (H->sg) H->sg->add(H->measured);
+    H->queue.emplace_back(T.slot, H->measured);
+    std::memcpy(lg.R_frame, R.m, sizeof(R.m));
+    std::memcpy(lg.R_accum, H->measured.m, sizeof(R.m));
+    H->log.push_back(lg);
+    H->have_ready = false;
 }
 
 extern "C" {
@@ -508,7 +553,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     output_camera(H->Kin, H->w, H->h, cfg->scale, cfg->crop_borders != 0, cfg->zoom, H->Kout, H->ow, H->oh);
     if (H->ow <= 0 || H->oh <= 0 || H->ow > 32767 || H->oh > 32767) return fail(VSTAB_ERR_INVALID, "vstab_create: output size out of range");
     if (cfg->smoother == VSTAB_SMOOTHER_SG) H->sg.reset(new RotationFilterSG(cfg->smooth_radius));
-    H->slots.resize((size_t)cfg->smooth_radius + 5);  // queue (r+1) + incoming + last gray + 2 spare for stream overlap
+    H->slots.resize((size_t)cfg->smooth_radius + 6);  // queue (r+1) + ready + in flight + first/last gray + 2 spare for stream overlap
     for (auto &s : H->slots) {
         VSTAB_TRY(s.buf.ensure((size_t)H->w * H->h * 3 / 2));
         VSTAB_HIP_TRY(hipEventCreateWithFlags(&s.ingested, hipEventDisableTiming));
@@ -531,20 +576,25 @@ vstab_status vstab_get_output_info(const vstab_handle *h, int *width, int *heigh
 // FrameSourceWarp::pull_frame, :452-476
 vstab_status vstab_pull_frame(vstab_handle *H, void *dst, size_t pitch_dst) {
     if (!H || !dst) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: null argument");
-    while (H->queue.size() <= (size_t)H->cfg.smooth_radius) {
-        vstab_frame f;
-        std::memset(&f, 0, sizeof(f));
-        // the previous frame's copy into the ring may still be in flight on the tracking stream; upstream
-        // is allowed to recycle that frame's memory as soon as it is called again
-        if (H->last_slot >= 0) VSTAB_HIP_TRY(hipEventSynchronize(H->slots[H->last_slot].ingested));
-        const int rc = H->src.pull(H->src.user, &f);
-        if (rc == VSTAB_EOF) {
-            // :456-461 pretend the camera kept its last orientation
+    while (H->queue.size() <= (size_t)H->cfg.smooth_radius) {  // :453
+        if (H->have_inflight) VSTAB_TRY(finish_wait(H));
+        if (H->have_ready) {
+            // read ahead: start tracking the following frame, then estimate this one on the host while
+            // the GPU works
+            if (!H->src_eof) {
+                const vstab_status st = begin_next(H);
+                if (st != VSTAB_OK && st != VSTAB_EOF) return st;
+            }
+            finish_estimate(H);
+            continue;
+        }
+        if (H->src_eof) {
+            // :456-461 pretend the camera kept its last orientation (once per call while draining)
             if (H->sg) H->sg->add(H->measured);
             break;
         }
-        if (rc != 0) return fail(VSTAB_ERR_SOURCE, "upstream pull failed with " + std::to_string(rc));
-        VSTAB_TRY(consume_frame(H, f));
+        const vstab_status st = begin_next(H);
+        if (st != VSTAB_OK && st != VSTAB_EOF) return st;
     }
     if (H->queue.empty()) return VSTAB_EOF;  // :465-467
     const int slot = H->queue.front().first;
@@ -581,7 +631,7 @@ vstab_status vstab_peek_frame(vstab_handle *h, void *dst, size_t pitch_dst) { re
 
 vstab_status vstab_enable_profiling(vstab_handle *h, int enable) {
     if (!h) return fail(VSTAB_ERR_INVALID, "null handle");
-    h->profiling = enable != 0;
+    h->profiling = enable < 0 ? 0 : enable > 2 ? 2 : enable;
     return VSTAB_OK;
 }
 
