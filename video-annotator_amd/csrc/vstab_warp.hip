@@ -318,13 +318,15 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
             const int y = ybase + 16 * j;
             const float vy = div_with_rcp((float)y - a.p.ocy, a.p.ofy, rfy);
             const RowTerm rt = {a.p.r[1] * vy, a.p.r[4] * vy, a.p.r[7] * vy};
-            const bool row_ok = y < a.dh;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float ax, ay;
                 map_pixel32(ta.p32, ct[i], rt, ax, ay);
-                // |32*map| >= 2^22 (or NaN) is outside any source <= 32767 wide; see quantise()
-                const bool ok = (fabsf(ax) < 4194304.0f) && (fabsf(ay) < 4194304.0f) && row_ok && (x0 + i < a.dw);
+                // v_cvt_i32_f32 saturates (+-inf and out-of-range -> INT_MAX / INT_MIN, which land far
+                // outside any source <= 32767 wide after >> 5); only NaN (-> 0) needs an explicit test,
+                // and one ordered compare covers both coordinates.  Equivalent to cv::remap's cvRound
+                // -> INT_MIN -> "outside" (see quantise()).
+                const bool ok = !__builtin_isunordered(ax, ay);
                 const int qx = (int)__builtin_rintf(ax), qy = (int)__builtin_rintf(ay);
                 const int X = qx >> 5, Y = qy >> 5;
                 sx[j][i] = qx, sy[j][i] = qy;
@@ -337,6 +339,16 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
                 }
             }
         }
+    }
+    {
+        // pixels of the tile that hang over the right / bottom edge of the output are neither sampled nor
+        // stored (they still took part in the bounding box, which only makes it slightly conservative)
+        uint32_t cols = 0, live = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) cols |= (x0 + i < a.dw ? 1u : 0u) << i;
+#pragma unroll
+        for (int j = 0; j < RPT; j++) live |= (ybase + 16 * j < a.dh ? cols : 0u) << (4 * j);
+        in_bits &= live, border_bits &= live;
     }
     // bounding box: DPP reduction inside each 16-lane row (4 steps), then one LDS atomic per row.
     // (same-address LDS atomics from all 64 lanes serialise badly; shuffles cost 6 steps + bpermutes)
