@@ -74,7 +74,7 @@ class Tracker {
         for (int l = 1; l < levels_; l++) {
             lw = (lw + 1) / 2, lh = (lh + 1) / 2;
             lvl_w_[l] = lw, lvl_h_[l] = lh;
-            for (int s = 0; s < 2; s++) VSTAB_TRY(pyr_[s][l].ensure((size_t)lw * lh));
+            for (int s = 0; s < 3; s++) VSTAB_TRY(pyr_[s][l].ensure((size_t)lw * lh));
         }
         lvl_w_[0] = w, lvl_h_[0] = h;
         VSTAB_TRY(small_.ensure(256));
@@ -231,7 +231,7 @@ class Tracker {
   private:
     int w_ = 0, h_ = 0, levels_ = 1;
     int lvl_w_[LK_MAX_LEVELS] = {0}, lvl_h_[LK_MAX_LEVELS] = {0};
-    DevBuf pyr_[2][LK_MAX_LEVELS], eig_, keys_, small_;
+    DevBuf pyr_[3][LK_MAX_LEVELS], eig_, keys_, small_;  // three pyramid sets: previous, current, prefetched
     PinnedBuf hsmall_, hkeys_, hpts_;
     unsigned int cap_ = 0;
     hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
@@ -251,7 +251,9 @@ struct vstab_handle {
     vstab_config cfg;
     vstab_source src;
     hipStream_t stream = nullptr;   // caller-visible stream: the warp runs here, dst is complete when it drains
-    hipStream_t tstream = nullptr;  // internal stream: ingest, pyramids, corner detection, LK (overlaps the warp)
+    hipStream_t tstream = nullptr;  // internal stream: corner detection + LK (the per-frame critical path)
+    hipStream_t pstream = nullptr;  // internal stream: ingest + pyramid of the NEXT frame (prefetch, overlaps LK)
+    hipEvent_t pyr_done[3] = {nullptr, nullptr, nullptr};  // recorded on pstream after pyramid set k
     int w = 0, h = 0, ow = 0, oh = 0;
     Mat3 Kin, Kout;
     Tracker tracker;
@@ -267,7 +269,8 @@ struct vstab_handle {
     long free_counter = 0;
     std::vector<Slot> slots;
     int last_slot = -1;  // m_last_input_frame
-    int cur_pyr = 0;     // pyramid slot holding the last input frame's pyramid
+    int last_ingest_slot = -1;
+    int cur_pyr = 0;     // pyramid set holding the last tracked frame's pyramid (frame index mod 3)
 
     long frame_index = 0, last_key = -1;       // m_frame_index, m_last_key_frame_index
     std::vector<float> corners;                // m_last_input_frame_corners
@@ -302,6 +305,7 @@ struct vstab_handle {
         return e;
     }
     void fold_pending() {
+        (void)hipStreamSynchronize(pstream);
         (void)hipStreamSynchronize(tstream);
         (void)hipStreamSynchronize(stream);
         double *sums[ST_COUNT] = {&prof.gpu_ingest_ms, &prof.gpu_pyramid_ms, &prof.gpu_corners_ms, &prof.gpu_lk_ms, &prof.gpu_warp_ms};
@@ -321,6 +325,10 @@ struct vstab_handle {
     };
     Tracked inflight, ready;
     bool have_inflight = false, have_ready = false, src_eof = false;
+    // a frame that has been pulled from upstream, copied into the ring and whose pyramid is being built
+    bool have_prefetched = false;
+    int prefetched_slot = -1, prefetched_pyr = 0;
+    long prefetch_count = 0;
 
     int acquire_slot() {
         int best = -1;
@@ -336,7 +344,8 @@ struct GpuStage {  // records an event pair around a stage when profiling is on
     hipEvent_t a = nullptr;
     int stage;
     hipStream_t s;
-    GpuStage(vstab_handle *h, int st) : H(h), stage(st), s(st == vstab_handle::ST_WARP ? h->stream : h->tstream) {
+    GpuStage(vstab_handle *h, int st)
+        : H(h), stage(st), s(st == vstab_handle::ST_WARP ? h->stream : (st == vstab_handle::ST_INGEST || st == vstab_handle::ST_PYRAMID) ? h->pstream : h->tstream) {
         if (H->profiling >= 2 || (H->profiling == 1 && st == vstab_handle::ST_WARP)) {
             a = H->get_event();
             (void)hipEventRecord(a, s);
@@ -363,36 +372,40 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
     if (f.width != H->w || f.height != H->h) return fail(VSTAB_ERR_INVALID, "frame size changed mid-stream");
     vstab_handle::Slot &S = H->slots[slot];
     uint8_t *dst = S.buf.as<uint8_t>();
-    if (S.warp_pending) {  // the warp that last read this slot runs on the other stream
-        VSTAB_HIP_TRY(hipStreamWaitEvent(H->tstream, S.warped, 0));
+    if (S.warp_pending) {  // the warp that last read this slot runs on another stream
+        VSTAB_HIP_TRY(hipStreamWaitEvent(H->pstream, S.warped, 0));
         S.warp_pending = false;
     }
     if (f.mem == 0) {
-        VSTAB_TRY(vstab_pack_nv12(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->tstream));
+        VSTAB_TRY(vstab_pack_nv12(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->pstream));
     } else {
-        VSTAB_HIP_TRY(hipMemcpy2DAsync(dst, H->w, f.y, f.pitch_y, H->w, H->h, hipMemcpyHostToDevice, H->tstream));
-        VSTAB_HIP_TRY(hipMemcpy2DAsync(dst + (size_t)H->w * H->h, H->w, f.uv, f.pitch_uv, H->w, H->h / 2, hipMemcpyHostToDevice, H->tstream));
-        VSTAB_HIP_TRY(hipStreamSynchronize(H->tstream));  // the caller may reuse its host buffer on return
+        VSTAB_HIP_TRY(hipMemcpy2DAsync(dst, H->w, f.y, f.pitch_y, H->w, H->h, hipMemcpyHostToDevice, H->pstream));
+        VSTAB_HIP_TRY(hipMemcpy2DAsync(dst + (size_t)H->w * H->h, H->w, f.uv, f.pitch_uv, H->w, H->h / 2, hipMemcpyHostToDevice, H->pstream));
+        VSTAB_HIP_TRY(hipStreamSynchronize(H->pstream));  // the caller may reuse its host buffer on return
     }
-    VSTAB_HIP_TRY(hipEventRecord(S.ingested, H->tstream));
+    VSTAB_HIP_TRY(hipEventRecord(S.ingested, H->pstream));
     return VSTAB_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// consume_frame (FrameSourceWarp.cpp:397-450) split into three steps so that the GPU tracking of
-// frame k+1 overlaps the host rotation estimate of frame k (one frame of upstream read-ahead):
-//   begin_next       pull the next upstream frame, key-frame rule (:415-419), pyramid, LK launch
+// consume_frame (FrameSourceWarp.cpp:397-450) split into four steps so that, per pull, the copy + pyramid
+// of frame k+2 and the LK tracking of frame k+1 run on the GPU while the host estimates the rotation
+// of frame k (one frame of upstream read-ahead; three HIP streams ordered by events):
+//   prefetch_next    pull the next upstream frame, copy it into the ring, build its pyramid (pstream)
+//   launch_tracking  key-frame rule (:415-419), LK launch (tstream)
 //   finish_wait      LK results -> surviving pairs (:422-427)
 //   finish_estimate  rotation + fallback + accumulation + filter.add + queue push (:429-446)
 // Every step runs in frame order, so every decision, random draw and queue entry is the one the
 // reference makes; only WHEN the upstream callback is called moves (one frame earlier).
 // ---------------------------------------------------------------------------------------------
-static vstab_status begin_next(vstab_handle *H) {
+// prefetch_next: upstream callback, copy into the ring, pyramid -- all on the prefetch stream, with no
+// dependence on the tracking state, so it overlaps the LK kernel of the previous frame.
+static vstab_status prefetch_next(vstab_handle *H) {
     vstab_frame f;
     std::memset(&f, 0, sizeof(f));
-    // the previous frame's copy into the ring may still be in flight on the tracking stream; upstream
-    // is allowed to recycle that frame's memory as soon as it is called again
-    if (H->last_slot >= 0) VSTAB_HIP_TRY(hipEventSynchronize(H->slots[H->last_slot].ingested));
+    // the previous frame's copy into the ring may still be in flight; upstream is allowed to recycle
+    // that frame's memory as soon as it is called again
+    if (H->last_ingest_slot >= 0) VSTAB_HIP_TRY(hipEventSynchronize(H->slots[H->last_ingest_slot].ingested));
     const int rc = H->src.pull(H->src.user, &f);
     if (rc == VSTAB_EOF) {
         H->src_eof = true;
@@ -401,33 +414,46 @@ static vstab_status begin_next(vstab_handle *H) {
     if (rc != 0) return fail(VSTAB_ERR_SOURCE, "upstream pull failed with " + std::to_string(rc));
     const int slot = H->acquire_slot();
     if (slot < 0) return fail(VSTAB_ERR_NOMEM, "look-ahead ring exhausted");
-    if (f.width != H->w || f.height != H->h) return fail(VSTAB_ERR_INVALID, "frame size changed mid-stream");
-    // Device-resident frames are tracked straight from the upstream planes (valid until the next
-    // callback); the copy into the ring is enqueued BEHIND the LK kernel, off the critical path.
-    const bool direct = f.mem == 0 && H->cfg.tracking && H->last_key != -1;
-    if (!direct) VSTAB_TRY(ingest(H, f, slot));
-    const uint8_t *g = direct ? static_cast<const uint8_t *>(f.y) : H->gray(slot);
-    const size_t pitch = direct ? f.pitch_y : (size_t)H->w;
-    const size_t ring_pitch = (size_t)H->w;
+    VSTAB_TRY(ingest(H, f, slot));
+    H->last_ingest_slot = slot;
+    H->slots[slot].queued = true;  // reserved from now on (released when its warp has been enqueued)
+    const int pyr = (int)(H->prefetch_count % 3);
+    if (H->cfg.tracking) {
+        GpuStage gs(H, vstab_handle::ST_PYRAMID);
+        VSTAB_TRY(H->tracker.build_pyramid(pyr, H->gray(slot), (size_t)H->w, H->pstream));
+        VSTAB_HIP_TRY(hipEventRecord(H->pyr_done[pyr], H->pstream));
+    }
+    H->prefetched_slot = slot, H->prefetched_pyr = pyr, H->have_prefetched = true;
+    H->prefetch_count++;
+    return VSTAB_OK;
+}
+
+// launch_tracking: key-frame rule (:415-419) and the LK launch for the prefetched frame.  Needs the
+// surviving corners of the previous frame (finish_wait), i.e. runs in frame order.
+static vstab_status launch_tracking(vstab_handle *H) {
+    const int slot = H->prefetched_slot, pyr = H->prefetched_pyr;
+    H->have_prefetched = false;
+    const size_t pitch = (size_t)H->w;
+    const uint8_t *g = H->gray(slot);
     if (!H->cfg.tracking) {
         // undistort-only mode (BASELINE config 1): every frame gets the identity rotation
         if (H->last_key == -1) {
             H->last_key = H->frame_index;
+            H->slots[slot].queued = false;  // the first frame is never emitted (:403-407)
         } else {
             if (H->sg) H->sg->add(H->measured);
-            H->slots[slot].queued = true;
             H->queue.emplace_back(slot, H->measured);
         }
     } else if (H->last_key == -1) {
         // :403-407 the first frame only seeds the corner set
         H->last_key = H->frame_index;
+        VSTAB_HIP_TRY(hipStreamWaitEvent(H->tstream, H->pyr_done[pyr], 0));
         {
             HostStage hs(&H->prof.host_corners_ms);
             VSTAB_TRY(H->tracker.good_features(g, pitch, 200, 0.01, 30.0, H->corners, H->tstream));
         }
         H->prof.key_frames++;
-        GpuStage gs(H, vstab_handle::ST_PYRAMID);
-        VSTAB_TRY(H->tracker.build_pyramid(H->cur_pyr, g, pitch, H->tstream));
+        H->slots[slot].queued = false;
     } else {
         vstab_handle::Tracked &T = H->inflight;
         T = vstab_handle::Tracked();
@@ -437,24 +463,18 @@ static vstab_status begin_next(vstab_handle *H) {
         if (H->frame_index - H->last_key > 20 || H->corners.size() / 2 < 150) {
             H->last_key = H->frame_index - 1;
             HostStage hs(&H->prof.host_corners_ms);
-            VSTAB_TRY(H->tracker.good_features(pg, ring_pitch, 200, 0.01, 30.0, H->corners, H->tstream));
+            VSTAB_TRY(H->tracker.good_features(pg, pitch, 200, 0.01, 30.0, H->corners, H->tstream));
             T.lg.key_frame = 1;
             H->prof.key_frames++;
         }
         T.lg.n_corners = (int)(H->corners.size() / 2);
         T.prev = H->corners;
-        const int prev_pyr = H->cur_pyr, next_pyr = 1 - H->cur_pyr;
-        {
-            GpuStage gs(H, vstab_handle::ST_PYRAMID);
-            VSTAB_TRY(H->tracker.build_pyramid(next_pyr, g, pitch, H->tstream));
-        }
-        VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(prev_pyr, pg, ring_pitch), H->tracker.pyramid(next_pyr, g, pitch), H->corners,
-                                          H->tstream, H->profiling >= 2));
-        if (direct) VSTAB_TRY(ingest(H, f, slot));  // runs behind LK
-        H->cur_pyr = next_pyr;
-        H->slots[slot].queued = true;  // reserved: it will enter the queue in finish_estimate
+        VSTAB_HIP_TRY(hipStreamWaitEvent(H->tstream, H->pyr_done[pyr], 0));  // pyramid (and ring copy) of this frame
+        VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(H->cur_pyr, pg, pitch), H->tracker.pyramid(pyr, g, pitch), H->corners, H->tstream,
+                                          H->profiling >= 2));
         H->have_inflight = true;
     }
+    H->cur_pyr = pyr;
     H->prof.frames_consumed++;
     if (H->last_slot >= 0) {
         H->slots[H->last_slot].last = false;
@@ -539,6 +559,8 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->tstream, hipStreamNonBlocking, hi));
+        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, hi));
+        for (auto &e : H->pyr_done) VSTAB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // :214-219 peek the first frame for the input size, then derive both cameras
     vstab_frame f;
@@ -577,24 +599,25 @@ vstab_status vstab_get_output_info(const vstab_handle *h, int *width, int *heigh
 vstab_status vstab_pull_frame(vstab_handle *H, void *dst, size_t pitch_dst) {
     if (!H || !dst) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: null argument");
     while (H->queue.size() <= (size_t)H->cfg.smooth_radius) {  // :453
+        // 1. read ahead: pull + copy + pyramid of the next frame overlap the LK kernel still in flight
+        if (!H->have_prefetched && !H->src_eof) {
+            const vstab_status st = prefetch_next(H);
+            if (st != VSTAB_OK && st != VSTAB_EOF) return st;
+        }
+        // 2. LK results of the frame in flight -> surviving corners
         if (H->have_inflight) VSTAB_TRY(finish_wait(H));
+        // 3. key-frame rule + LK launch for the prefetched frame (GPU), then
+        if (H->have_prefetched) VSTAB_TRY(launch_tracking(H));
+        // 4. ... the host estimates the rotation of the frame whose tracks just arrived meanwhile
         if (H->have_ready) {
-            // read ahead: start tracking the following frame, then estimate this one on the host while
-            // the GPU works
-            if (!H->src_eof) {
-                const vstab_status st = begin_next(H);
-                if (st != VSTAB_OK && st != VSTAB_EOF) return st;
-            }
             finish_estimate(H);
             continue;
         }
-        if (H->src_eof) {
+        if (!H->have_inflight && !H->have_prefetched && H->src_eof) {
             // :456-461 pretend the camera kept its last orientation (once per call while draining)
             if (H->sg) H->sg->add(H->measured);
             break;
         }
-        const vstab_status st = begin_next(H);
-        if (st != VSTAB_OK && st != VSTAB_EOF) return st;
     }
     if (H->queue.empty()) return VSTAB_EOF;  // :465-467
     const int slot = H->queue.front().first;
@@ -650,6 +673,9 @@ void vstab_destroy(vstab_handle *h) {
         if (s.ingested) (void)hipEventDestroy(s.ingested);
         if (s.warped) (void)hipEventDestroy(s.warped);
     }
+    for (auto e : h->pyr_done)
+        if (e) (void)hipEventDestroy(e);
+    if (h->pstream) (void)hipStreamDestroy(h->pstream);
     if (h->tstream) (void)hipStreamDestroy(h->tstream);
     delete h;
 }
