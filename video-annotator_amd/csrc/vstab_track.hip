@@ -222,39 +222,58 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return __builtin_amdgcn_readlane(v, 63);
 }
-// per-lane |v| < 2^31: split into a signed high part and a 16-bit low part so that both partial
-// sums over 64 lanes stay inside int32, then recombine exactly
-__device__ __forceinline__ long long wave_sum_split(int v) {
-    const int hi = wave_sum_i32(v >> 16), lo = wave_sum_i32(v & 0xffff);
-    return ((long long)hi << 16) + lo;
-}
-// the same total as a float: hi*65536 + lo is exact in double (|.| < 2^53), and double -> float
-// rounds the exact integer once, i.e. equals (float)(int64 sum)
-__device__ __forceinline__ float wave_sum_split_f32(int v) {
-    const int hi = wave_sum_i32(v >> 16), lo = wave_sum_i32(v & 0xffff);
-    return (float)__builtin_fma((double)hi, 65536.0, (double)lo);
-}
-
 #define LK_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
-__global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const float2 *__restrict__ prev_pts,
-                                                 int n, float2 *__restrict__ next_pts, uint8_t *__restrict__ status,
-                                                 uint4 *__restrict__ host_rec, unsigned int seq) {
+// k_lk_track: ONE WORKGROUP OF 4 WAVES PER FEATURE.  The tracker is latency bound (<= 200 features, a
+// dependent Gauss-Newton chain of up to 4 x 30 iterations), so the 441 window pixels are spread over
+// 256 lanes (<= 2 per lane) to shorten every iteration.  Integer partial sums are reduced per wave with
+// DPP, exchanged through a double-buffered LDS array (one barrier per iteration) and added in a fixed
+// order; integer addition is associative, so the totals -- and everything derived from them -- are
+// independent of the decomposition.  Each per-lane partial is split into a signed high part and a 16-bit
+// low part so that every partial sum stays inside int32; hi * 65536 + lo is exact in double and the one
+// double -> float conversion equals (float)(int64 total).
+constexpr int LK_THREADS = 256, LK_WAVES = 4;
+
+struct LkExchange {
+    int part[2][LK_WAVES][6];  // [parity][wave][hi/lo of up to three quantities]
+};
+
+template <int NQ>
+__device__ __forceinline__ void lk_block_sums(LkExchange &ex, int parity, int wave, int lane, const int (&v)[NQ], float (&out)[NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int hi = wave_sum_i32(v[q] >> 16), lo = wave_sum_i32(v[q] & 0xffff);  // uniform (SGPR) results
+        if (lane == 0) ex.part[parity][wave][2 * q] = hi, ex.part[parity][wave][2 * q + 1] = lo;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        int hi = 0, lo = 0;
+#pragma unroll
+        for (int wv = 0; wv < LK_WAVES; wv++) hi += ex.part[parity][wv][2 * q], lo += ex.part[parity][wv][2 * q + 1];
+        out[q] = (float)__builtin_fma((double)hi, 65536.0, (double)lo);
+    }
+}
+
+__global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid J, const float2 *__restrict__ prev_pts,
+                                                         int n, float2 *__restrict__ next_pts, uint8_t *__restrict__ status,
+                                                         uint4 *__restrict__ host_rec, unsigned int seq) {
     __shared__ int regI[LKR * LKR];
     __shared__ int derx[LKT * LKT], dery[LKT * LKT];
     __shared__ int regJ[LKJR * LKJR];
-    const int f = blockIdx.x, lane = threadIdx.x;
+    __shared__ LkExchange ex;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (f >= n) return;
     const float2 pp = prev_pts[f];
     float2 np = make_float2(0.f, 0.f);
-    int st = 1;
+    int st = 1, parity = 0;
     const float half = (LKW - 1) * 0.5f;
     const int max_level = I.levels - 1;
-    // window pixel -> (wy, wx) of this lane's up to 7 pixels, fixed for the whole kernel
-    int woff[7];
+    // this thread's window pixels: k = tid and tid + 256 (441 pixels in all)
+    int woff[2];
 #pragma unroll
-    for (int m = 0; m < 7; m++) {
-        const int k = lane + 64 * m;
+    for (int m = 0; m < 2; m++) {
+        const int k = tid + LK_THREADS * m;
         const int wy = k / LKW, wx = k - wy * LKW;
         woff[m] = k < LKW * LKW ? (wy << 8) | wx : -1;
     }
@@ -284,7 +303,7 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
         __syncthreads();  // previous level's readers are done with LDS
         {
             const bool interior = ipx >= 1 && ipy >= 1 && ipx + LKR - 1 <= w && ipy + LKR - 1 <= h;
-            for (int e = lane; e < LKR * LKR; e += 64) {
+            for (int e = tid; e < LKR * LKR; e += LK_THREADS) {
                 const int ry = e / LKR, rx = e - ry * LKR;
                 const int Y = ipy - 1 + ry, X = ipx - 1 + rx;
                 regI[e] = interior ? img[(uint32_t)Y * ipitch + (uint32_t)X]
@@ -292,7 +311,7 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
             }
         }
         __syncthreads();
-        for (int e = lane; e < LKT * LKT; e += 64) {
+        for (int e = tid; e < LKT * LKT; e += LK_THREADS) {
             const int tyy = e / LKT, txx = e - tyy * LKT;
             const int X = ipx + txx, Y = ipy + tyy;
             int dx = 0, dy = 0;
@@ -305,10 +324,10 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
             derx[e] = dx, dery[e] = dy;
         }
         __syncthreads();
-        short Iw[7], Ixw[7], Iyw[7];
-        int pA11 = 0, pA12 = 0, pA22 = 0;  // per-lane partial sums: 7 * 4080^2 < 2^27
+        short Iw[2], Ixw[2], Iyw[2];
+        int pA[3] = {0, 0, 0};  // per-lane partial sums: 2 * 4080^2 < 2^26
 #pragma unroll
-        for (int m = 0; m < 7; m++) {
+        for (int m = 0; m < 2; m++) {
             Iw[m] = Ixw[m] = Iyw[m] = 0;
             if (woff[m] >= 0) {
                 const int wy = woff[m] >> 8, wx = woff[m] & 255;
@@ -318,12 +337,14 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
                 const int ixval = LK_DESCALE(derx[d] * iw00 + derx[d + 1] * iw01 + derx[d + LKT] * iw10 + derx[d + LKT + 1] * iw11, 14);
                 const int iyval = LK_DESCALE(dery[d] * iw00 + dery[d + 1] * iw01 + dery[d + LKT] * iw10 + dery[d + LKT + 1] * iw11, 14);
                 Iw[m] = (short)ival, Ixw[m] = (short)ixval, Iyw[m] = (short)iyval;
-                pA11 += ixval * ixval, pA12 += ixval * iyval, pA22 += iyval * iyval;
+                pA[0] += ixval * ixval, pA[1] += ixval * iyval, pA[2] += iyval * iyval;
             }
         }
+        float sA[3];
+        lk_block_sums<3>(ex, parity, wave, lane, pA, sA);
+        parity ^= 1;
         const float FLT_SCALE = 1.0f / (1 << 20);
-        const float A11 = wave_sum_split_f32(pA11) * FLT_SCALE, A12 = wave_sum_split_f32(pA12) * FLT_SCALE,
-                    A22 = wave_sum_split_f32(pA22) * FLT_SCALE;
+        const float A11 = sA[0] * FLT_SCALE, A12 = sA[1] * FLT_SCALE, A22 = sA[2] * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = ((A22 + A11) - sqrtf((A11 - A22) * (A11 - A22) + (4.f * A12) * A12)) / (float)(2 * LKW * LKW);
         if (minEig < 1e-4f || D < 1.1920928955078125e-7f) {
@@ -346,11 +367,11 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
             iw10 = (int)rintf((1.f - a) * b * 16384.f);
             iw11 = 16384 - iw00 - iw01 - iw10;
             if (inx < jx0 || iny < jy0 || inx + LKT > jx0 + LKJR || iny + LKT > jy0 + LKJR) {
-                // (re)stage a 32x32 block of the next image centred on the window; wave-uniform branch
+                // (re)stage a 32x32 block of the next image centred on the window; block-uniform branch
                 jx0 = inx - LKJM, jy0 = iny - LKJM;
                 const bool interior = jx0 >= 0 && jy0 >= 0 && jx0 + LKJR <= w && jy0 + LKJR <= h;
                 __syncthreads();
-                for (int e = lane; e < LKJR * LKJR; e += 64) {
+                for (int e = tid; e < LKJR * LKJR; e += LK_THREADS) {
                     const int ry = e / LKJR, rx = e - ry * LKJR;
                     regJ[e] = interior ? jmg[(uint32_t)(jy0 + ry) * jpitch + (uint32_t)(jx0 + rx)]
                                        : jmg[(uint32_t)reflect101(jy0 + ry, h) * jpitch + (uint32_t)reflect101(jx0 + rx, w)];
@@ -358,16 +379,19 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
                 __syncthreads();
             }
             const int jbase = (iny - jy0) * LKJR + (inx - jx0);
-            int pb1 = 0, pb2 = 0;  // per-lane partial sums: 7 * 16320 * 4080 < 2^29
+            int pb[2] = {0, 0};  // per-lane partial sums: 2 * 16320 * 4080 < 2^28
 #pragma unroll
-            for (int m = 0; m < 7; m++) {
+            for (int m = 0; m < 2; m++) {
                 if (woff[m] >= 0) {
                     const int *c = &regJ[jbase + (woff[m] >> 8) * LKJR + (woff[m] & 255)];
                     const int diff = LK_DESCALE(c[0] * iw00 + c[1] * iw01 + c[LKJR] * iw10 + c[LKJR + 1] * iw11, 9) - Iw[m];
-                    pb1 += diff * Ixw[m], pb2 += diff * Iyw[m];
+                    pb[0] += diff * Ixw[m], pb[1] += diff * Iyw[m];
                 }
             }
-            const float b1 = wave_sum_split_f32(pb1) * FLT_SCALE, b2 = wave_sum_split_f32(pb2) * FLT_SCALE;
+            float sb[2];
+            lk_block_sums<2>(ex, parity, wave, lane, pb, sb);
+            parity ^= 1;
+            const float b1 = sb[0] * FLT_SCALE, b2 = sb[1] * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
             npx += dx, npy += dy;
             np = make_float2(npx + half, npy + half);
@@ -379,7 +403,7 @@ __global__ void __launch_bounds__(64) k_lk_track(LkPyramid I, LkPyramid J, const
             pdx = dx, pdy = dy;
         }
     }
-    if (lane == 0) {
+    if (tid == 0) {
         if (host_rec) {
             // one self-validating 16-byte record per feature in coherent (uncached) host memory: data and
             // sequence tag leave in a single store, so no fence or counter is needed and the host simply
@@ -428,7 +452,7 @@ vstab_status launch_corner_candidates(const float *eig, int w, int h, const int 
 vstab_status launch_lk(const LkPyramid &I, const LkPyramid &J, const float2 *prev_pts, int n, float2 *next_pts,
                        uint8_t *status, void *host_records, unsigned int seq, hipStream_t s) {
     if (n <= 0) return VSTAB_OK;
-    hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(64), 0, s, I, J, prev_pts, n, next_pts, status, static_cast<uint4 *>(host_records), seq);
+    hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(LK_THREADS), 0, s, I, J, prev_pts, n, next_pts, status, static_cast<uint4 *>(host_records), seq);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }
