@@ -103,35 +103,33 @@ static bool solve_pnp_lm(const double *obj, const float *img, const int *idx, in
     double cost = reproj_cost(pose, obj, img, idx, n, f, cx, cy);
     if (!std::isfinite(cost)) return false;
     for (int it = 0; it < max_iter; it++) {
-        double JtJ[36] = {0}, Jtr[6] = {0};
+        // normal equations: upper triangle of J^T J (21 entries) and J^T r, with the closed-form Jacobian
+        // of u = f*x/z + cx, v = f*y/z + cy with respect to a left rotation increment w and translation t:
+        //   dY/dw = -[R X]x , dY/dt = I
+        double H[6][6] = {{0}}, g[6] = {0};
         for (int i = 0; i < n; i++) {
             const int k = idx ? idx[i] : i;
-            double u[2], Y[3];
-            project(pose, obj + 3 * k, f, cx, cy, u, Y);
-            const double ex = u[0] - img[2 * k], ey = u[1] - img[2 * k + 1];
-            const double iz = 1.0 / Y[2];
-            const double RX[3] = {Y[0] - pose.t[0], Y[1] - pose.t[1], Y[2] - pose.t[2]};
-            // d(pi)/dY
-            const double a[2][3] = {{f * iz, 0, -f * Y[0] * iz * iz}, {0, f * iz, -f * Y[1] * iz * iz}};
-            // dY/d(omega) = -[RX]x ; dY/dt = I
-            const double S[3][3] = {{0, RX[2], -RX[1]}, {-RX[2], 0, RX[0]}, {RX[1], -RX[0], 0}};
-            double J[2][6];
-            for (int r = 0; r < 2; r++) {
-                for (int c = 0; c < 3; c++) J[r][c] = a[r][0] * S[0][c] + a[r][1] * S[1][c] + a[r][2] * S[2][c];
-                for (int c = 0; c < 3; c++) J[r][3 + c] = a[r][c];
+            const double *X = obj + 3 * k;
+            const double x = pose.R(0, 0) * X[0] + pose.R(0, 1) * X[1] + pose.R(0, 2) * X[2];
+            const double y = pose.R(1, 0) * X[0] + pose.R(1, 1) * X[1] + pose.R(1, 2) * X[2];
+            const double z = pose.R(2, 0) * X[0] + pose.R(2, 1) * X[1] + pose.R(2, 2) * X[2];  // R X
+            const double Yx = x + pose.t[0], Yy = y + pose.t[1], Yz = z + pose.t[2];
+            const double iz = 1.0 / Yz, fz = f * iz, xz = Yx * iz, yz = Yy * iz;
+            const double eu = fz * Yx + cx - img[2 * k], ev = fz * Yy + cy - img[2 * k + 1];
+            const double Ju[6] = {-fz * xz * y, fz * (z + xz * x), -fz * y, fz, 0.0, -fz * xz};
+            const double Jv[6] = {-fz * (z + yz * y), fz * yz * x, fz * x, 0.0, fz, -fz * yz};
+            for (int c = 0; c < 6; c++) {
+                g[c] += Ju[c] * eu + Jv[c] * ev;
+                for (int d = c; d < 6; d++) H[c][d] += Ju[c] * Ju[d] + Jv[c] * Jv[d];
             }
-            const double e[2] = {ex, ey};
-            for (int r = 0; r < 2; r++)
-                for (int c = 0; c < 6; c++) {
-                    Jtr[c] += J[r][c] * e[r];
-                    for (int d = 0; d < 6; d++) JtJ[c * 6 + d] += J[r][c] * J[r][d];
-                }
         }
         bool improved = false;
         for (int tries = 0; tries < 8 && !improved; tries++) {
             double A[36], b[6];
-            std::memcpy(A, JtJ, sizeof(A));
-            for (int c = 0; c < 6; c++) A[c * 6 + c] += lambda * (JtJ[c * 6 + c] + 1e-12), b[c] = -Jtr[c];
+            for (int c = 0; c < 6; c++) {
+                for (int d = 0; d < 6; d++) A[c * 6 + d] = c <= d ? H[c][d] : H[d][c];
+                A[c * 6 + c] += lambda * (H[c][c] + 1e-12), b[c] = -g[c];
+            }
             if (!solve6(A, b)) {
                 lambda *= 10;
                 continue;
@@ -143,7 +141,7 @@ static bool solve_pnp_lm(const double *obj, const float *img, const int *idx, in
             if (std::isfinite(c2) && c2 < cost) {
                 const double rel = (cost - c2) / std::max(cost, 1e-300);
                 pose = cand, cost = c2, lambda = std::max(lambda * 0.1, 1e-12), improved = true;
-                if (rel < 1e-12 || cost < 1e-20) return true;
+                if (rel < 1e-9 || cost < 1e-20) return true;
             } else {
                 lambda *= 10;
             }
@@ -165,9 +163,11 @@ static int ransac_update_iters(double p, double ep, int model_points, int max_it
 int estimate_rotation(const float *prev, const float *cur, int n, const Mat3 &Kin, const Mat3 &Kout, Pcg32 &rng, Mat3 &R) {
     R = Mat3::identity();
     if (n < 5) return 0;  // solvePnPRansac needs >= model size; the reference maps failure to (I, 0) (:367-371)
-    std::vector<double> tmp(2 * (size_t)n), und(2 * (size_t)n);
-    std::vector<float> img(2 * (size_t)n);
-    std::vector<double> obj(3 * (size_t)n);
+    static thread_local std::vector<double> tmp, und, obj;
+    static thread_local std::vector<float> img;
+    static thread_local std::vector<uint8_t> best_mask, mask;
+    static thread_local std::vector<int> inl;
+    tmp.resize(2 * (size_t)n), und.resize(2 * (size_t)n), obj.resize(3 * (size_t)n), img.resize(2 * (size_t)n);
     // :322-330 current points -> output-camera pixels (R = I, P = output matrix), stored as Point2f
     for (int i = 0; i < 2 * n; i++) tmp[i] = cur[i];
     fisheye_undistort(tmp.data(), n, Kin, Kout, und.data());
@@ -186,7 +186,7 @@ int estimate_rotation(const float *prev, const float *cur, int n, const Mat3 &Ki
     const double thresh2 = 8.0 * 8.0, confidence = 0.99;
     int niters = 100, best_count = 0;
     Pose best;
-    std::vector<uint8_t> best_mask(n, 0), mask(n, 0);
+    best_mask.assign(n, 0), mask.assign(n, 0);
     for (int iter = 0; iter < niters; iter++) {
         int idx[5];
         for (int k = 0; k < model_points;) {
@@ -213,7 +213,7 @@ int estimate_rotation(const float *prev, const float *cur, int n, const Mat3 &Ki
     }
     if (best_count <= 0) return 0;
     // refit on all inliers (SOLVEPNP_ITERATIVE in the reference), starting from the best sample model
-    std::vector<int> inl;
+    inl.clear();
     for (int i = 0; i < n; i++)
         if (best_mask[i]) inl.push_back(i);
     Pose refined = best;

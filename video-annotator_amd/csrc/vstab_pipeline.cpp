@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -270,6 +271,8 @@ struct vstab_handle {
     std::vector<Slot> slots;
     int last_slot = -1;  // m_last_input_frame
     int last_ingest_slot = -1;
+    int last_warp_slot = -1;
+    bool serialize_prefetch = false;  // VSTAB_SERIALIZE_PREFETCH=1: start copy+pyramid only after the last warp (measured slower)
     int cur_pyr = 0;     // pyramid set holding the last tracked frame's pyramid (frame index mod 3)
 
     long frame_index = 0, last_key = -1;       // m_frame_index, m_last_key_frame_index
@@ -376,6 +379,10 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
         VSTAB_HIP_TRY(hipStreamWaitEvent(H->pstream, S.warped, 0));
         S.warp_pending = false;
     }
+    // Copy + pyramid are full-GPU streaming kernels: running them beside the (VALU-bound, full-GPU) warp
+    // only makes both slower.  Start them when the last warp has drained; what overlaps the warp is the
+    // low-occupancy LK kernel.
+    if (H->last_warp_slot >= 0 && H->serialize_prefetch) VSTAB_HIP_TRY(hipStreamWaitEvent(H->pstream, H->slots[H->last_warp_slot].warped, 0));
     if (f.mem == 0) {
         VSTAB_TRY(vstab_pack_nv12(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->pstream));
     } else {
@@ -552,6 +559,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     std::unique_ptr<vstab_handle> H(new vstab_handle);
     H->cfg = *cfg, H->src = *src;
     H->rng = Pcg32(cfg->seed);
+    if (const char *e = getenv("VSTAB_SERIALIZE_PREFETCH")) H->serialize_prefetch = atoi(e) != 0;
     H->stream = static_cast<hipStream_t>(cfg->stream);  // NULL = the default stream, as for the stateless operators
     {
         // the tracking chain is the per-frame critical path; the warp only has to finish before the
@@ -647,6 +655,7 @@ vstab_status vstab_pull_frame(vstab_handle *H, void *dst, size_t pitch_dst) {
                                                 pitch_dst, H->ow, H->oh, H->stream);
     VSTAB_HIP_TRY(hipEventRecord(S.warped, H->stream));  // the next ingest into this slot waits for it
     S.warp_pending = true, S.queued = false, S.freed_at = ++H->free_counter;
+    H->last_warp_slot = slot;
     return st;
 }
 
