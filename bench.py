@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--mode", default="auto", choices=["auto", "warp", "pipeline"])
     ap.add_argument("--ring", type=int, default=64, help="distinct input frames / output buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo only for rehearsing ranks on one GPU")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--traffic", default=None, help="measured HBM bytes per launch from PMC passes (profiles/)")
     return ap.parse_args()
 
@@ -143,11 +146,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     vs = importlib.import_module("video-annotator_amd")  # raises if libvstab.so is missing: no fallback
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where collective payloads live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     w, h = (3840, 2160) if args.workload == "4k" else (1920, 1080)
     preset = vs.GOPRO_H4B_WIDE169_MEASURED
@@ -212,7 +221,7 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -221,7 +230,7 @@ def main():
     shard = importlib.import_module("video-annotator_amd.shard")
     last = outs[(args.warmup + args.steps - 1) % args.ring]
     rec = dict(rank=rank, clip=rank, frames=args.steps, elapsed_ns=int(el * 1e9), crc=shard.crc_of(last[:64].cpu().numpy()))
-    records = shard.gather_records([rec], device=dev)
+    records = shard.gather_records([rec], device=cdev)
     if rank == 0 and world > 1:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", f"concat_list_{world}gpu.txt"), "w") as fh:

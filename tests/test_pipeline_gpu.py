@@ -130,3 +130,98 @@ def test_kalman_and_none_smoothers_run(vs, cuda, clip):
         assert len(outs) == 9
         if sm == vs.SMOOTHER_NONE:
             assert np.allclose(stab.warp_rotation(4), np.eye(3), atol=1e-9)   # corrected == measured -> no correction
+
+
+def test_host_memory_frames_and_pitched_planes(vs, cuda, clip):
+    """vstab_frame.mem = 1 (host planes, any pitch) must give the same stream as device frames."""
+    import ctypes
+    K, frames, _ = clip
+    n = 10
+    ref_stab, ref_outs = run_product(vs, cuda, frames[:n], smooth_radius=3, seed=9)
+    # host source with padded pitches, driven through the raw C ABI callbacks
+    pitch = W + 32
+    bufs = []
+    for f in frames[:n]:
+        yb = np.zeros((H, pitch), np.uint8)
+        ub = np.zeros((H // 2, pitch), np.uint8)
+        yb[:, :W], ub[:, :W] = f[:H], f[H:]
+        bufs.append((yb, ub))
+    state = {"i": 0}
+
+    def fill(out, advance):
+        if state["i"] >= n:
+            return vs.EOF
+        yb, ub = bufs[state["i"]]
+        o = out.contents
+        o.y, o.uv = yb.ctypes.data, ub.ctypes.data
+        o.pitch_y = o.pitch_uv = pitch
+        o.width, o.height, o.mem, o.pts = W, H, 1, state["i"]
+        if advance:
+            state["i"] += 1
+        return 0
+    pull = vs.PULL_FN(lambda u, o: fill(o, True))
+    peek = vs.PULL_FN(lambda u, o: fill(o, False))
+    src = vs.Source(pull, peek, None)
+    cfg = vs.default_config(smooth_radius=3, seed=9)
+    h = ctypes.c_void_p()
+    assert vs.lib.vstab_create(ctypes.byref(cfg), ctypes.byref(src), ctypes.byref(h)) == vs.OK
+    import torch
+    cw, ch = ref_stab.out_size
+    outs = []
+    while True:
+        o = torch.empty((ch, cw, 3), dtype=torch.uint8, device=cuda)
+        st = vs.lib.vstab_pull_frame(h, o.data_ptr(), o.stride(0))
+        if st == vs.EOF:
+            break
+        assert st == vs.OK, vs.lib.vstab_last_error()
+        outs.append(o.cpu().numpy())
+    vs.lib.vstab_destroy(h)
+    assert len(outs) == len(ref_outs) == n - 1
+    for a, b in zip(outs, ref_outs):
+        assert np.array_equal(a, b)
+
+
+def test_upstream_error_code_is_propagated(vs, cuda, clip):
+    """A non-EOF upstream failure (the reference rethrows the int, FrameSourceWarp.cpp:462) -> VSTAB_ERR_SOURCE."""
+    import ctypes
+    import torch
+    K, frames, _ = clip
+    dev_frames = [torch.from_numpy(f).to(cuda) for f in frames[:3]]
+    state = {"i": 0}
+
+    def fill(out, advance):
+        if state["i"] >= 3:
+            return 7          # some upstream error code
+        f = dev_frames[state["i"]]
+        o = out.contents
+        o.y, o.uv = f.data_ptr(), f.data_ptr() + H * f.stride(0)
+        o.pitch_y = o.pitch_uv = f.stride(0)
+        o.width, o.height, o.mem, o.pts = W, H, 0, 0
+        if advance:
+            state["i"] += 1
+        return 0
+    pull = vs.PULL_FN(lambda u, o: fill(o, True))
+    peek = vs.PULL_FN(lambda u, o: fill(o, False))
+    src = vs.Source(pull, peek, None)
+    cfg = vs.default_config(smooth_radius=5)
+    h = ctypes.c_void_p()
+    assert vs.lib.vstab_create(ctypes.byref(cfg), ctypes.byref(src), ctypes.byref(h)) == vs.OK
+    o = torch.empty((400, 700, 3), dtype=torch.uint8, device=cuda)
+    assert vs.lib.vstab_pull_frame(h, o.data_ptr(), o.stride(0)) == vs.ERR_SOURCE
+    assert b"7" in vs.lib.vstab_last_error()
+    vs.lib.vstab_destroy(h)
+
+
+def test_profile_counts_and_stage_times(vs, cuda, clip):
+    K, frames, _ = clip
+    import torch
+    dev_frames = [torch.from_numpy(f).to(cuda) for f in frames[:12]]
+    stab = vs.Stabilizer(dev_frames, total=12, smooth_radius=2, seed=4)
+    stab.enable_profiling(2)
+    n = 0
+    while stab.pull() is not None:
+        n += 1
+    p = stab.profile()
+    assert n == 11 and p["frames_emitted"] == 11 and p["frames_consumed"] == 12 and p["warp_launches"] == 11
+    assert p["gpu_warp_ms"] > 0 and p["gpu_lk_ms"] > 0 and p["gpu_pyramid_ms"] > 0 and p["host_estimate_ms"] > 0
+    assert p["key_frames"] >= 1

@@ -278,8 +278,9 @@ __device__ __forceinline__ uint32_t load_u32_bytes(const uint8_t *p, int valid) 
     return v;
 }
 
-template <int RPT>
-__global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
+template <int RPT, int TY>
+__global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
+    constexpr int NT = 16 * TY;  // threads per workgroup: 16 columns of 4 pixels x TY thread rows
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     int *bbox = reinterpret_cast<int *>(smem);  // minX, minY, maxX, maxY (16 B; keeps the tile 16-B aligned)
     uint32_t *tile = smem + 4;
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
     if (tile_id >= ntiles) return;  // uniform for the workgroup (before any barrier)
     const int tile_y = tile_id / ta.tiles_x, tile_x = tile_id - tile_y * ta.tiles_x;
     const int x0 = tile_x * WARP_TILE_W + tx * 4;
-    const int ybase = tile_y * (16 * RPT) + ty;
+    const int ybase = tile_y * (TY * RPT) + ty;
     if (tid == 0) bbox[0] = bbox[1] = INT_MAX, bbox[2] = bbox[3] = INT_MIN;
     __syncthreads();
 
@@ -315,7 +316,7 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
         const uint32_t sw1 = (uint32_t)(a.sw - 1), sh1 = (uint32_t)(a.sh - 1);
 #pragma unroll
         for (int j = 0; j < RPT; j++) {
-            const int y = ybase + 16 * j;
+            const int y = ybase + TY * j;
             const float vy = div_with_rcp((float)y - a.p.ocy, a.p.ofy, rfy);
             const RowTerm rt = {a.p.r[1] * vy, a.p.r[4] * vy, a.p.r[7] * vy};
 #pragma unroll
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
 #pragma unroll
         for (int i = 0; i < 4; i++) cols |= (x0 + i < a.dw ? 1u : 0u) << i;
 #pragma unroll
-        for (int j = 0; j < RPT; j++) live |= (ybase + 16 * j < a.dh ? cols : 0u) << (4 * j);
+        for (int j = 0; j < RPT; j++) live |= (ybase + TY * j < a.dh ? cols : 0u) << (4 * j);
         in_bits &= live, border_bits &= live;
     }
     // bounding box: DPP reduction inside each 16-lane row (4 steps), then one LDS atomic per row.
@@ -374,7 +375,7 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
         const int ux_n = wb >> 2, units = ux_n * (hb >> 1);
         const uint32_t magic = (1u << 18) / (uint32_t)ux_n + 1u;  // u / ux_n == (u * magic) >> 18 for u < 2048
         const uint32_t pitch_y = (uint32_t)a.pitch_y, pitch_uv = (uint32_t)a.pitch_uv;  // < 2^24 (host check)
-        for (int u = tid; u < units; u += 256) {
+        for (int u = tid; u < units; u += NT) {
             const uint32_t uy = ((uint32_t)u * magic) >> 18, ux = (uint32_t)u - __umul24(uy, (uint32_t)ux_n);
             const uint32_t gx = (uint32_t)bx0 + 4u * ux, gy = (uint32_t)by0 + 2u * uy;
             const uint32_t oy = __umul24(gy, pitch_y) + gx, ouv = __umul24(gy >> 1, pitch_uv) + gx;  // frame < 4 GiB
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(256) k_warp_tiled(TiledArgs ta) {
     const int lds_origin = by0 * wb + bx0;
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
-        const int y = ybase + 16 * j;
+        const int y = ybase + TY * j;
         if (y >= a.dh) break;
         uint32_t px[4];
 #pragma unroll
@@ -571,17 +572,20 @@ vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const void *uv, 
         static const int dbg = getenv("VSTAB_DEBUG_MODE") ? atoi(getenv("VSTAB_DEBUG_MODE")) : 0;
         ta.debug_mode = dbg;
         static const int rpt = getenv("VSTAB_RPT") ? atoi(getenv("VSTAB_RPT")) : 2;
+        static const int tyr = getenv("VSTAB_TY") ? atoi(getenv("VSTAB_TY")) : 16;
         static const int lds_kb = getenv("VSTAB_LDS_KB") ? atoi(getenv("VSTAB_LDS_KB")) : 40;
         const size_t lds_bytes = (size_t)lds_kb * 1024;  // 40 KB -> 4 workgroups (16 waves) per CU
         ta.lds_capacity_px = (int)(lds_bytes / 4) - 4;
-        ta.tiles_x = (int)div_up(dw, WARP_TILE_W), ta.tiles_y = (int)div_up(dh, 16 * rpt);
+        ta.tiles_x = (int)div_up(dw, WARP_TILE_W), ta.tiles_y = (int)div_up(dh, tyr * rpt);
         dim3 grid(8 * div_up((unsigned)(ta.tiles_x * ta.tiles_y), 8));
-        if (rpt == 1)
-            hipLaunchKernelGGL(k_warp_tiled<1>, grid, dim3(256), lds_bytes, static_cast<hipStream_t>(stream), ta);
-        else if (rpt == 4)
-            hipLaunchKernelGGL(k_warp_tiled<4>, grid, dim3(256), lds_bytes, static_cast<hipStream_t>(stream), ta);
-        else
-            hipLaunchKernelGGL(k_warp_tiled<2>, grid, dim3(256), lds_bytes, static_cast<hipStream_t>(stream), ta);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+#define VSTAB_LAUNCH(R, T) hipLaunchKernelGGL((k_warp_tiled<R, T>), grid, dim3(16 * T), lds_bytes, st, ta)
+        if (tyr == 8 && rpt == 2) VSTAB_LAUNCH(2, 8);
+        else if (tyr == 8 && rpt == 4) VSTAB_LAUNCH(4, 8);
+        else if (tyr == 4 && rpt == 4) VSTAB_LAUNCH(4, 4);
+        else if (tyr == 16 && rpt == 1) VSTAB_LAUNCH(1, 16);
+        else VSTAB_LAUNCH(2, 16);
+#undef VSTAB_LAUNCH
     }
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
