@@ -15,6 +15,15 @@ __device__ __forceinline__ int reflect101(int i, int n) {  // BORDER_REFLECT_101
     return i;
 }
 
+// One dword of a REFLECT_101-padded image row at columns gx .. gx+3 (gx a multiple of 4).
+__device__ __forceinline__ uint32_t load4_reflect_row(const uint8_t *__restrict__ row, int w, int gx, bool vec_ok) {
+    if (vec_ok && gx >= 0 && gx + 4 <= w) return *reinterpret_cast<const uint32_t *>(row + gx);
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v |= (uint32_t)row[reflect101(gx + i, w)] << (8 * i);
+    return v;
+}
+
 // One dword of a REFLECT_101-padded u8 image at (gx .. gx+3, gy), gx a multiple of 4.  Dwords that lie
 // inside the row are one aligned load (also on border tiles); only dwords straddling the left /
 // right image edge are assembled from bytes.
@@ -31,58 +40,43 @@ __device__ __forceinline__ uint32_t load4_reflect(const uint8_t *__restrict__ sr
 // =============================================================================================
 // k_pyr_down -- cv::pyrDown as used by buildOpticalFlowPyramid: 5x5 binomial
 // [1 4 6 4 1]^2, integer, (sum + 128) >> 8, REFLECT_101, dst = ((w+1)/2, (h+1)/2).
-// 128 x 8 outputs per workgroup.  The 264 x 19 byte source tile is loaded with coalesced dword
-// loads (interior tiles) into LDS, the horizontal pass runs once per source row (4 outputs per
-// thread from one 12-byte LDS read), the vertical pass produces 4 outputs = one dword store.
+// Register-only: one thread produces 4 adjacent outputs of one row from five 16-byte row segments
+// (aligned dword loads; the 2.5x overlap between vertically adjacent threads is served by L1/L2),
+// vertical pass first (11 columns), then the horizontal pass, one dword store.  No LDS, no barriers:
+// the kernel is a pure stream and overlaps well with the LK kernel of the previous frame.
 // =============================================================================================
-constexpr int PD_TW = 128, PD_TH = 8, PD_SW = 2 * PD_TW + 8, PD_SH = 2 * PD_TH + 3;  // tile starts at 2*ox - 4
+__device__ __forceinline__ uint32_t pd_byte(const uint32_t (&d)[4], int b) { return (d[b >> 2] >> ((b & 3) * 8)) & 255u; }
 
 __global__ void __launch_bounds__(256) k_pyr_down(const uint8_t *__restrict__ src, size_t spitch, int sw, int sh,
                                                   uint8_t *__restrict__ dst, size_t dpitch, int dw, int dh, int vec_ok) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[PD_SH][PD_SW];
-    __shared__ __attribute__((aligned(16))) uint16_t hrow[PD_SH][PD_TW];
-    const int tid = threadIdx.x;
-    const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
-    const int sx0 = 2 * ox - 4, sy0 = 2 * oy - 2;
-    for (int e = tid; e < PD_SH * (PD_SW / 4); e += 256) {
-        const int ry = e / (PD_SW / 4), rd = e - ry * (PD_SW / 4);
-        reinterpret_cast<uint32_t *>(&tile[ry][0])[rd] = load4_reflect(src, (uint32_t)spitch, sw, sh, sx0 + 4 * rd, sy0 + ry, vec_ok != 0);
-    }
-    __syncthreads();
-    for (int e = tid; e < PD_SH * (PD_TW / 4); e += 256) {
-        const int ry = e / (PD_TW / 4), q = e - ry * (PD_TW / 4);  // outputs 4q .. 4q+3 of this row
-        // taps of output c start at tile byte 2c + 2: bytes [8q + 2, 8q + 12]
-        const uint32_t *t32 = reinterpret_cast<const uint32_t *>(&tile[ry][8 * q]);
-        const uint32_t d0 = t32[0], d1 = t32[1], d2 = t32[2], d3 = t32[3];
-        const uint32_t b[16] = {d0 & 255, (d0 >> 8) & 255, (d0 >> 16) & 255, d0 >> 24, d1 & 255, (d1 >> 8) & 255, (d1 >> 16) & 255, d1 >> 24,
-                                d2 & 255, (d2 >> 8) & 255, (d2 >> 16) & 255, d2 >> 24, d3 & 255, (d3 >> 8) & 255, (d3 >> 16) & 255, d3 >> 24};
-        uint32_t o[4];
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= dw || y >= dh) return;
+    const int sx0 = 2 * x0 - 4;  // the 16 bytes [sx0, sx0+16) hold the taps of outputs x0..x0+3 at offsets 2..12
+    uint32_t v[11];  // vertical pass result for tile bytes 2..12
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const uint32_t *t = &b[2 * c + 2];
-            o[c] = t[0] + 4 * t[1] + 6 * t[2] + 4 * t[3] + t[4];
-        }
-        *reinterpret_cast<uint2 *>(&hrow[ry][4 * q]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-    }
-    __syncthreads();
-    const int q = tid & 31, ty = tid >> 5;
-    const int x = ox + 4 * q, y = oy + ty;
-    if (x < dw && y < dh) {
-        uint32_t acc[4] = {0, 0, 0, 0};
-        const int kk[5] = {1, 4, 6, 4, 1};
+    for (int b = 0; b < 11; b++) v[b] = 0;
+    const uint32_t kk[5] = {1, 4, 6, 4, 1};
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
-            const uint2 v = *reinterpret_cast<const uint2 *>(&hrow[2 * ty + j][4 * q]);
-            acc[0] += kk[j] * (v.x & 0xffff), acc[1] += kk[j] * (v.x >> 16), acc[2] += kk[j] * (v.y & 0xffff), acc[3] += kk[j] * (v.y >> 16);
-        }
-        uint8_t *o = dst + (size_t)y * dpitch + x;
-        const uint32_t r0 = (acc[0] + 128) >> 8, r1 = (acc[1] + 128) >> 8, r2 = (acc[2] + 128) >> 8, r3 = (acc[3] + 128) >> 8;
-        if (vec_ok && x + 4 <= dw) {
-            *reinterpret_cast<uint32_t *>(o) = r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
-        } else {
-            const uint32_t r[4] = {r0, r1, r2, r3};
-            for (int c = 0; c < 4 && x + c < dw; c++) o[c] = (uint8_t)r[c];
-        }
+    for (int j = 0; j < 5; j++) {
+        const uint32_t roff = (uint32_t)reflect101(2 * y - 2 + j, sh) * (uint32_t)spitch;
+        uint32_t d[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)  // per-dword edge handling: only dwords straddling an image edge take the byte path
+            d[q] = load4_reflect_row(src + roff, sw, sx0 + 4 * q, vec_ok != 0);
+#pragma unroll
+        for (int b = 0; b < 11; b++) v[b] += kk[j] * pd_byte(d, b + 2);
+    }
+    uint32_t r[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t s = v[2 * c] + 4 * v[2 * c + 1] + 6 * v[2 * c + 2] + 4 * v[2 * c + 3] + v[2 * c + 4];
+        r[c] = (s + 128) >> 8;
+    }
+    uint8_t *o = dst + (size_t)y * dpitch + x0;
+    if (vec_ok && x0 + 4 <= dw) {
+        *reinterpret_cast<uint32_t *>(o) = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+    } else {
+        for (int c = 0; c < 4 && x0 + c < dw; c++) o[c] = (uint8_t)r[c];
     }
 }
 
@@ -423,7 +417,7 @@ vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, 
                              hipStream_t s) {
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
     const int vec_ok = reinterpret_cast<uintptr_t>(src) % 4 == 0 && spitch % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && dpitch % 4 == 0;
-    dim3 grid(div_up(dw, PD_TW), div_up(dh, PD_TH));
+    dim3 grid(div_up(dw, 256), div_up(dh, 4));  // 64 threads x 4 outputs wide, 4 rows per workgroup
     hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, src, spitch, sw, sh, dst, dpitch, dw, dh, vec_ok);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
