@@ -567,7 +567,9 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->tstream, hipStreamNonBlocking, hi));
-        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, hi));
+        // copy + pyramid of the NEXT frame have a whole frame period of slack: lowest priority, so they fill
+        // in behind the warp instead of taking its CUs
+        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, getenv("VSTAB_PSTREAM_HI") ? hi : lo));
         for (auto &e : H->pyr_done) VSTAB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // :214-219 peek the first frame for the input size, then derive both cameras
