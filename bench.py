@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--workload", default="4k", choices=["4k", "1080p"])
     ap.add_argument("--mode", default="auto", choices=["auto", "warp", "pipeline"])
     ap.add_argument("--ring", type=int, default=64, help="distinct input frames / output buffers")
+    ap.add_argument("--no-tracking", action="store_true",
+                    help="BASELINE config 1: undistort only (identity rotations) through the pipeline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo only for rehearsing ranks on one GPU")
@@ -195,7 +197,8 @@ def main():
         workload = f"{args.workload} NV12 {w}x{h} -> BGR {cw}x{ch}, fused undistort-remap (createMap+cvtColor+remap), per-frame rotation, tracking/smoothing NOT included"
     else:
         clip, _ = shaky_ring(torch, dev, w, h, K, args.ring, seed=rank)
-        stab = vs.Stabilizer(clip, total=args.warmup + args.steps + 1000, preset=preset, smooth_radius=30, seed=1234 + rank)
+        stab = vs.Stabilizer(clip, total=args.warmup + args.steps + 1000, preset=preset, smooth_radius=30, seed=1234 + rank,
+                             tracking=0 if args.no_tracking else 1)
         assert stab.out_size == (cw, ch)
 
         def step(i, timed):
@@ -205,6 +208,8 @@ def main():
             assert stab.pull_into(outs[i % args.ring])
         stab.enable_profiling(1)  # timed region: HIP events around the warp launches only
         workload = f"{args.workload} NV12 {w}x{h} -> BGR {cw}x{ch}, full pipeline: NV12 ingest, corner detect, pyramidal LK, rotation estimate, SG smoothing (r=30), fused undistort-remap"
+        if args.no_tracking:
+            workload = f"{args.workload} NV12 {w}x{h} -> BGR {cw}x{ch}, undistort only (tracking off, identity rotations): NV12 ingest + fused undistort-remap"
 
     for i in range(args.warmup):
         step(i, False)
