@@ -91,3 +91,17 @@ def test_pyr_lk_empty_and_tiny(vs, cuda):
     got, gst = vs.pyr_lk(dev(g, cuda), dev(g, cuda), pts)
     exp, est = oracle.pyr_lk(g, g, pts)
     assert np.array_equal(gst, est) and np.array_equal(got, exp)
+
+
+def test_tracking_parity_at_4k(vs, cuda):
+    """BASELINE.json's full size: corner indices and LK tracks of a 3840x2160 frame pair, bit for bit."""
+    w, h = 3840, 2160
+    g0 = synth.luma(41, w, h, rects=400)
+    g1 = synth.shifted(g0, 2.6, -1.9)
+    got = vs.good_features(dev(g0, cuda))
+    exp = oracle.good_features(g0)
+    assert np.array_equal(got, exp) and len(got) == 200
+    nxt, st = vs.pyr_lk(dev(g0, cuda), dev(g1, cuda), exp)
+    onxt, ost = oracle.pyr_lk(g0, g1, exp)
+    assert np.array_equal(st, ost) and np.array_equal(nxt.view(np.uint32), onxt.view(np.uint32))
+    assert st.sum() > 150
