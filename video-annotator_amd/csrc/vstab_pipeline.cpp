@@ -103,6 +103,52 @@ class Tracker {
         return p;
     }
 
+    // host half of goodFeaturesToTrack: sort the candidate keys (value descending, ties -> later raster
+    // position first: greaterThanPtr in OpenCV) and run the minimum-distance grid
+    void select_corners(unsigned long long *k, unsigned int n, int max_corners, double min_distance, std::vector<float> &xy) {
+        xy.clear();
+        const int cell = (int)std::nearbyint(min_distance);
+        const int gw = cell >= 1 ? (w_ + cell - 1) / cell : 0, gh = cell >= 1 ? (h_ + cell - 1) / cell : 0;
+        const double md2 = min_distance * min_distance;
+        if (cell >= 1) grid_head_.assign((size_t)gw * gh, -1), grid_next_.clear();
+        // The greedy pass consumes candidates in sorted order and usually stops after a few hundred, so the
+        // keys are sorted lazily in chunks: nth_element splits off the next `chunk` largest keys (O(n)),
+        // only that chunk is sorted.  The visiting order is exactly the fully sorted order.
+        unsigned int done = 0;
+        const auto greater = [](unsigned long long a, unsigned long long b) { return a > b; };
+        while (done < n) {
+            const unsigned int chunk = std::min(n - done, 1024u);
+            if (done + chunk < n) std::nth_element(k + done, k + done + chunk, k + n, greater);
+            std::sort(k + done, k + done + chunk, greater);
+            for (unsigned int i = done; i < done + chunk; i++) {
+                const unsigned int idx = (unsigned int)(k[i] & 0xffffffffu);
+                const int x = (int)(idx % w_), y = (int)(idx / w_);
+                if (cell < 1) {
+                    xy.push_back((float)x), xy.push_back((float)y);
+                } else {
+                    const int xc = x / cell, yc = y / cell;
+                    const int x1 = std::max(0, xc - 1), y1 = std::max(0, yc - 1), x2 = std::min(gw - 1, xc + 1), y2 = std::min(gh - 1, yc + 1);
+                    bool good = true;
+                    for (int yy = y1; yy <= y2 && good; yy++)
+                        for (int xx = x1; xx <= x2 && good; xx++)
+                            for (int j = grid_head_[(size_t)yy * gw + xx]; j >= 0; j = grid_next_[j]) {
+                                const float dx = (float)x - xy[2 * j], dy = (float)y - xy[2 * j + 1];
+                                if ((double)(dx * dx + dy * dy) < md2) {
+                                    good = false;
+                                    break;
+                                }
+                            }
+                    if (!good) continue;
+                    grid_next_.push_back(grid_head_[(size_t)yc * gw + xc]);
+                    grid_head_[(size_t)yc * gw + xc] = (int)(xy.size() / 2);
+                    xy.push_back((float)x), xy.push_back((float)y);
+                }
+                if (max_corners > 0 && (int)(xy.size() / 2) == max_corners) return;
+            }
+            done += chunk;
+        }
+    }
+
     // goodFeaturesToTrack(gray, max_corners, quality, min_distance); synchronises the stream
     vstab_status good_features(const uint8_t *gray, size_t pitch, int max_corners, double quality, double min_distance,
                                std::vector<float> &xy, hipStream_t st, float *eig_out = nullptr) {
@@ -133,43 +179,39 @@ class Tracker {
         VSTAB_TRY(hkeys_.ensure(sizeof(unsigned long long) * n));
         VSTAB_HIP_TRY(hipMemcpyAsync(hkeys_.p, keys_.p, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, st));
         VSTAB_HIP_TRY(hipStreamSynchronize(st));
-        unsigned long long *k = hkeys_.as<unsigned long long>();
-        // value descending, ties -> later raster position first (greaterThanPtr in OpenCV)
-        std::sort(k, k + n, [](unsigned long long a, unsigned long long b) { return a > b; });
-        // minimum-distance grid (goodFeaturesToTrack)
-        const int cell = (int)std::nearbyint(min_distance);
-        if (cell < 1) {
-            for (unsigned int i = 0; i < n && (max_corners <= 0 || (int)(xy.size() / 2) < max_corners); i++) {
-                const unsigned int idx = (unsigned int)(k[i] & 0xffffffffu);
-                xy.push_back((float)(idx % w_)), xy.push_back((float)(idx / w_));
-            }
-            return VSTAB_OK;
-        }
-        const int gw = (w_ + cell - 1) / cell, gh = (h_ + cell - 1) / cell;
-        std::vector<std::vector<int>> grid((size_t)gw * gh);
-        const double md2 = min_distance * min_distance;
-        for (unsigned int i = 0; i < n; i++) {
-            const unsigned int idx = (unsigned int)(k[i] & 0xffffffffu);
-            const int x = (int)(idx % w_), y = (int)(idx / w_);
-            const int xc = x / cell, yc = y / cell;
-            const int x1 = std::max(0, xc - 1), y1 = std::max(0, yc - 1), x2 = std::min(gw - 1, xc + 1), y2 = std::min(gh - 1, yc + 1);
-            bool good = true;
-            for (int yy = y1; yy <= y2 && good; yy++)
-                for (int xx = x1; xx <= x2 && good; xx++)
-                    for (int j : grid[(size_t)yy * gw + xx]) {
-                        const float dx = (float)x - xy[2 * j], dy = (float)y - xy[2 * j + 1];
-                        if ((double)(dx * dx + dy * dy) < md2) {
-                            good = false;
-                            break;
-                        }
-                    }
-            if (good) {
-                grid[(size_t)yc * gw + xc].push_back((int)(xy.size() / 2));
-                xy.push_back((float)x), xy.push_back((float)y);
-                if (max_corners > 0 && (int)(xy.size() / 2) == max_corners) break;
-            }
-        }
+        select_corners(hkeys_.as<unsigned long long>(), n, max_corners, min_distance, xy);
         return VSTAB_OK;
+    }
+
+    // Speculative detection: the same two kernels enqueued on another stream ahead of time (the counter
+    // half of the key-frame rule is predictable), with the count and the first SPEC_CAP keys copied to
+    // pinned memory behind them.  spec_finish() only has to wait for the event and run the host half.
+    static constexpr unsigned int SPEC_CAP = 1u << 15;
+    vstab_status spec_launch(const uint8_t *gray, size_t pitch, double quality, hipStream_t st, long tag) {
+        VSTAB_TRY(spec_eig_.ensure(sizeof(float) * (size_t)w_ * h_));
+        VSTAB_TRY(spec_keys_.ensure(sizeof(unsigned long long) * SPEC_CAP));
+        VSTAB_TRY(spec_small_.ensure(256));
+        VSTAB_TRY(spec_host_.ensure(64 + sizeof(unsigned long long) * SPEC_CAP));
+        if (!spec_ev_) VSTAB_HIP_TRY(hipEventCreateWithFlags(&spec_ev_, hipEventDisableTiming));
+        int *max_bits = spec_small_.as<int>();
+        unsigned int *count = spec_small_.as<unsigned int>() + 4;
+        VSTAB_TRY(launch_min_eig(gray, pitch, w_, h_, spec_eig_.as<float>(), max_bits, st));
+        VSTAB_TRY(launch_corner_candidates(spec_eig_.as<float>(), w_, h_, max_bits, quality, spec_keys_.as<unsigned long long>(), count, SPEC_CAP, st));
+        VSTAB_HIP_TRY(hipMemcpyAsync(spec_host_.p, count, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        VSTAB_HIP_TRY(hipMemcpyAsync(spec_host_.as<uint8_t>() + 64, spec_keys_.p, sizeof(unsigned long long) * SPEC_CAP, hipMemcpyDeviceToHost, st));
+        VSTAB_HIP_TRY(hipEventRecord(spec_ev_, st));
+        spec_tag_ = tag;
+        return VSTAB_OK;
+    }
+    long spec_tag() const { return spec_tag_; }
+    // returns true and fills xy if the speculative result is usable (candidate count within SPEC_CAP)
+    bool spec_finish(int max_corners, double min_distance, std::vector<float> &xy) {
+        spec_tag_ = -1;
+        if (!spec_ev_ || hipEventSynchronize(spec_ev_) != hipSuccess) return false;
+        const unsigned int n = *spec_host_.as<unsigned int>();
+        if (n > SPEC_CAP) return false;
+        select_corners(reinterpret_cast<unsigned long long *>(spec_host_.as<uint8_t>() + 64), n, max_corners, min_distance, xy);
+        return true;
     }
 
     // calcOpticalFlowPyrLK(prev, next, pts), split in two so the caller can enqueue more work behind the
@@ -233,6 +275,11 @@ class Tracker {
     int w_ = 0, h_ = 0, levels_ = 1;
     int lvl_w_[LK_MAX_LEVELS] = {0}, lvl_h_[LK_MAX_LEVELS] = {0};
     DevBuf pyr_[3][LK_MAX_LEVELS], eig_, keys_, small_;  // three pyramid sets: previous, current, prefetched
+    DevBuf spec_eig_, spec_keys_, spec_small_;
+    PinnedBuf spec_host_;
+    hipEvent_t spec_ev_ = nullptr;
+    long spec_tag_ = -1;
+    std::vector<int> grid_head_, grid_next_;  // min-distance grid: per-cell singly linked lists of accepted corners
     PinnedBuf hsmall_, hkeys_, hpts_;
     unsigned int cap_ = 0;
     hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
@@ -272,6 +319,7 @@ struct vstab_handle {
     int last_slot = -1;  // m_last_input_frame
     int last_ingest_slot = -1;
     int last_warp_slot = -1;
+    bool speculate = true;            // VSTAB_SPECULATE=0 disables speculative corner detection
     bool serialize_prefetch = false;  // VSTAB_SERIALIZE_PREFETCH=1: start copy+pyramid only after the last warp (measured slower)
     int cur_pyr = 0;     // pyramid set holding the last tracked frame's pyramid (frame index mod 3)
 
@@ -430,6 +478,18 @@ static vstab_status prefetch_next(vstab_handle *H) {
         VSTAB_TRY(H->tracker.build_pyramid(pyr, H->gray(slot), (size_t)H->w, H->pstream));
         VSTAB_HIP_TRY(hipEventRecord(H->pyr_done[pyr], H->pstream));
     }
+    // Key-frame rule, counter half (:415): the frame after this one re-detects corners on THIS frame when
+    // (index + 1) - last_key > 20.  That is known now, so the detector runs here, on the prefetch stream,
+    // a whole frame period before its result is needed; launch_tracking falls back to detecting on demand
+    // if the prediction turns out wrong (an extra key frame in between) or the candidates overflow.
+    // (launch_tracking for THIS frame has not run yet: if it re-detects, last_key moves and the next
+    // frame will not, so speculate only when this frame's own rule is false and the next one's is true.)
+    if (H->cfg.tracking && H->speculate && H->last_key != -1 && !(H->prefetch_count - H->last_key > 20) &&
+        (H->prefetch_count + 1) - H->last_key > 20)
+    {
+        if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "spec launch for frame %ld (last_key %ld)\n", H->prefetch_count, H->last_key);
+        VSTAB_TRY(H->tracker.spec_launch(H->gray(slot), (size_t)H->w, 0.01, H->pstream, H->prefetch_count));
+    }
     H->prefetched_slot = slot, H->prefetched_pyr = pyr, H->have_prefetched = true;
     H->prefetch_count++;
     return VSTAB_OK;
@@ -470,7 +530,10 @@ static vstab_status launch_tracking(vstab_handle *H) {
         if (H->frame_index - H->last_key > 20 || H->corners.size() / 2 < 150) {
             H->last_key = H->frame_index - 1;
             HostStage hs(&H->prof.host_corners_ms);
-            VSTAB_TRY(H->tracker.good_features(pg, pitch, 200, 0.01, 30.0, H->corners, H->tstream));
+            // the previous frame is frame_index - 1: use its speculative detection if there is one
+            const bool spec = H->tracker.spec_tag() == H->frame_index - 1 && H->tracker.spec_finish(200, 30.0, H->corners);
+            if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "key frame at %ld: spec_tag %ld used %d\n", H->frame_index, H->tracker.spec_tag(), (int)spec);
+            if (!spec) VSTAB_TRY(H->tracker.good_features(pg, pitch, 200, 0.01, 30.0, H->corners, H->tstream));
             T.lg.key_frame = 1;
             H->prof.key_frames++;
         }
@@ -560,6 +623,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     H->cfg = *cfg, H->src = *src;
     H->rng = Pcg32(cfg->seed);
     if (const char *e = getenv("VSTAB_SERIALIZE_PREFETCH")) H->serialize_prefetch = atoi(e) != 0;
+    if (const char *e = getenv("VSTAB_SPECULATE")) H->speculate = atoi(e) != 0;
     H->stream = static_cast<hipStream_t>(cfg->stream);  // NULL = the default stream, as for the stateless operators
     {
         // the tracking chain is the per-frame critical path; the warp only has to finish before the
