@@ -218,7 +218,9 @@ VSTAB_API vstab_status vstab_get_output_info(const vstab_handle *h, int *width, 
  * buffered (or EOF), then warps the oldest buffered frame into dst (device BGR8).  Returns
  * VSTAB_EOF when the stream is drained.  The first input frame is never emitted (:403-407).
  * dst is complete once vstab_config.stream is synchronised.  Upstream frames handed to the callbacks
- * must already be complete in memory when the callback returns (they are read on an internal stream). */
+ * must already be complete in memory when the callback returns (they are read on an internal stream).
+ * Read-ahead: to overlap copy, pyramid and tracking with the host work, the library pulls upstream up
+ * to three frames earlier than the reference's loop would (same frames, same order, same outputs). */
 VSTAB_API vstab_status vstab_pull_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
 /* FrameSourceWarp::peek_frame (:478-480) IS pull_frame in the reference (destructive); kept. */
 VSTAB_API vstab_status vstab_peek_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);

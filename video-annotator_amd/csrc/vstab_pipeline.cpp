@@ -67,6 +67,9 @@ struct PinnedBuf {  // host memory the device can read and write directly (mappe
 // ---------------------------------------------------------------------------------------------
 // Tracker: device workspace for goodFeaturesToTrack + calcOpticalFlowPyrLK
 // ---------------------------------------------------------------------------------------------
+constexpr int PYR_SETS = 4;       // previous + current (in flight) + two prefetched frames
+constexpr int PREFETCH_DEPTH = 2;  // frames pulled from upstream ahead of the one being tracked
+
 class Tracker {
   public:
     vstab_status init(int w, int h) {
@@ -75,7 +78,7 @@ class Tracker {
         for (int l = 1; l < levels_; l++) {
             lw = (lw + 1) / 2, lh = (lh + 1) / 2;
             lvl_w_[l] = lw, lvl_h_[l] = lh;
-            for (int s = 0; s < 3; s++) VSTAB_TRY(pyr_[s][l].ensure((size_t)lw * lh));
+            for (int s = 0; s < PYR_SETS; s++) VSTAB_TRY(pyr_[s][l].ensure((size_t)lw * lh));
         }
         lvl_w_[0] = w, lvl_h_[0] = h;
         VSTAB_TRY(small_.ensure(256));
@@ -274,7 +277,7 @@ class Tracker {
   private:
     int w_ = 0, h_ = 0, levels_ = 1;
     int lvl_w_[LK_MAX_LEVELS] = {0}, lvl_h_[LK_MAX_LEVELS] = {0};
-    DevBuf pyr_[3][LK_MAX_LEVELS], eig_, keys_, small_;  // three pyramid sets: previous, current, prefetched
+    DevBuf pyr_[PYR_SETS][LK_MAX_LEVELS], eig_, keys_, small_;  // pyramid sets: previous, current, prefetched x2
     DevBuf spec_eig_, spec_keys_, spec_small_;
     PinnedBuf spec_host_;
     hipEvent_t spec_ev_ = nullptr;
@@ -301,7 +304,7 @@ struct vstab_handle {
     hipStream_t stream = nullptr;   // caller-visible stream: the warp runs here, dst is complete when it drains
     hipStream_t tstream = nullptr;  // internal stream: corner detection + LK (the per-frame critical path)
     hipStream_t pstream = nullptr;  // internal stream: ingest + pyramid of the NEXT frame (prefetch, overlaps LK)
-    hipEvent_t pyr_done[3] = {nullptr, nullptr, nullptr};  // recorded on pstream after pyramid set k
+    hipEvent_t pyr_done[PYR_SETS] = {};  // recorded on pstream after pyramid set k
     int w = 0, h = 0, ow = 0, oh = 0;
     Mat3 Kin, Kout;
     Tracker tracker;
@@ -377,8 +380,7 @@ struct vstab_handle {
     Tracked inflight, ready;
     bool have_inflight = false, have_ready = false, src_eof = false;
     // a frame that has been pulled from upstream, copied into the ring and whose pyramid is being built
-    bool have_prefetched = false;
-    int prefetched_slot = -1, prefetched_pyr = 0;
+    std::deque<std::pair<int, int>> prefetched;  // (ring slot, pyramid set), oldest first
     long prefetch_count = 0;
 
     int acquire_slot() {
@@ -444,14 +446,14 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
 
 // ---------------------------------------------------------------------------------------------
 // consume_frame (FrameSourceWarp.cpp:397-450) split into four steps so that, per pull, the copy + pyramid
-// of frame k+2 and the LK tracking of frame k+1 run on the GPU while the host estimates the rotation
-// of frame k (one frame of upstream read-ahead; three HIP streams ordered by events):
+// of frames k+2, k+3 and the LK tracking of frame k+1 run on the GPU while the host estimates the rotation
+// of frame k (PREFETCH_DEPTH frames of upstream read-ahead; three HIP streams ordered by events):
 //   prefetch_next    pull the next upstream frame, copy it into the ring, build its pyramid (pstream)
 //   launch_tracking  key-frame rule (:415-419), LK launch (tstream)
 //   finish_wait      LK results -> surviving pairs (:422-427)
 //   finish_estimate  rotation + fallback + accumulation + filter.add + queue push (:429-446)
 // Every step runs in frame order, so every decision, random draw and queue entry is the one the
-// reference makes; only WHEN the upstream callback is called moves (one frame earlier).
+// reference makes; only WHEN the upstream callback is called moves (up to PREFETCH_DEPTH + 1 frames earlier).
 // ---------------------------------------------------------------------------------------------
 // prefetch_next: upstream callback, copy into the ring, pyramid -- all on the prefetch stream, with no
 // dependence on the tracking state, so it overlaps the LK kernel of the previous frame.
@@ -472,7 +474,7 @@ static vstab_status prefetch_next(vstab_handle *H) {
     VSTAB_TRY(ingest(H, f, slot));
     H->last_ingest_slot = slot;
     H->slots[slot].queued = true;  // reserved from now on (released when its warp has been enqueued)
-    const int pyr = (int)(H->prefetch_count % 3);
+    const int pyr = (int)(H->prefetch_count % PYR_SETS);
     if (H->cfg.tracking) {
         GpuStage gs(H, vstab_handle::ST_PYRAMID);
         VSTAB_TRY(H->tracker.build_pyramid(pyr, H->gray(slot), (size_t)H->w, H->pstream));
@@ -482,15 +484,14 @@ static vstab_status prefetch_next(vstab_handle *H) {
     // (index + 1) - last_key > 20.  That is known now, so the detector runs here, on the prefetch stream,
     // a whole frame period before its result is needed; launch_tracking falls back to detecting on demand
     // if the prediction turns out wrong (an extra key frame in between) or the candidates overflow.
-    // (launch_tracking for THIS frame has not run yet: if it re-detects, last_key moves and the next
-    // frame will not, so speculate only when this frame's own rule is false and the next one's is true.)
-    if (H->cfg.tracking && H->speculate && H->last_key != -1 && !(H->prefetch_count - H->last_key > 20) &&
-        (H->prefetch_count + 1) - H->last_key > 20)
+    // (The rule has not been evaluated yet for the frames still in the read-ahead window; "== 21" is the
+    // one frame for which it is false for every pending frame and true for the next.)
+    if (H->cfg.tracking && H->speculate && H->last_key != -1 && (H->prefetch_count + 1) - H->last_key == 21)
     {
         if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "spec launch for frame %ld (last_key %ld)\n", H->prefetch_count, H->last_key);
         VSTAB_TRY(H->tracker.spec_launch(H->gray(slot), (size_t)H->w, 0.01, H->pstream, H->prefetch_count));
     }
-    H->prefetched_slot = slot, H->prefetched_pyr = pyr, H->have_prefetched = true;
+    H->prefetched.emplace_back(slot, pyr);
     H->prefetch_count++;
     return VSTAB_OK;
 }
@@ -498,8 +499,8 @@ static vstab_status prefetch_next(vstab_handle *H) {
 // launch_tracking: key-frame rule (:415-419) and the LK launch for the prefetched frame.  Needs the
 // surviving corners of the previous frame (finish_wait), i.e. runs in frame order.
 static vstab_status launch_tracking(vstab_handle *H) {
-    const int slot = H->prefetched_slot, pyr = H->prefetched_pyr;
-    H->have_prefetched = false;
+    const int slot = H->prefetched.front().first, pyr = H->prefetched.front().second;
+    H->prefetched.pop_front();
     const size_t pitch = (size_t)H->w;
     const uint8_t *g = H->gray(slot);
     if (!H->cfg.tracking) {
@@ -649,7 +650,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     output_camera(H->Kin, H->w, H->h, cfg->scale, cfg->crop_borders != 0, cfg->zoom, H->Kout, H->ow, H->oh);
     if (H->ow <= 0 || H->oh <= 0 || H->ow > 32767 || H->oh > 32767) return fail(VSTAB_ERR_INVALID, "vstab_create: output size out of range");
     if (cfg->smoother == VSTAB_SMOOTHER_SG) H->sg.reset(new RotationFilterSG(cfg->smooth_radius));
-    H->slots.resize((size_t)cfg->smooth_radius + 6);  // queue (r+1) + ready + in flight + first/last gray + 2 spare for stream overlap
+    H->slots.resize((size_t)cfg->smooth_radius + 5 + PREFETCH_DEPTH);  // queue (r+1) + ready + in flight + first/last gray + 2 spare for stream overlap
     for (auto &s : H->slots) {
         VSTAB_TRY(s.buf.ensure((size_t)H->w * H->h * 3 / 2));
         VSTAB_HIP_TRY(hipEventCreateWithFlags(&s.ingested, hipEventDisableTiming));
@@ -674,20 +675,20 @@ vstab_status vstab_pull_frame(vstab_handle *H, void *dst, size_t pitch_dst) {
     if (!H || !dst) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: null argument");
     while (H->queue.size() <= (size_t)H->cfg.smooth_radius) {  // :453
         // 1. read ahead: pull + copy + pyramid of the next frame overlap the LK kernel still in flight
-        if (!H->have_prefetched && !H->src_eof) {
+        while ((int)H->prefetched.size() < PREFETCH_DEPTH && !H->src_eof) {
             const vstab_status st = prefetch_next(H);
             if (st != VSTAB_OK && st != VSTAB_EOF) return st;
         }
         // 2. LK results of the frame in flight -> surviving corners
         if (H->have_inflight) VSTAB_TRY(finish_wait(H));
         // 3. key-frame rule + LK launch for the prefetched frame (GPU), then
-        if (H->have_prefetched) VSTAB_TRY(launch_tracking(H));
+        if (!H->prefetched.empty() && !H->have_inflight) VSTAB_TRY(launch_tracking(H));
         // 4. ... the host estimates the rotation of the frame whose tracks just arrived meanwhile
         if (H->have_ready) {
             finish_estimate(H);
             continue;
         }
-        if (!H->have_inflight && !H->have_prefetched && H->src_eof) {
+        if (!H->have_inflight && H->prefetched.empty() && H->src_eof) {
             // :456-461 pretend the camera kept its last orientation (once per call while draining)
             if (H->sg) H->sg->add(H->measured);
             break;
