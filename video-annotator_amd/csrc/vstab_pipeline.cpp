@@ -2,7 +2,11 @@
 // look-ahead ring in HBM, consume_frame / pull_frame state machine (FrameSourceWarp.cpp:397-476),
 // plus the stateless tracking / motion entry points.  Host C++; every pixel touches a HIP kernel.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -291,6 +295,72 @@ class Tracker {
     uint32_t seq_ = 0;
 };
 
+// ---------------------------------------------------------------------------------------------
+// EstimateWorker: one helper thread per handle that runs guess_camera_rotation's arithmetic
+// (estimate_rotation: undistortion, RANSAC, LM refit -- pure host code on <= 200 points) while the
+// calling thread issues the next frame's HIP launches.  One job at a time, posted and joined by the
+// calling thread inside the same vstab_pull_frame call, so results are applied in frame order.  The
+// worker spins briefly for the next job (the pipeline posts one every ~60 us) and then sleeps.
+// ---------------------------------------------------------------------------------------------
+class EstimateWorker {
+  public:
+    ~EstimateWorker() {
+        if (th_.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                state_.store(QUIT, std::memory_order_release);
+            }
+            cv_.notify_one();
+            th_.join();
+        }
+    }
+    void post(const float *prev, const float *cur, int n, const Mat3 *Kin, const Mat3 *Kout, Pcg32 *rng) {
+        if (!th_.joinable()) th_ = std::thread([this] { run(); });
+        prev_ = prev, cur_ = cur, n_ = n, Kin_ = Kin, Kout_ = Kout, rng_ = rng;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            state_.store(POSTED, std::memory_order_release);
+        }
+        cv_.notify_one();
+    }
+    int join(Mat3 &R) {  // blocks until the posted job is done
+        while (state_.load(std::memory_order_acquire) != DONE) __builtin_ia32_pause();
+        state_.store(IDLE, std::memory_order_relaxed);
+        R = R_;
+        return inliers_;
+    }
+
+  private:
+    enum { IDLE = 0, POSTED = 1, DONE = 2, QUIT = 3 };
+    void run() {
+        for (;;) {
+            int st = state_.load(std::memory_order_acquire);
+            for (int spins = 0; st != POSTED && st != QUIT && spins < 20000; spins++) {
+                __builtin_ia32_pause();
+                st = state_.load(std::memory_order_acquire);
+            }
+            if (st != POSTED && st != QUIT) {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [this] { const int s = state_.load(std::memory_order_acquire); return s == POSTED || s == QUIT; });
+                st = state_.load(std::memory_order_acquire);
+            }
+            if (st == QUIT) return;
+            inliers_ = estimate_rotation(prev_, cur_, n_, *Kin_, *Kout_, *rng_, R_);
+            state_.store(DONE, std::memory_order_release);
+        }
+    }
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::atomic<int> state_{IDLE};
+    const float *prev_ = nullptr, *cur_ = nullptr;
+    int n_ = 0;
+    const Mat3 *Kin_ = nullptr, *Kout_ = nullptr;
+    Pcg32 *rng_ = nullptr;
+    Mat3 R_;
+    int inliers_ = 0;
+};
+
 }  // namespace vstab
 
 using namespace vstab;
@@ -322,6 +392,9 @@ struct vstab_handle {
     int last_slot = -1;  // m_last_input_frame
     int last_ingest_slot = -1;
     int last_warp_slot = -1;
+    EstimateWorker worker;            // runs estimate_rotation beside the launch calls of the next frame
+    bool estimate_posted = false;
+    bool threaded_estimate = true;    // VSTAB_THREADED_ESTIMATE=0: estimate on the calling thread
     bool speculate = true;            // VSTAB_SPECULATE=0 disables speculative corner detection
     bool serialize_prefetch = false;  // VSTAB_SERIALIZE_PREFETCH=1: start copy+pyramid only after the last warp (measured slower)
     int cur_pyr = 0;     // pyramid set holding the last tracked frame's pyramid (frame index mod 3)
@@ -579,6 +652,14 @@ static vstab_status finish_wait(vstab_handle *H) {
     return VSTAB_OK;
 }
 
+// start the rotation estimate of the ready frame on the worker thread (:429-431)
+static void post_estimate(vstab_handle *H) {
+    if (!H->have_ready || H->estimate_posted || !H->threaded_estimate) return;
+    vstab_handle::Tracked &T = H->ready;
+    H->worker.post(T.pp.data(), T.cp.data(), T.lg.n_tracked, &H->Kin, &H->Kout, &H->rng);
+    H->estimate_posted = true;
+}
+
 static void finish_estimate(vstab_handle *H) {
     if (!H->have_ready) return;
     vstab_handle::Tracked &T = H->ready;
@@ -587,8 +668,11 @@ static void finish_estimate(vstab_handle *H) {
     Mat3 R;
     int inl;
     {
-        HostStage hs(&H->prof.host_estimate_ms);
-        inl = estimate_rotation(T.pp.data(), T.cp.data(), lg.n_tracked, H->Kin, H->Kout, H->rng, R);
+        HostStage hs(&H->prof.host_estimate_ms);  // threaded: only the time the caller still had to wait
+        if (H->estimate_posted)
+            inl = H->worker.join(R), H->estimate_posted = false;
+        else
+            inl = estimate_rotation(T.pp.data(), T.cp.data(), lg.n_tracked, H->Kin, H->Kout, H->rng, R);
     }
     lg.n_inliers = inl;
     if (inl < 40) {
@@ -625,6 +709,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     H->rng = Pcg32(cfg->seed);
     if (const char *e = getenv("VSTAB_SERIALIZE_PREFETCH")) H->serialize_prefetch = atoi(e) != 0;
     if (const char *e = getenv("VSTAB_SPECULATE")) H->speculate = atoi(e) != 0;
+    if (const char *e = getenv("VSTAB_THREADED_ESTIMATE")) H->threaded_estimate = atoi(e) != 0;
     H->stream = static_cast<hipStream_t>(cfg->stream);  // NULL = the default stream, as for the stateless operators
     {
         // the tracking chain is the per-frame critical path; the warp only has to finish before the
@@ -674,16 +759,22 @@ vstab_status vstab_get_output_info(const vstab_handle *h, int *width, int *heigh
 vstab_status vstab_pull_frame(vstab_handle *H, void *dst, size_t pitch_dst) {
     if (!H || !dst) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: null argument");
     while (H->queue.size() <= (size_t)H->cfg.smooth_radius) {  // :453
-        // 1. read ahead: pull + copy + pyramid of the next frame overlap the LK kernel still in flight
+        // 1. LK results of the frame in flight -> surviving corners; its rotation estimate starts on the
+        //    worker thread right away
+        if (H->have_inflight) VSTAB_TRY(finish_wait(H));
+        post_estimate(H);
+        // 2. key-frame rule + LK launch for the oldest prefetched frame (the GPU's critical path)
+        if (H->prefetched.empty() && !H->src_eof) {
+            const vstab_status st = prefetch_next(H);
+            if (st != VSTAB_OK && st != VSTAB_EOF) return st;
+        }
+        if (!H->prefetched.empty() && !H->have_inflight) VSTAB_TRY(launch_tracking(H));
+        // 3. read ahead: pull + copy + pyramid of the following frames (prefetch stream)
         while ((int)H->prefetched.size() < PREFETCH_DEPTH && !H->src_eof) {
             const vstab_status st = prefetch_next(H);
             if (st != VSTAB_OK && st != VSTAB_EOF) return st;
         }
-        // 2. LK results of the frame in flight -> surviving corners
-        if (H->have_inflight) VSTAB_TRY(finish_wait(H));
-        // 3. key-frame rule + LK launch for the prefetched frame (GPU), then
-        if (!H->prefetched.empty() && !H->have_inflight) VSTAB_TRY(launch_tracking(H));
-        // 4. ... the host estimates the rotation of the frame whose tracks just arrived meanwhile
+        // 4. collect the rotation estimate (it ran beside steps 2-3) and queue the frame
         if (H->have_ready) {
             finish_estimate(H);
             continue;
@@ -748,7 +839,11 @@ vstab_status vstab_get_profile(vstab_handle *h, vstab_profile *out) {
 
 void vstab_destroy(vstab_handle *h) {
     if (!h) return;
-    h->fold_pending();  // drains both streams
+    if (h->estimate_posted) {
+        Mat3 r;
+        (void)h->worker.join(r);
+    }
+    h->fold_pending();  // drains the streams
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     for (auto &s : h->slots) {
         if (s.ingested) (void)hipEventDestroy(s.ingested);
