@@ -225,3 +225,26 @@ def test_profile_counts_and_stage_times(vs, cuda, clip):
     assert n == 11 and p["frames_emitted"] == 11 and p["frames_consumed"] == 12 and p["warp_launches"] == 11
     assert p["gpu_warp_ms"] > 0 and p["gpu_lk_ms"] > 0 and p["gpu_pyramid_ms"] > 0 and p["host_estimate_ms"] > 0
     assert p["key_frames"] >= 1
+
+
+def test_pipeline_at_1080p_baseline_config(vs, cuda):
+    """BASELINE config 2 geometry (1920x1080, WIDE169_MEASURED -> 1759x998): a short clip through the whole
+    pipeline, every emitted frame bit-exact against the oracle warp with the product's rotation, rotations
+    close to ground truth, decisions equal to the oracle state machine."""
+    w, h, r, n = 1920, 1080, 2, 6
+    K = oracle.get_preset_camera(4, w, h)
+    frames, rots = synth.shaky_clip(7, K, w, h, n, sigma=0.003)
+    stab, outs = run_product(vs, cuda, frames, smooth_radius=r, seed=2)
+    Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
+    assert (cw, ch) == (1759, 998) and stab.out_size == (cw, ch) and len(outs) == n - 1
+    log = stab.frame_log()
+    for k, lg in enumerate(log, start=1):
+        assert lg["inliers"] >= 40
+        assert oracle.rotation_angle(lg["R"] @ (rots[k] @ rots[k - 1].T).T) < 3e-3
+    # the same tracking decisions as the oracle (bit-exact detector + tracker at this size)
+    corners = oracle.good_features(np.ascontiguousarray(frames[0][:h]))
+    nxt, st = oracle.pyr_lk(frames[0][:h], frames[1][:h], corners)
+    assert log[0]["n_corners"] == len(corners) and log[0]["n_tracked"] == int((st > 0).sum())
+    for i in range(n - 1):
+        p = oracle.map_params(K, Ko, stab.warp_rotation(i))
+        assert np.array_equal(outs[i], oracle.warp_nv12(frames[i + 1], p, cw, ch)), i
