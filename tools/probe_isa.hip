@@ -42,6 +42,16 @@ __device__ __forceinline__ float sqrt_fast(float x) {
     s = ru > 0.0f ? su : s;
     return s;
 }
+// rsq-based correctly rounded sqrt (LLVM's expansion for the flush-denormal mode)
+__device__ __forceinline__ float sqrt_rsq(float x) {
+    float y = __builtin_amdgcn_rsqf(x);
+    float g = x * y, h = 0.5f * y;
+    float e = __builtin_fmaf(-h, g, 0.5f);
+    h = __builtin_fmaf(h, e, h);
+    g = __builtin_fmaf(g, e, g);
+    float d = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(d, h, g);
+}
 __global__ void k_div(const float *n, const float *d, int count, unsigned long long *bad) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -52,6 +62,8 @@ __global__ void k_div(const float *n, const float *d, int count, unsigned long l
     float x = fabsf(n[i]);
     float sr = sqrtf(x), sf = sqrt_fast(x);
     if (__float_as_uint(sr) != __float_as_uint(sf)) atomicAdd(&bad[2], 1ull);
+    float sq = sqrt_rsq(x);
+    if (__float_as_uint(sr) != __float_as_uint(sq) && x != 0.0f) atomicAdd(&bad[4], 1ull);
     float rr = 1.0f / d[i], rf = div_fast(1.0f, d[i]);
     if (__float_as_uint(rr) != __float_as_uint(rf) && !(rr != rr && rf != rf)) atomicAdd(&bad[3], 1ull);
 }
@@ -84,11 +96,11 @@ int main() {
         hn[i] = mode == 0 ? (u * 8 - 4) : mode == 1 ? (u - 0.5f) * 1e-3f : mode == 2 ? u * 20 : (u - 0.5f) * 200;
         hd[i] = mode == 0 ? (v * 2 + 0.05f) : mode == 1 ? v + 0.1f : mode == 2 ? (v * 6 + 1e-3f) : (v - 0.5f) * 3;
     }
-    float *dn, *dd; unsigned long long *bad, hbad[4];
-    hipMalloc(&dn, M * 4); hipMalloc(&dd, M * 4); hipMalloc(&bad, 32); hipMemset(bad, 0, 32);
+    float *dn, *dd; unsigned long long *bad, hbad[5];
+    hipMalloc(&dn, M * 4); hipMalloc(&dd, M * 4); hipMalloc(&bad, 40); hipMemset(bad, 0, 40);
     hipMemcpy(dn, hn, M * 4, hipMemcpyHostToDevice); hipMemcpy(dd, hd, M * 4, hipMemcpyHostToDevice);
     k_div<<<M / 256, 256>>>(dn, dd, M, bad);
-    hipMemcpy(hbad, bad, 32, hipMemcpyDeviceToHost);
-    printf("of %d: div 2-step mismatches %llu, div 1-step mismatches %llu, sqrt mismatches %llu, rcp mismatches %llu\n", M, hbad[0], hbad[1], hbad[2], hbad[3]);
+    hipMemcpy(hbad, bad, 40, hipMemcpyDeviceToHost);
+    printf("of %d: div 2-step mismatches %llu, div 1-step mismatches %llu, sqrt mismatches %llu, rcp mismatches %llu, rsq-sqrt mismatches %llu\n", M, hbad[0], hbad[1], hbad[2], hbad[3], hbad[4]);
     return 0;
 }

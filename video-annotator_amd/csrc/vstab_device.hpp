@@ -91,13 +91,17 @@ __device__ __forceinline__ float div_with_rcp(float n, float d, float r) {
     e = __builtin_fmaf(-d, q, n);
     return __builtin_fmaf(e, r, q);
 }
-// correctly rounded sqrt: v_sqrt_f32 (1 ulp) then pick among the three neighbours by residual sign
+// correctly rounded sqrt: v_rsq_f32 seed, one coupled Newton step for sqrt and 1/(2 sqrt), one residual
+// correction (LLVM's AMDGPU expansion of fsqrt for normal inputs; all plain FMAs).  x = 0 or inf give
+// NaN here instead of 0 / inf -- both can only occur on a degenerate ray whose pixel is black either way.
 __device__ __forceinline__ float sqrt_rn(float x) {
-    float s = __builtin_amdgcn_sqrtf(x);
-    const float sd = __int_as_float(__float_as_int(s) - 1), su = __int_as_float(__float_as_int(s) + 1);
-    const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
-    s = rd <= 0.0f ? sd : s;
-    return ru > 0.0f ? su : s;
+    const float y = __builtin_amdgcn_rsqf(x);
+    float g = x * y, h = 0.5f * y;
+    const float e = __builtin_fmaf(-h, g, 0.5f);
+    h = __builtin_fmaf(h, e, h);
+    g = __builtin_fmaf(g, e, g);
+    const float d = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(d, h, g);
 }
 
 // createMap.cl:13-50 with the primitives above; returns 32*map (exact power-of-two scaling folded
