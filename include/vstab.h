@@ -110,6 +110,35 @@ VSTAB_API vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const 
                                            const float params[17], void *dst_bgr, size_t pitch_dst,
                                            int dst_width, int dst_height, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * the camera surface of the CLI's libdewobble filter (render.ts:611-617,
+ * 669-683, 711-717: in_p / out_p in {fish, rect}) and NV12 output for the encoder hand-off
+ * (render.ts:275-281).  libdewobble is not part of the reference tree: these modes are defined by this
+ * library and have no reference output to compare with.
+ * ------------------------------------------------------------------------------------------ */
+typedef enum vstab_map_mode {
+    VSTAB_MAP_CREATEMAP_CL = 0, /* the reference kernel, quirks included (0/0 on the axis, mirrored rays behind the camera) */
+    VSTAB_MAP_FISH_TO_RECT = 1, /* fisheye input -> pinhole output: createMap.cl's arithmetic without those two quirks */
+    VSTAB_MAP_FISH_TO_FISH = 2,
+    VSTAB_MAP_RECT_TO_RECT = 3,
+    VSTAB_MAP_RECT_TO_FISH = 4
+} vstab_map_mode;
+typedef enum vstab_out_format {
+    VSTAB_OUT_BGR8 = 0, /* what FrameSourceWarp emits (FrameSourceWarp.cpp:313) */
+    VSTAB_OUT_NV12 = 1  /* BGR result converted with cvtColor(COLOR_BGR2YUV_I420) arithmetic, chroma interleaved */
+} vstab_out_format;
+/* vstab_create_map with a projection pair.  params as for vstab_create_map (focal lengths in pixels). */
+VSTAB_API vstab_status vstab_create_map_ex(void *map_x, size_t pitch_x, void *map_y, size_t pitch_y,
+                                           int cols, int rows, const float params[17], int map_mode,
+                                           void *stream);
+/* vstab_warp_nv12_bgr with a projection pair and an output format.  VSTAB_OUT_NV12: dst is the luma plane
+ * (width bytes per row), dst_uv the interleaved chroma plane (ceil(height/2) rows of 2*ceil(width/2) bytes);
+ * dst_uv is ignored for VSTAB_OUT_BGR8. */
+VSTAB_API vstab_status vstab_warp_nv12_ex(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv,
+                                          int src_width, int src_height, const float params[17], int map_mode,
+                                          int out_format, void *dst, size_t pitch_dst, void *dst_uv,
+                                          size_t pitch_dst_uv, int dst_width, int dst_height, void *stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Tracking front-end (device images in; small point lists on the host, as in the reference where
@@ -188,7 +217,16 @@ typedef struct vstab_source {
     void *user;
 } vstab_source;
 
-enum { VSTAB_SMOOTHER_SG = 0, VSTAB_SMOOTHER_KALMAN = 1, VSTAB_SMOOTHER_NONE = 2 };
+/* SG = the reference (gram_sg, FrameSourceWarp.cpp:212); NONE = no correction (libdewobble stab=none with tracking on);
+ * FIXED = hold the first frame's orientation (libdewobble stab=fixed, render.ts:676); KALMAN = opencv/kalman constants. */
+enum { VSTAB_SMOOTHER_SG = 0, VSTAB_SMOOTHER_KALMAN = 1, VSTAB_SMOOTHER_NONE = 2, VSTAB_SMOOTHER_FIXED = 3 };
+
+/* Lens description of the CLI's libdewobble filter (render.ts:611-617,669-683): projection + diagonal field of view. */
+typedef enum vstab_projection { VSTAB_PROJ_RECT = 0, VSTAB_PROJ_FISH = 1 } vstab_projection;
+/* Camera matrix of such a lens: f = (d/2)/tan(dfov/2) (rect) or (d/2)/(dfov/2) (fish, equidistant), d = the image
+ * diagonal in pixels; principal point (cx, cy), negative = the image centre (width/2, height/2) as render.ts:682-683. */
+VSTAB_API vstab_status vstab_lens_camera(int projection, double dfov_deg, int width, int height, double cx,
+                                         double cy, double K[9]);
 
 /* Constructor arguments of FrameSourceWarp (FrameSourceWarp.hpp:83-91) plus what the reference
  * hard-codes.  vstab_config_default fills the reference's defaults. */
@@ -204,6 +242,17 @@ typedef struct vstab_config {
     uint64_t seed;       /* PCG32 seed replacing the reference's un-seeded rand() */
     void *stream;        /* hipStream_t the warp (and so dst) is enqueued on; NULL = default stream.  Ingest and
                             tracking run on an internal stream that overlaps it; ordering is by events. */
+    /* libdewobble-style lens surface.  lens_mode 0 (default) = the reference's preset cameras
+     * and createMap.cl; 1 = the fields below replace preset / scale / crop_borders / zoom. */
+    int lens_mode;
+    int in_projection;   /* in_p: vstab_projection */
+    int out_projection;  /* out_p */
+    double in_dfov;      /* in_dfov, degrees, (0, 360) for fish and (0, 180) for rect */
+    double out_dfov;     /* out_dfov; 0 = in_dfov (render.ts:673) */
+    int out_width;       /* out_w; 0 = input width (render.ts:678) */
+    int out_height;      /* out_h; 0 = input height */
+    double out_cx;       /* out_fx "focal point"; negative = out_width / 2 (render.ts:682) */
+    double out_cy;       /* out_fy; negative = out_height / 2 */
 } vstab_config;
 
 typedef struct vstab_handle vstab_handle;
@@ -222,6 +271,11 @@ VSTAB_API vstab_status vstab_get_output_info(const vstab_handle *h, int *width, 
  * Read-ahead: to overlap copy, pyramid and tracking with the host work, the library pulls upstream up
  * to three frames earlier than the reference's loop would (same frames, same order, same outputs). */
 VSTAB_API vstab_status vstab_pull_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
+/* pull_frame with NV12 output for the encoder hand-off (render.ts:275-281): the same frame,
+ * converted as vstab_warp_nv12_ex(VSTAB_OUT_NV12) defines.  dst_y: width bytes per row; dst_uv: ceil(height/2) rows
+ * of 2*ceil(width/2) bytes.  BGR and NV12 pulls may be mixed freely on one handle. */
+VSTAB_API vstab_status vstab_pull_frame_nv12(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv,
+                                             size_t pitch_uv);
 /* FrameSourceWarp::peek_frame (:478-480) IS pull_frame in the reference (destructive); kept. */
 VSTAB_API vstab_status vstab_peek_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
 VSTAB_API void vstab_destroy(vstab_handle *h);

@@ -56,6 +56,10 @@ def lib():
         L.vo_create_map.argtypes = [f32p, f32p, c.c_int, c.c_int, f32p]
         L.vo_remap_bilinear.argtypes = [u8p, c.c_int, c.c_int, c.c_int, f32p, f32p, u8p, c.c_int, c.c_int]
         L.vo_warp_nv12_reference_path.argtypes = [u8p, c.c_int, c.c_int, f32p, u8p, c.c_int, c.c_int, u8p]
+        L.vo_sincosf_array.argtypes = [f32p, f32p, f32p, c.c_long]
+        L.vo_create_map_ex.argtypes = [f32p, f32p, c.c_int, c.c_int, f32p, c.c_int]
+        L.vo_cvt_bgr_nv12.argtypes = [u8p, c.c_int, c.c_int, u8p, u8p]
+        L.vo_warp_nv12_ex.argtypes = [u8p, c.c_int, c.c_int, f32p, c.c_int, c.c_int, u8p, c.c_int, c.c_int, u8p]
         L.vo_min_eig.argtypes = [u8p, c.c_size_t, c.c_int, c.c_int, f32p]
         L.vo_good_features.argtypes = [u8p, c.c_size_t, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, f32p, f32p]
         L.vo_good_features.restype = c.c_int
@@ -177,6 +181,51 @@ def warp_nv12(nv12, params, dw, dh):
     work = np.empty(w * h * 3 + 16 + 2 * dw * dh * 4, np.uint8)
     lib().vo_warp_nv12_reference_path(ap, w, h, pp, _p(out, ctypes.c_uint8), dw, dh, _p(work, ctypes.c_uint8))
     return out
+
+
+def sincosf(t):
+    """sin, cos on [0, pi] as the generalised map defines them (vo_sincosf_pos)."""
+    t, tp = _f32(t)
+    sn, cs = np.empty_like(t), np.empty_like(t)
+    lib().vo_sincosf_array(tp, _p(sn, ctypes.c_float), _p(cs, ctypes.c_float), t.size)
+    return sn, cs
+
+
+MAP_CREATEMAP_CL, MAP_FISH_TO_RECT, MAP_FISH_TO_FISH, MAP_RECT_TO_RECT, MAP_RECT_TO_FISH = range(5)
+
+
+def create_map_ex(params, cols, rows, mode):
+    """Generalised map; mode 0 = createMap.cl."""
+    p, pp = _f32(params)
+    mx = np.empty((rows, cols), np.float32)
+    my = np.empty((rows, cols), np.float32)
+    lib().vo_create_map_ex(_p(mx, ctypes.c_float), _p(my, ctypes.c_float), cols, rows, pp, int(mode))
+    return mx, my
+
+
+def cvt_bgr_nv12(bgr):
+    """OpenCV BGR -> YUV 4:2:0 arithmetic with NV12 chroma layout.  -> (y (h,w), uv (ceil(h/2), ceil(w/2), 2))."""
+    b, bp = _u8(bgr)
+    h, w = b.shape[:2]
+    y = np.empty((h, w), np.uint8)
+    uv = np.empty(((h + 1) // 2, (w + 1) // 2, 2), np.uint8)
+    lib().vo_cvt_bgr_nv12(bp, w, h, _p(y, ctypes.c_uint8), _p(uv, ctypes.c_uint8))
+    return y, uv
+
+
+def warp_nv12_ex(nv12, params, dw, dh, mode=0, out_format=0):
+    """Generalised warp chain.  out_format 0 -> (dh, dw, 3) BGR; 1 -> (y, uv) as cvt_bgr_nv12."""
+    rows, w = nv12.shape
+    h = rows * 2 // 3
+    a, ap = _u8(nv12)
+    p, pp = _f32(params)
+    cw, ch = (dw + 1) // 2, (dh + 1) // 2
+    out = np.empty(dw * dh * 3 if out_format == 0 else dw * dh + 2 * cw * ch, np.uint8)
+    work = np.empty(w * h * 3 + 16 + 2 * dw * dh * 4 + dw * dh * 3, np.uint8)
+    lib().vo_warp_nv12_ex(ap, w, h, pp, int(mode), int(out_format), _p(out, ctypes.c_uint8), dw, dh, _p(work, ctypes.c_uint8))
+    if out_format == 0:
+        return out.reshape(dh, dw, 3)
+    return out[: dw * dh].reshape(dh, dw), out[dw * dh:].reshape(ch, cw, 2)
 
 
 def min_eig(gray):

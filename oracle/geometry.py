@@ -57,6 +57,30 @@ def get_preset_camera(preset, width, height):
     return K
 
 
+PROJ_RECT, PROJ_FISH = 0, 1
+
+
+def lens_camera(projection, dfov_deg, width, height, cx=None, cy=None):
+    """Camera matrix of a libdewobble-style lens (render.ts:611-617,669-683): projection + diagonal field of
+    view; principal point defaults to (width/2, height/2) (render.ts:682-683).  Defined by this project
+    (libdewobble is not in the reference tree)."""
+    half_diag = 0.5 * math.hypot(width, height)
+    half_fov = 0.5 * math.radians(dfov_deg)
+    f = half_diag / math.tan(half_fov) if projection == PROJ_RECT else half_diag / half_fov
+    K = np.eye(3)
+    K[0, 0] = K[1, 1] = f
+    K[0, 2] = width / 2 if cx is None else cx
+    K[1, 2] = height / 2 if cy is None else cy
+    return K
+
+
+def map_mode(in_projection, out_projection):
+    """vstab_map_mode of a projection pair: 1 fish->rect, 2 fish->fish, 3 rect->rect, 4 rect->fish."""
+    if in_projection == PROJ_FISH:
+        return 2 if out_projection == PROJ_FISH else 1
+    return 4 if out_projection == PROJ_FISH else 3
+
+
 def fisheye_undistort_points(pts, K, R=None, P=None):
     """cv::fisheye::undistortPoints with D = 0 (calls at FrameSourceWarp.cpp:93,322,333).
 

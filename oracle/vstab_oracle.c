@@ -232,6 +232,141 @@ VO_API void vo_warp_nv12_reference_path(const uint8_t *nv12, int w, int h, const
 }
 
 /* ------------------------------------------------------------------------------------------
+ * f1: the libdewobble-style camera surface the CLI drives
+ * (render.ts:611-617, 669-683, 711-717): in_p / out_p in {fish, rect}.  libdewobble itself is
+ * NOT in the reference tree (third-party ffmpeg filter, unpinned), so this map has no reference
+ * output to pin against -- "parity unpinned": the arithmetic is DEFINED here, chosen so that
+ * mode fish->rect performs exactly the createMap.cl operations wherever those are well defined,
+ * and differs from createMap.cl only in the two degenerate cases it mishandles:
+ *   - the ray that hits the optical axis (radius 0): createMap.cl divides 0/0 and blacks the
+ *     pixel out; here the correction factor is 1 (its limit);
+ *   - rays behind the camera (w.z <= 0): createMap.cl mirrors them; here they are outside.
+ * Modes: 1 fish->rect, 2 fish->fish, 3 rect->rect, 4 rect->fish (input -> output projection);
+ * fish = equidistant (r = f*theta), rect = pinhole (r = f*tan(theta)).
+ * ------------------------------------------------------------------------------------------ */
+#define VO_PI_F 3.1415927410125732421875f
+#define VO_TWO_OVER_PI 0.636619746685028076171875f
+
+/* sin and cos of t in [0, pi]: quadrant k = rint(t*2/pi), r = t - k*pi/2 (two-constant Cody-Waite
+ * with fmaf), degree-7 / degree-8 polynomials on |r| <= pi/4 (Cephes single-precision
+ * coefficients), then the quadrant symmetry.  Built from IEEE operations and fmaf only, so a GPU
+ * kernel can match it bit for bit. */
+VO_API void vo_sincosf_pos(float t, float *sn, float *cs) {
+    float k = rintf(t * VO_TWO_OVER_PI);
+    float r = fmaf(k, -VO_PIO2_HI, t);
+    r = fmaf(k, -VO_PIO2_LO, r);
+    float z = r * r;
+    float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    float s = fmaf(r * z, ps, r);
+    float c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+    if (k == 1.0f) *sn = c, *cs = -s;
+    else if (k == 2.0f) *sn = -s, *cs = -c;
+    else *sn = s, *cs = c;
+}
+
+VO_API void vo_sincosf_array(const float *t, float *sn, float *cs, long n) {
+    for (long i = 0; i < n; i++) vo_sincosf_pos(t[i], sn + i, cs + i);
+}
+
+static inline void vo_map_pixel_ex(int x, int y, const float *p, int mode, float *mx, float *my) {
+    const int out_fish = mode == 2 || mode == 4, in_fish = mode == 1 || mode == 2;
+    float vx = ((float)x - p[4]) / p[6];
+    float vy = ((float)y - p[5]) / p[7];
+    float rx = vx, ry = vy, rz = 1.0f;
+    *mx = *my = NAN;
+    if (out_fish) {
+        float rho = sqrtf(vx * vx + vy * vy); /* = theta of the output ray */
+        if (!(rho < VO_PI_F)) return;
+        float sn, cs;
+        vo_sincosf_pos(rho, &sn, &cs);
+        float s = rho == 0.0f ? 1.0f : sn / rho;
+        rx = vx * s, ry = vy * s, rz = cs;
+    }
+    float wx = (p[8] * rx + p[9] * ry) + p[10] * rz;
+    float wy = (p[11] * rx + p[12] * ry) + p[13] * rz;
+    float wz = (p[14] * rx + p[15] * ry) + p[16] * rz;
+    if (!(wz > 0.0f)) return;
+    float cx = wx / wz, cy = wy / wz;
+    if (in_fish) {
+        float r = sqrtf(cx * cx + cy * cy);
+        float k = r == 0.0f ? 1.0f : vo_atanf(r) / r;
+        *mx = p[0] + (cx * k) * p[2];
+        *my = p[1] + (cy * k) * p[3];
+    } else {
+        *mx = p[0] + cx * p[2];
+        *my = p[1] + cy * p[3];
+    }
+}
+
+/* mode 0 = createMap.cl (vo_create_map); 1..4 as above */
+VO_API void vo_create_map_ex(float *mapx, float *mapy, int cols, int rows, const float *p, int mode) {
+    if (mode == 0) {
+        vo_create_map(mapx, mapy, cols, rows, p);
+        return;
+    }
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++)
+            vo_map_pixel_ex(x, y, p, mode, mapx + (size_t)y * cols + x, mapy + (size_t)y * cols + x);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * f2: NV12 output for the encoder hand-off (render.ts:275-281).
+ * The reference's C++ path stops at BGR; the conversion is DEFINED as OpenCV 4.5's
+ * cvtColor(COLOR_BGR2YUV_I420) arithmetic (imgproc color_yuv, RGB8toYUV420pInvoker: BT.601
+ * limited range, 20-bit fixed point, chroma taken from the top-left pixel of each 2x2 block, no
+ * averaging) with U and V interleaved as NV12.  Odd sizes: chroma planes are ceil(w/2) x
+ * ceil(h/2) (every 2x2 block's top-left pixel exists).  y: w x h, uv: 2*ceil(w/2) x ceil(h/2).
+ * ------------------------------------------------------------------------------------------ */
+#define VO_CRY 269484
+#define VO_CGY 528482
+#define VO_CBY 102760
+#define VO_CRU (-155188)
+#define VO_CGU (-305135)
+#define VO_CBU 460324
+#define VO_CGV (-385875)
+#define VO_CBV (-74448)
+
+VO_API void vo_cvt_bgr_nv12(const uint8_t *bgr, int w, int h, uint8_t *yp, uint8_t *uvp) {
+    const int half = 1 << 19, s16 = 16 << 20, s128 = 128 << 20;
+    const int cw = (w + 1) / 2;
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < h; r++) {
+        const uint8_t *row = bgr + (size_t)r * w * 3;
+        for (int c = 0; c < w; c++) {
+            int B = row[3 * c], G = row[3 * c + 1], R = row[3 * c + 2];
+            yp[(size_t)r * w + c] = vo_sat8((VO_CRY * R + VO_CGY * G + VO_CBY * B + half + s16) >> 20);
+            if (!(r & 1) && !(c & 1)) {
+                uint8_t *o = uvp + ((size_t)(r >> 1) * cw + (c >> 1)) * 2;
+                o[0] = vo_sat8((VO_CRU * R + VO_CGU * G + VO_CBU * B + half + s128) >> 20);
+                o[1] = vo_sat8((VO_CBU * R + VO_CGV * G + VO_CBV * B + half + s128) >> 20);
+            }
+        }
+    }
+}
+
+/* the generalised warp as a reference-style chain: cvtColor, map planes (mode), remap,
+ * optional BGR -> NV12.  out_format 0: dst = BGR (dw*dh*3); 1: dst = Y plane then the
+ * interleaved chroma plane (dw*dh + 2*ceil(dw/2)*ceil(dh/2) bytes).  work as for
+ * vo_warp_nv12_reference_path plus dw*dh*3 bytes when out_format = 1. */
+VO_API void vo_warp_nv12_ex(const uint8_t *nv12, int w, int h, const float *p, int mode, int out_format,
+                            uint8_t *dst, int dw, int dh, uint8_t *work) {
+    uint8_t *bgr = work;
+    float *mapx = (float *)(work + (((size_t)w * h * 3 + 15) & ~(size_t)15));
+    float *mapy = mapx + (size_t)dw * dh;
+    uint8_t *tmp = (uint8_t *)(mapy + (size_t)dw * dh);
+    vo_cvt_nv12_bgr(nv12, w, h, bgr);
+    vo_create_map_ex(mapx, mapy, dw, dh, p, mode);
+    if (out_format == 0) {
+        vo_remap_bilinear(bgr, w, h, 3, mapx, mapy, dst, dw, dh);
+    } else {
+        vo_remap_bilinear(bgr, w, h, 3, mapx, mapy, tmp, dw, dh);
+        vo_cvt_bgr_nv12(tmp, dw, dh, dst, dst + (size_t)dw * dh);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * a3: goodFeaturesToTrack(gray, 200, 0.01, 30), call site FrameSourceWarp.cpp:230.
  * Third-party arithmetic (OpenCV 4.5 imgproc featureselect/corner, CPU path).
  * ------------------------------------------------------------------------------------------ */

@@ -71,6 +71,13 @@ def fisheye_rays(K, w, h):
     return np.stack([px * s, py * s, np.cos(th)], axis=-1)
 
 
+def pinhole_rays(K, w, h):
+    """Unit rays of every pixel of a pinhole camera."""
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    d = np.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], np.ones((h, w))], axis=-1)
+    return d / np.linalg.norm(d, axis=-1, keepdims=True)
+
+
 def fisheye_project(K, rays):
     """Inverse of fisheye_rays for arbitrary rays (n,3) -> pixels (n,2)."""
     x, y, z = rays[:, 0], rays[:, 1], rays[:, 2]
@@ -94,12 +101,12 @@ def render_frame(tex, rays, R):
     return np.clip(np.rint(val), 0, 255).astype(np.uint8)
 
 
-def shaky_clip(seed, K, w, h, n, sigma=0.004):
+def shaky_clip(seed, K, w, h, n, sigma=0.004, projection="fish"):
     """n packed NV12 frames + the camera orientations R_k (random walk, sigma rad/frame/axis)."""
     import oracle
     rng = np.random.default_rng(seed)
     tex = sphere_texture(seed)
-    rays = fisheye_rays(K, w, h)
+    rays = fisheye_rays(K, w, h) if projection == "fish" else pinhole_rays(K, w, h)
     R = np.eye(3)
     frames, rots = [], []
     for k in range(n):

@@ -53,7 +53,9 @@ class Source(_c.Structure):  # vstab_source
 
 class Config(_c.Structure):  # vstab_config
     _fields_ = [("preset", _i), ("scale", _d), ("crop_borders", _i), ("zoom", _d), ("smooth_radius", _i),
-                ("interpolation", _i), ("smoother", _i), ("tracking", _i), ("seed", _u64), ("stream", _vp)]
+                ("interpolation", _i), ("smoother", _i), ("tracking", _i), ("seed", _u64), ("stream", _vp),
+                ("lens_mode", _i), ("in_projection", _i), ("out_projection", _i), ("in_dfov", _d), ("out_dfov", _d),
+                ("out_width", _i), ("out_height", _i), ("out_cx", _d), ("out_cy", _d)]
 
 
 class FrameLog(_c.Structure):  # vstab_frame_log
@@ -68,7 +70,10 @@ class Profile(_c.Structure):  # vstab_profile
                 ("warp_launches", _c.c_long)]
 
 
-SMOOTHER_SG, SMOOTHER_KALMAN, SMOOTHER_NONE = 0, 1, 2
+SMOOTHER_SG, SMOOTHER_KALMAN, SMOOTHER_NONE, SMOOTHER_FIXED = 0, 1, 2, 3
+PROJ_RECT, PROJ_FISH = 0, 1
+MAP_CREATEMAP_CL, MAP_FISH_TO_RECT, MAP_FISH_TO_FISH, MAP_RECT_TO_RECT, MAP_RECT_TO_FISH = range(5)
+OUT_BGR8, OUT_NV12 = 0, 1
 _pp = _c.POINTER(_vp)
 
 # name -> (restype, argtypes); mirrors include/vstab.h one to one
@@ -85,6 +90,8 @@ SIGNATURES = {
     "vstab_create_map": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _vp]),
     "vstab_remap_bilinear": (_i, [_vp, _sz, _i, _i, _i, _vp, _sz, _vp, _sz, _vp, _sz, _i, _i, _vp]),
     "vstab_warp_nv12_bgr": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _vp, _sz, _i, _i, _vp]),
+    "vstab_create_map_ex": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _vp]),
+    "vstab_warp_nv12_ex": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
     "vstab_pyr_down": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp]),
     "vstab_min_eig": (_i, [_vp, _sz, _i, _i, _vp, _vp]),
     "vstab_good_features": (_i, [_vp, _sz, _i, _i, _i, _d, _d, _fp, _ip, _vp]),
@@ -99,6 +106,8 @@ SIGNATURES = {
     "vstab_create": (_i, [_c.POINTER(Config), _c.POINTER(Source), _pp]),
     "vstab_get_output_info": (_i, [_vp, _ip, _ip, _dp, _dp]),
     "vstab_pull_frame": (_i, [_vp, _vp, _sz]),
+    "vstab_pull_frame_nv12": (_i, [_vp, _vp, _sz, _vp, _sz]),
+    "vstab_lens_camera": (_i, [_i, _d, _i, _i, _d, _d, _dp]),
     "vstab_peek_frame": (_i, [_vp, _vp, _sz]),
     "vstab_destroy": (None, [_vp]),
     "vstab_frame_log_count": (_i, [_vp]),
@@ -166,6 +175,12 @@ def get_output_camera(K_in, width, height, scale=1.0, crop_borders=False, zoom=1
     return Ko.reshape(3, 3), (ow.value, oh.value)
 
 
+def lens_camera(projection, dfov_deg, width, height, cx=-1.0, cy=-1.0):
+    K = np.zeros(9)
+    _check(_L.vstab_lens_camera(int(projection), float(dfov_deg), width, height, cx, cy, _dptr(K)), "vstab_lens_camera")
+    return K.reshape(3, 3)
+
+
 def fisheye_undistort_points(pts, K, R=None, P=None):
     p = np.ascontiguousarray(pts, np.float64).reshape(-1, 2)
     Kc = np.ascontiguousarray(K, np.float64).reshape(9)
@@ -219,13 +234,17 @@ def cvt_nv12_bgr(nv12, out=None):
     return out
 
 
-def create_map(params, cols, rows, device="cuda"):
+def create_map(params, cols, rows, device="cuda", mode=MAP_CREATEMAP_CL):
     import torch
     p = np.ascontiguousarray(params, np.float32)
     mx = torch.empty((rows, cols), dtype=torch.float32, device=device)
     my = torch.empty((rows, cols), dtype=torch.float32, device=device)
-    _check(_L.vstab_create_map(mx.data_ptr(), mx.stride(0) * 4, my.data_ptr(), my.stride(0) * 4, cols, rows,
-                               _fptr(p), _stream()), "vstab_create_map")
+    if mode == MAP_CREATEMAP_CL:
+        _check(_L.vstab_create_map(mx.data_ptr(), mx.stride(0) * 4, my.data_ptr(), my.stride(0) * 4, cols, rows,
+                                   _fptr(p), _stream()), "vstab_create_map")
+    else:
+        _check(_L.vstab_create_map_ex(mx.data_ptr(), mx.stride(0) * 4, my.data_ptr(), my.stride(0) * 4, cols, rows,
+                                      _fptr(p), int(mode), _stream()), "vstab_create_map_ex")
     return mx, my
 
 
@@ -251,6 +270,32 @@ def warp_nv12_bgr(nv12, params, dw, dh, out=None):
     _check(_L.vstab_warp_nv12_bgr(yp, pitch, uvp, pitch, w, h, _fptr(p), out.data_ptr(), out.stride(0), dw, dh,
                                   _stream()), "vstab_warp_nv12_bgr")
     return out
+
+
+def nv12_out_planes(dw, dh, device="cuda"):
+    """Output planes for OUT_NV12: luma (dh, dw) and interleaved chroma (ceil(dh/2), 2*ceil(dw/2))."""
+    import torch
+    return (torch.empty((dh, dw), dtype=torch.uint8, device=device),
+            torch.empty(((dh + 1) // 2, 2 * ((dw + 1) // 2)), dtype=torch.uint8, device=device))
+
+
+def warp_nv12(nv12, params, dw, dh, mode=MAP_CREATEMAP_CL, out_format=OUT_BGR8, out=None):
+    """vstab_warp_nv12_ex.  OUT_BGR8 -> (dh, dw, 3) tensor; OUT_NV12 -> (luma, chroma) tensors."""
+    import torch
+    yp, uvp, pitch, w, h = _planes(nv12)
+    p = np.ascontiguousarray(params, np.float32)
+    if out_format == OUT_BGR8:
+        if out is None:
+            out = torch.empty((dh, dw, 3), dtype=torch.uint8, device=nv12.device)
+        _check(_L.vstab_warp_nv12_ex(yp, pitch, uvp, pitch, w, h, _fptr(p), int(mode), OUT_BGR8, out.data_ptr(),
+                                     out.stride(0), None, 0, dw, dh, _stream()), "vstab_warp_nv12_ex")
+        return out
+    if out is None:
+        out = nv12_out_planes(dw, dh, nv12.device)
+    yo, co = out
+    _check(_L.vstab_warp_nv12_ex(yp, pitch, uvp, pitch, w, h, _fptr(p), int(mode), int(out_format), yo.data_ptr(), yo.stride(0),
+                                 co.data_ptr(), co.stride(0), dw, dh, _stream()), "vstab_warp_nv12_ex")
+    return yo, co
 
 
 # ---------------------------------------------------------------------------------------------
@@ -407,6 +452,18 @@ class Stabilizer:
         import torch
         out = torch.empty((self.out_size[1], self.out_size[0], 3), dtype=torch.uint8, device="cuda")
         return out if self.pull_into(out) else None
+
+    def pull_nv12_into(self, y, uv):
+        st = _L.vstab_pull_frame_nv12(self._h, y.data_ptr(), y.stride(0), uv.data_ptr(), uv.stride(0))
+        if st == EOF:
+            return False
+        _check(st, "vstab_pull_frame_nv12")
+        return True
+
+    def pull_nv12(self):
+        """-> (luma, chroma) tensors, or None at end of stream."""
+        y, uv = nv12_out_planes(self.out_size[0], self.out_size[1])
+        return (y, uv) if self.pull_nv12_into(y, uv) else None
 
     def frame_log(self):
         out = []

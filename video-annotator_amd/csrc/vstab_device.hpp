@@ -139,6 +139,95 @@ __device__ __forceinline__ void map_pixel32(const MapParams32 &p, const ColTerm 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Generalised map (the libdewobble option surface in_p / out_p in {fish, rect},
+// render.ts:611-617,669-683,711-717).  libdewobble is not part of the reference tree, so the arithmetic
+// is defined by this project (the test suite holds a plain-C statement of it): mode
+// FISH_TO_RECT performs createMap.cl's operations and differs only where createMap.cl degenerates
+// (axis ray: correction factor 1 instead of 0/0; rays behind the camera: outside instead of mirrored).
+// ---------------------------------------------------------------------------------------------
+enum MapMode { MAP_CREATEMAP_CL = 0, MAP_FISH_TO_RECT = 1, MAP_FISH_TO_FISH = 2, MAP_RECT_TO_RECT = 3, MAP_RECT_TO_FISH = 4 };
+template <int MODE>
+struct ModeTraits {
+    static constexpr bool out_fish = MODE == MAP_FISH_TO_FISH || MODE == MAP_RECT_TO_FISH;
+    static constexpr bool in_fish = MODE == MAP_FISH_TO_RECT || MODE == MAP_FISH_TO_FISH || MODE == MAP_CREATEMAP_CL;
+};
+
+// sin, cos on [0, pi]: quadrant reduction with a two-constant pi/2, Cephes single-precision polynomials
+__device__ __forceinline__ void sincos_pos(float t, float &sn, float &cs) {
+    const float k = __builtin_rintf(t * 0.636619746685028076171875f);
+    float r = __builtin_fmaf(k, -1.57079637050628662109375f, t);
+    r = __builtin_fmaf(k, 4.37113900018624283e-8f, r);
+    const float z = r * r;
+    const float ps = __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    const float pc = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    const float s = __builtin_fmaf(r * z, ps, r);
+    const float c = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+    sn = k == 1.0f ? c : k == 2.0f ? -s : s;
+    cs = k == 1.0f ? -s : k == 2.0f ? -c : c;
+}
+
+// One pixel of the generalised map.  p holds the input camera (scaled by 32 in the fused kernel, unscaled in
+// the map-plane kernel -- the scaling is an exact power of two either way), P the output camera and rotation.
+// c / r are the hoisted column / row products for pinhole output; vx, vy the normalised output coordinates for
+// fisheye output.  Outside (NaN) when the output ray is beyond 180 degrees or lands behind the input camera.
+template <int MODE>
+__device__ __forceinline__ void map_pixel_ex(const MapParams32 &p, const MapParams &P, const ColTerm &c, const RowTerm &r,
+                                             float vx, float vy, float &ax, float &ay) {
+    if constexpr (MODE == MAP_CREATEMAP_CL) {
+        map_pixel32(p, c, r, ax, ay);
+    } else {
+        float wx, wy, wz;
+        bool ok = true;
+        if constexpr (ModeTraits<MODE>::out_fish) {
+            const float q = vx * vx + vy * vy;
+            const bool zero = q == 0.0f;
+            const float rho = sqrt_rn(q);  // NaN when q == 0
+            ok = zero || rho < 3.1415927410125732421875f;
+            float sn, cs;
+            sincos_pos(zero ? 0.0f : rho, sn, cs);
+            const float s = zero ? 1.0f : div_with_rcp(sn, rho, rcp_refined(rho));
+            const float rx = vx * s, ry = vy * s;
+            wx = (P.r[0] * rx + P.r[1] * ry) + P.r[2] * cs;
+            wy = (P.r[3] * rx + P.r[4] * ry) + P.r[5] * cs;
+            wz = (P.r[6] * rx + P.r[7] * ry) + P.r[8] * cs;
+        } else {
+            wx = (c.a0 + r.b0) + p.r02;
+            wy = (c.a1 + r.b1) + p.r12;
+            wz = (c.a2 + r.b2) + p.r22;
+        }
+        ok = ok && wz > 0.0f;
+        const float rz = rcp_refined(wz);
+        const float px = div_with_rcp(wx, wz, rz), py = div_with_rcp(wy, wz, rz);
+        if constexpr (ModeTraits<MODE>::in_fish) {
+            const float q = px * px + py * py;
+            const bool zero = q == 0.0f;
+            const float rad = sqrt_rn(q);
+            const float rr = rcp_refined(rad);
+            const bool inv = rad > 1.0f;
+            const float t = inv ? div_with_rcp(1.0f, rad, rr) : rad;
+            const float s = t * t;
+            float g = 0.0028423243202269077f;
+            g = __builtin_fmaf(g, s, -0.016053270548582077f);
+            g = __builtin_fmaf(g, s, 0.04269874095916748f);
+            g = __builtin_fmaf(g, s, -0.07508683204650879f);
+            g = __builtin_fmaf(g, s, 0.1064559817314148f);
+            g = __builtin_fmaf(g, s, -0.14205896854400635f);
+            g = __builtin_fmaf(g, s, 0.19993145763874054f);
+            g = __builtin_fmaf(g, s, -0.33333125710487366f);
+            float at = __builtin_fmaf(t * s, g, t);
+            at = inv ? (1.57079637050628662109375f - at) + (-4.37113900018624283e-8f) : at;
+            const float k = zero ? 1.0f : div_with_rcp(at, rad, rr);
+            ax = p.icx32 + (px * k) * p.ifx32;
+            ay = p.icy32 + (py * k) * p.ify32;
+        } else {
+            ax = p.icx32 + px * p.ifx32;
+            ay = p.icy32 + py * p.ify32;
+        }
+        if (!ok) ax = ay = __builtin_nanf("");
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // cv::remap coordinate quantisation (OpenCV 4.5 CPU path): sx = cvRound(map*32),
 // X = sx >> 5, f = sx & 31.  cvRound of NaN / out-of-int-range is INT_MIN on x86, which always
 // lands outside the source; `far` reports those cases so the caller writes 0.
@@ -169,6 +258,20 @@ struct ChromaTerm {
 __device__ __forceinline__ ChromaTerm chroma_term(int U, int V) {
     const int u = U - 128, v = V - 128;
     return {(1 << 19) + CVR * v, (1 << 19) + CVG * v + CUG * u, (1 << 19) + CUB * u};
+}
+// OpenCV 4.5 cvtColor(COLOR_BGR2YUV_I420) arithmetic (RGB8toYUV420pInvoker): BT.601 limited range, 20-bit
+// fixed point; chroma from the top-left pixel of each 2x2 block.  No saturation is needed: Y in [16, 235],
+// U / V in [16, 240] for every 8-bit BGR.  v = B | G << 8 | R << 16.
+constexpr int CRY = 269484, CGY = 528482, CBY = 102760, CRU = -155188, CGU = -305135, CBU = 460324, CGV = -385875, CBV = -74448;
+__device__ __forceinline__ uint32_t bgr_to_y(uint32_t v) {
+    const int B = v & 255, G = (v >> 8) & 255, R = (v >> 16) & 255;
+    return (uint32_t)(CRY * R + CGY * G + CBY * B + (1 << 19) + (16 << 20)) >> 20;
+}
+__device__ __forceinline__ uint32_t bgr_to_uv(uint32_t v) {  // U | V << 8
+    const int B = v & 255, G = (v >> 8) & 255, R = (v >> 16) & 255;
+    const uint32_t U = (uint32_t)(CRU * R + CGU * G + CBU * B + (1 << 19) + (128 << 20)) >> 20;
+    const uint32_t V = (uint32_t)(CBU * R + CGV * G + CBV * B + (1 << 19) + (128 << 20)) >> 20;
+    return U | (V << 8);
 }
 __device__ __forceinline__ int sat8(int v) { return min(max(v, 0), 255); }
 

@@ -54,19 +54,39 @@ bool preset_camera(int preset, int w, int h, Mat3 &K) {
 }
 
 // OpenCV 4.5 fisheye::undistortPoints with D = 0: theta_d clipped to pi/2, scale = tan(theta)/theta.
-void fisheye_undistort(const double *pts, int n, const Mat3 &K, const Mat3 &RR, double *out) {
+void fisheye_undistort(const double *pts, int n, const Mat3 &K, const Mat3 &RR, double *out, bool fish) {
     for (int i = 0; i < n; i++) {
         const double pwx = (pts[2 * i] - K(0, 2)) / K(0, 0), pwy = (pts[2 * i + 1] - K(1, 2)) / K(1, 1);
         double theta_d = std::sqrt(pwx * pwx + pwy * pwy);
         theta_d = std::min(std::max(-M_PI / 2., theta_d), M_PI / 2.);
         double scale = 0.0;
         if (std::fabs(theta_d) > 1e-8) scale = std::tan(theta_d) / theta_d;
+        if (!fish) scale = 1.0;
         const double ux = pwx * scale, uy = pwy * scale;
         const double x = RR(0, 0) * ux + RR(0, 1) * uy + RR(0, 2);
         const double y = RR(1, 0) * ux + RR(1, 1) * uy + RR(1, 2);
         const double z = RR(2, 0) * ux + RR(2, 1) * uy + RR(2, 2);
         out[2 * i] = x / z, out[2 * i + 1] = y / z;
     }
+}
+
+bool lens_camera(int projection, double dfov_deg, int w, int h, double cx, double cy, Mat3 &K) {
+    if (w <= 0 || h <= 0 || !(dfov_deg > 0)) return false;
+    const double half_diag = 0.5 * std::sqrt((double)w * w + (double)h * h), half_fov = 0.5 * dfov_deg * M_PI / 180.0;
+    double f;
+    if (projection == VSTAB_PROJ_RECT) {
+        if (!(dfov_deg < 180)) return false;
+        f = half_diag / std::tan(half_fov);
+    } else if (projection == VSTAB_PROJ_FISH) {
+        if (!(dfov_deg < 360)) return false;
+        f = half_diag / half_fov;
+    } else {
+        return false;
+    }
+    K = Mat3::identity();
+    K(0, 0) = K(1, 1) = f;
+    K(0, 2) = cx < 0 ? 0.5 * w : cx, K(1, 2) = cy < 0 ? 0.5 * h : cy;
+    return true;
 }
 
 static int cv_round(double v) { return (int)std::nearbyint(v); }  // round half to even
@@ -137,6 +157,14 @@ vstab_status vstab_get_output_camera(const double K_in[9], int width, int height
     std::memcpy(ki.m, K_in, sizeof(ki.m));
     output_camera(ki, width, height, scale, crop_borders != 0, zoom, ko, *out_width, *out_height);
     std::memcpy(K_out, ko.m, sizeof(ko.m));
+    return VSTAB_OK;
+}
+
+vstab_status vstab_lens_camera(int projection, double dfov_deg, int width, int height, double cx, double cy, double K[9]) {
+    Mat3 k;
+    if (!K || !lens_camera(projection, dfov_deg, width, height, cx, cy, k))
+        return fail(VSTAB_ERR_INVALID, "vstab_lens_camera: bad projection, field of view or size");
+    std::memcpy(K, k.m, sizeof(k.m));
     return VSTAB_OK;
 }
 

@@ -33,7 +33,10 @@ struct Mat3 {
 };
 
 bool preset_camera(int preset, int w, int h, Mat3 &K);
-void fisheye_undistort(const double *pts, int n, const Mat3 &K, const Mat3 &RR, double *out);
+// fish = false: pinhole input, the points are only normalised and rotated
+void fisheye_undistort(const double *pts, int n, const Mat3 &K, const Mat3 &RR, double *out, bool fish = true);
+// camera matrix of a libdewobble-style lens (projection 0 rect / 1 fish, diagonal field of view in degrees)
+bool lens_camera(int projection, double dfov_deg, int w, int h, double cx, double cy, Mat3 &K);
 void output_camera(const Mat3 &Kin, int w, int h, double scale, bool crop, double zoom, Mat3 &Kout, int &ow, int &oh);
 void map_params(const Mat3 &Kin, const Mat3 &Kout, const Mat3 &R, float p[17]);
 

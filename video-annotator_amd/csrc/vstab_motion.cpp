@@ -160,7 +160,8 @@ static int ransac_update_iters(double p, double ep, int model_points, int max_it
     return (denom >= 0 || -num >= max_iters * (-denom)) ? max_iters : (int)std::nearbyint(num / denom);
 }
 
-int estimate_rotation(const float *prev, const float *cur, int n, const Mat3 &Kin, const Mat3 &Kout, Pcg32 &rng, Mat3 &R) {
+int estimate_rotation(const float *prev, const float *cur, int n, const Mat3 &Kin, const Mat3 &Kout, Pcg32 &rng, Mat3 &R,
+                      bool in_fish) {
     R = Mat3::identity();
     if (n < 5) return 0;  // solvePnPRansac needs >= model size; the reference maps failure to (I, 0) (:367-371)
     static thread_local std::vector<double> tmp, und, obj;
@@ -170,11 +171,11 @@ int estimate_rotation(const float *prev, const float *cur, int n, const Mat3 &Ki
     tmp.resize(2 * (size_t)n), und.resize(2 * (size_t)n), obj.resize(3 * (size_t)n), img.resize(2 * (size_t)n);
     // :322-330 current points -> output-camera pixels (R = I, P = output matrix), stored as Point2f
     for (int i = 0; i < 2 * n; i++) tmp[i] = cur[i];
-    fisheye_undistort(tmp.data(), n, Kin, Kout, und.data());
+    fisheye_undistort(tmp.data(), n, Kin, Kout, und.data(), in_fish);
     for (int i = 0; i < 2 * n; i++) img[i] = (float)und[i];
     // :333-338 previous points -> normalised identity-camera coordinates, stored as Point2f
     for (int i = 0; i < 2 * n; i++) tmp[i] = prev[i];
-    fisheye_undistort(tmp.data(), n, Kin, Mat3::identity(), und.data());
+    fisheye_undistort(tmp.data(), n, Kin, Mat3::identity(), und.data(), in_fish);
     for (int i = 0; i < n; i++) {
         const double s = rng.uniform();  // :345 random depth ("prevents the detection of translations")
         const float px = (float)und[2 * i], py = (float)und[2 * i + 1];

@@ -32,8 +32,9 @@ void rodrigues_inv(const Mat3 &R, double rvec[3]);
 
 // guess_camera_rotation, FrameSourceWarp.cpp:316-375.  prev/cur: n (x,y) float pairs in input
 // (fisheye) pixels.  Returns the number of RANSAC inliers; R = rotation since the last frame.
+// in_fish = false: pinhole input lens (libdewobble in_p=rect); the reference only has fisheye input.
 int estimate_rotation(const float *prev, const float *cur, int n, const Mat3 &Kin, const Mat3 &Kout, Pcg32 &rng,
-                      Mat3 &R);
+                      Mat3 &R, bool in_fish = true);
 
 // Savitzky-Golay weights for (m, t=0, n=2, s=0) -- gram_sg::SavitzkyGolayFilterConfig(r,0,2,0),
 // FrameSourceWarp.cpp:212.

@@ -314,9 +314,9 @@ class EstimateWorker {
             th_.join();
         }
     }
-    void post(const float *prev, const float *cur, int n, const Mat3 *Kin, const Mat3 *Kout, Pcg32 *rng) {
+    void post(const float *prev, const float *cur, int n, const Mat3 *Kin, const Mat3 *Kout, Pcg32 *rng, bool in_fish) {
         if (!th_.joinable()) th_ = std::thread([this] { run(); });
-        prev_ = prev, cur_ = cur, n_ = n, Kin_ = Kin, Kout_ = Kout, rng_ = rng;
+        prev_ = prev, cur_ = cur, n_ = n, Kin_ = Kin, Kout_ = Kout, rng_ = rng, in_fish_ = in_fish;
         {
             std::lock_guard<std::mutex> lk(m_);
             state_.store(POSTED, std::memory_order_release);
@@ -345,7 +345,7 @@ class EstimateWorker {
                 st = state_.load(std::memory_order_acquire);
             }
             if (st == QUIT) return;
-            inliers_ = estimate_rotation(prev_, cur_, n_, *Kin_, *Kout_, *rng_, R_);
+            inliers_ = estimate_rotation(prev_, cur_, n_, *Kin_, *Kout_, *rng_, R_, in_fish_);
             state_.store(DONE, std::memory_order_release);
         }
     }
@@ -357,6 +357,7 @@ class EstimateWorker {
     int n_ = 0;
     const Mat3 *Kin_ = nullptr, *Kout_ = nullptr;
     Pcg32 *rng_ = nullptr;
+    bool in_fish_ = true;
     Mat3 R_;
     int inliers_ = 0;
 };
@@ -377,6 +378,8 @@ struct vstab_handle {
     hipEvent_t pyr_done[PYR_SETS] = {};  // recorded on pstream after pyramid set k
     int w = 0, h = 0, ow = 0, oh = 0;
     Mat3 Kin, Kout;
+    int map_mode = VSTAB_MAP_CREATEMAP_CL;  // createMap.cl for the preset path, a projection pair in lens mode
+    bool in_fish = true;
     Tracker tracker;
 
     struct Slot {
@@ -656,7 +659,7 @@ static vstab_status finish_wait(vstab_handle *H) {
 static void post_estimate(vstab_handle *H) {
     if (!H->have_ready || H->estimate_posted || !H->threaded_estimate) return;
     vstab_handle::Tracked &T = H->ready;
-    H->worker.post(T.pp.data(), T.cp.data(), T.lg.n_tracked, &H->Kin, &H->Kout, &H->rng);
+    H->worker.post(T.pp.data(), T.cp.data(), T.lg.n_tracked, &H->Kin, &H->Kout, &H->rng, H->in_fish);
     H->estimate_posted = true;
 }
 
@@ -672,7 +675,7 @@ static void finish_estimate(vstab_handle *H) {
         if (H->estimate_posted)
             inl = H->worker.join(R), H->estimate_posted = false;
         else
-            inl = estimate_rotation(T.pp.data(), T.cp.data(), lg.n_tracked, H->Kin, H->Kout, H->rng, R);
+            inl = estimate_rotation(T.pp.data(), T.cp.data(), lg.n_tracked, H->Kin, H->Kout, H->rng, R, H->in_fish);
     }
     lg.n_inliers = inl;
     if (inl < 40) {
@@ -697,6 +700,8 @@ void vstab_config_default(vstab_config *cfg) {
     cfg->preset = VSTAB_GOPRO_H4B_WIDE169_MEASURED;
     cfg->scale = 1, cfg->crop_borders = 0, cfg->zoom = 1, cfg->smooth_radius = 30;  // FrameSourceWarp.hpp:86-89
     cfg->interpolation = 1, cfg->smoother = VSTAB_SMOOTHER_SG, cfg->tracking = 1, cfg->seed = 1, cfg->stream = nullptr;
+    cfg->lens_mode = 0, cfg->in_projection = VSTAB_PROJ_FISH, cfg->out_projection = VSTAB_PROJ_RECT;
+    cfg->in_dfov = 0, cfg->out_dfov = 0, cfg->out_width = 0, cfg->out_height = 0, cfg->out_cx = -1, cfg->out_cy = -1;
 }
 
 vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vstab_handle **out) {
@@ -704,6 +709,8 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (cfg->smooth_radius < 0 || cfg->smooth_radius > 10000) return fail(VSTAB_ERR_INVALID, "vstab_create: bad smooth_radius");
     if (cfg->interpolation != 1) return fail(VSTAB_ERR_INVALID, "vstab_create: only INTER_LINEAR is implemented (the only mode the reference passes)");
     if (!(cfg->scale > 0) || !(cfg->zoom > 0)) return fail(VSTAB_ERR_INVALID, "vstab_create: scale and zoom must be positive");
+    if (cfg->smoother < VSTAB_SMOOTHER_SG || cfg->smoother > VSTAB_SMOOTHER_FIXED) return fail(VSTAB_ERR_INVALID, "vstab_create: unknown smoother");
+    if (cfg->lens_mode != 0 && cfg->lens_mode != 1) return fail(VSTAB_ERR_INVALID, "vstab_create: lens_mode must be 0 or 1");
     std::unique_ptr<vstab_handle> H(new vstab_handle);
     H->cfg = *cfg, H->src = *src;
     H->rng = Pcg32(cfg->seed);
@@ -731,8 +738,21 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (f.width <= 0 || f.height <= 0 || (f.width & 1) || (f.height & 1) || f.width > 32767 || f.height > 32767)
         return fail(VSTAB_ERR_INVALID, "vstab_create: frame size must be even and <= 32767");
     H->w = f.width, H->h = f.height;
-    if (!preset_camera(cfg->preset, H->w, H->h, H->Kin)) return fail(VSTAB_ERR_INVALID, "vstab_create: unknown preset");
-    output_camera(H->Kin, H->w, H->h, cfg->scale, cfg->crop_borders != 0, cfg->zoom, H->Kout, H->ow, H->oh);
+    if (cfg->lens_mode == 0) {
+        if (!preset_camera(cfg->preset, H->w, H->h, H->Kin)) return fail(VSTAB_ERR_INVALID, "vstab_create: unknown preset");
+        output_camera(H->Kin, H->w, H->h, cfg->scale, cfg->crop_borders != 0, cfg->zoom, H->Kout, H->ow, H->oh);
+    } else {
+        // the libdewobble filter options as the CLI sets them (render.ts:669-683)
+        H->ow = cfg->out_width > 0 ? cfg->out_width : H->w, H->oh = cfg->out_height > 0 ? cfg->out_height : H->h;
+        const double out_dfov = cfg->out_dfov > 0 ? cfg->out_dfov : cfg->in_dfov;
+        if (!lens_camera(cfg->in_projection, cfg->in_dfov, H->w, H->h, -1, -1, H->Kin) ||
+            !lens_camera(cfg->out_projection, out_dfov, H->ow, H->oh, cfg->out_cx, cfg->out_cy, H->Kout))
+            return fail(VSTAB_ERR_INVALID, "vstab_create: bad lens description (projection / field of view / size)");
+        H->in_fish = cfg->in_projection == VSTAB_PROJ_FISH;
+        const bool out_fish = cfg->out_projection == VSTAB_PROJ_FISH;
+        H->map_mode = H->in_fish ? (out_fish ? VSTAB_MAP_FISH_TO_FISH : VSTAB_MAP_FISH_TO_RECT)
+                                 : (out_fish ? VSTAB_MAP_RECT_TO_FISH : VSTAB_MAP_RECT_TO_RECT);
+    }
     if (H->ow <= 0 || H->oh <= 0 || H->ow > 32767 || H->oh > 32767) return fail(VSTAB_ERR_INVALID, "vstab_create: output size out of range");
     if (cfg->smoother == VSTAB_SMOOTHER_SG) H->sg.reset(new RotationFilterSG(cfg->smooth_radius));
     H->slots.resize((size_t)cfg->smooth_radius + 5 + PREFETCH_DEPTH);  // queue (r+1) + ready + in flight + first/last gray + 2 spare for stream overlap
@@ -755,9 +775,11 @@ vstab_status vstab_get_output_info(const vstab_handle *h, int *width, int *heigh
     return VSTAB_OK;
 }
 
+}  // extern "C"
+
 // FrameSourceWarp::pull_frame, :452-476
-vstab_status vstab_pull_frame(vstab_handle *H, void *dst, size_t pitch_dst) {
-    if (!H || !dst) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: null argument");
+static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, size_t pitch_dst, void *dst_uv, size_t pitch_dst_uv) {
+    if (!H || !dst || (out_format == VSTAB_OUT_NV12 && !dst_uv)) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: null argument");
     while (H->queue.size() <= (size_t)H->cfg.smooth_radius) {  // :453
         // 1. LK results of the frame in flight -> surviving corners; its rotation estimate starts on the
         //    worker thread right away
@@ -796,6 +818,8 @@ vstab_status vstab_pull_frame(vstab_handle *H, void *dst, size_t pitch_dst) {
             corrected = H->sg->filter();  // :471
         else if (H->cfg.smoother == VSTAB_SMOOTHER_KALMAN)
             corrected = H->kalman.update(measured);
+        else if (H->cfg.smoother == VSTAB_SMOOTHER_FIXED)
+            corrected = Mat3::identity();  // hold the orientation of the first frame
         else
             corrected = measured;
         const Mat3 correction = corrected * measured.inv();  // :472
@@ -813,13 +837,23 @@ vstab_status vstab_pull_frame(vstab_handle *H, void *dst, size_t pitch_dst) {
         // the profiling events bracket the launch call and nothing else, so the interval is the kernel
         // (plus its dispatch), not host work between two API calls
         GpuStage gs(H, vstab_handle::ST_WARP);
-        st = vstab_warp_nv12_bgr(nv12, (size_t)H->w, nv12 + (size_t)H->w * H->h, (size_t)H->w, H->w, H->h, p, dst, pitch_dst, H->ow,
-                                 H->oh, H->stream);
+        st = vstab_warp_nv12_ex(nv12, (size_t)H->w, nv12 + (size_t)H->w * H->h, (size_t)H->w, H->w, H->h, p, H->map_mode, out_format, dst,
+                                pitch_dst, dst_uv, pitch_dst_uv, H->ow, H->oh, H->stream);
     }
     VSTAB_HIP_TRY(hipEventRecord(S.warped, H->stream));  // the next ingest into this slot waits for it
     S.warp_pending = true, S.queued = false, S.freed_at = ++H->free_counter;
     H->last_warp_slot = slot;
     return st;
+}
+
+extern "C" {
+
+vstab_status vstab_pull_frame(vstab_handle *h, void *dst, size_t pitch_dst) {
+    return pull_frame_impl(h, VSTAB_OUT_BGR8, dst, pitch_dst, nullptr, 0);
+}
+
+vstab_status vstab_pull_frame_nv12(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv) {
+    return pull_frame_impl(h, VSTAB_OUT_NV12, dst_y, pitch_y, dst_uv, pitch_uv);
 }
 
 vstab_status vstab_peek_frame(vstab_handle *h, void *dst, size_t pitch_dst) { return vstab_pull_frame(h, dst, pitch_dst); }  // :478-480

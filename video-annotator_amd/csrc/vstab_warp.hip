@@ -117,6 +117,34 @@ __global__ void __launch_bounds__(256) k_create_map(float *__restrict__ mapx, si
     }
 }
 
+// k_create_map_ex -- the generalised map (modes 1..4, vstab_device.hpp map_pixel_ex) as map planes.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_create_map_ex(float *__restrict__ mapx, size_t pitch_x,
+                                                       float *__restrict__ mapy, size_t pitch_y,
+                                                       int cols, int rows, MapParams p, int vec_ok) {
+    const int x0 = (blockIdx.x * 16 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 16 + threadIdx.y;
+    if (x0 >= cols || y >= rows) return;
+    const MapParams32 in = {p.icx, p.icy, p.ifx, p.ify, p.r[2], p.r[5], p.r[8]};  // unscaled here
+    const float vy = ((float)y - p.ocy) / p.ofy;
+    const RowTerm rt = {p.r[1] * vy, p.r[4] * vy, p.r[7] * vy};
+    float mx[4], my[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float vx = ((float)(x0 + i) - p.ocx) / p.ofx;
+        const ColTerm ct = {p.r[0] * vx, p.r[3] * vx, p.r[6] * vx};
+        map_pixel_ex<MODE>(in, p, ct, rt, vx, vy, mx[i], my[i]);
+    }
+    float *px = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(mapx) + (size_t)y * pitch_x) + x0;
+    float *py = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(mapy) + (size_t)y * pitch_y) + x0;
+    if (vec_ok && x0 + 4 <= cols) {
+        *reinterpret_cast<float4 *>(px) = make_float4(mx[0], mx[1], mx[2], mx[3]);
+        *reinterpret_cast<float4 *>(py) = make_float4(my[0], my[1], my[2], my[3]);
+    } else {
+        for (int i = 0; i < 4 && x0 + i < cols; i++) px[i] = mx[i], py[i] = my[i];
+    }
+}
+
 // =============================================================================================
 // k_remap_bilinear -- cv::remap(INTER_LINEAR, BORDER_CONSTANT 0), FrameSourceWarp.cpp:306-312,
 // reading float map planes (un-fused compatibility mode).  One thread per output pixel.
@@ -169,8 +197,9 @@ constexpr int WARP_TILE_W = 64, WARP_TILE_H = 16 * WARP_ROWS_PER_THREAD;
 struct WarpArgs {
     const uint8_t *y;
     const uint8_t *uv;
-    uint8_t *dst;
-    size_t pitch_y, pitch_uv, pitch_dst;
+    uint8_t *dst;     // BGR8, or the luma plane in NV12 output mode
+    uint8_t *dst_uv;  // NV12 output mode: interleaved chroma plane, ceil(dh/2) rows of 2*ceil(dw/2) bytes
+    size_t pitch_y, pitch_uv, pitch_dst, pitch_dst_uv;
     int sw, sh, dw, dh;
     MapParams p;
 };
@@ -278,7 +307,7 @@ __device__ __forceinline__ uint32_t load_u32_bytes(const uint8_t *p, int valid) 
     return v;
 }
 
-template <int RPT, int TY>
+template <int RPT, int TY, int MODE = MAP_CREATEMAP_CL, int FMT = 0>
 __global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
     constexpr int NT = 16 * TY;  // threads per workgroup: 16 columns of 4 pixels x TY thread rows
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -308,10 +337,12 @@ __global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
         // column / row terms with ONE refined reciprocal per axis (createMap.cl:16-17 divisions)
         const float rfx = rcp_refined(a.p.ofx), rfy = rcp_refined(a.p.ofy);
         ColTerm ct[4];
+        float vxs[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const float vx = div_with_rcp((float)(x0 + i) - a.p.ocx, a.p.ofx, rfx);
             ct[i] = {a.p.r[0] * vx, a.p.r[3] * vx, a.p.r[6] * vx};
+            vxs[i] = vx;
         }
         const uint32_t sw1 = (uint32_t)(a.sw - 1), sh1 = (uint32_t)(a.sh - 1);
 #pragma unroll
@@ -322,7 +353,7 @@ __global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float ax, ay;
-                map_pixel32(ta.p32, ct[i], rt, ax, ay);
+                map_pixel_ex<MODE>(ta.p32, a.p, ct[i], rt, vxs[i], vy, ax, ay);
                 // v_cvt_i32_f32 saturates (+-inf and out-of-range -> INT_MAX / INT_MIN, which land far
                 // outside any source <= 32767 wide after >> 5); only NaN (-> 0) needs an explicit test,
                 // and one ordered compare covers both coordinates.  Equivalent to cv::remap's cvRound
@@ -425,15 +456,35 @@ __global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
             }
             px[i] = v;
         }
-        uint8_t *o = a.dst + ((size_t)(uint32_t)y * a.pitch_dst + (uint32_t)x0 * 3u);
-        if (ta.dst_vec_ok && x0 + 4 <= a.dw) {
-            uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
-            o32[0] = px[0] | (px[1] << 24);
-            o32[1] = (px[1] >> 8) | (px[2] << 16);
-            o32[2] = (px[2] >> 16) | (px[3] << 8);
+        if constexpr (FMT == 0) {
+            uint8_t *o = a.dst + ((size_t)(uint32_t)y * a.pitch_dst + (uint32_t)x0 * 3u);
+            if (ta.dst_vec_ok && x0 + 4 <= a.dw) {
+                uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
+                o32[0] = px[0] | (px[1] << 24);
+                o32[1] = (px[1] >> 8) | (px[2] << 16);
+                o32[2] = (px[2] >> 16) | (px[3] << 8);
+            } else {
+                for (int i = 0; i < 4 && x0 + i < a.dw; i++) {
+                    o[3 * i] = px[i] & 255, o[3 * i + 1] = (px[i] >> 8) & 255, o[3 * i + 2] = (px[i] >> 16) & 255;
+                }
+            }
         } else {
-            for (int i = 0; i < 4 && x0 + i < a.dw; i++) {
-                o[3 * i] = px[i] & 255, o[3 * i + 1] = (px[i] >> 8) & 255, o[3 * i + 2] = (px[i] >> 16) & 255;
+            // NV12 output: luma for every pixel, chroma from the even-row / even-column pixels
+            const uint32_t yw = bgr_to_y(px[0]) | (bgr_to_y(px[1]) << 8) | (bgr_to_y(px[2]) << 16) | (bgr_to_y(px[3]) << 24);
+            uint8_t *o = a.dst + ((size_t)(uint32_t)y * a.pitch_dst + (uint32_t)x0);
+            if (ta.dst_vec_ok && x0 + 4 <= a.dw) {
+                *reinterpret_cast<uint32_t *>(o) = yw;
+            } else {
+                for (int i = 0; i < 4 && x0 + i < a.dw; i++) o[i] = (yw >> (8 * i)) & 255;
+            }
+            if (!(y & 1)) {
+                const uint32_t cw = bgr_to_uv(px[0]) | (bgr_to_uv(px[2]) << 16);
+                uint8_t *c = a.dst_uv + ((size_t)(uint32_t)(y >> 1) * a.pitch_dst_uv + (uint32_t)x0);
+                if (ta.dst_vec_ok && x0 + 2 < a.dw) {
+                    *reinterpret_cast<uint32_t *>(c) = cw;
+                } else {
+                    for (int i = 0; i < 4 && x0 + (i & ~1) < a.dw; i++) c[i] = (cw >> (8 * i)) & 255;
+                }
             }
         }
     }
@@ -502,19 +553,33 @@ vstab_status vstab_cvt_nv12_bgr(const void *y, size_t pitch_y, const void *uv, s
     return VSTAB_OK;
 }
 
-vstab_status vstab_create_map(void *map_x, size_t pitch_x, void *map_y, size_t pitch_y, int cols, int rows,
-                              const float params[17], void *stream) {
+vstab_status vstab_create_map_ex(void *map_x, size_t pitch_x, void *map_y, size_t pitch_y, int cols, int rows,
+                                 const float params[17], int map_mode, void *stream) {
     if (!map_x || !map_y || !params) return fail(VSTAB_ERR_INVALID, "vstab_create_map: null pointer");
     if (cols <= 0 || rows <= 0 || cols > 32767 || rows > 32767)
         return fail(VSTAB_ERR_INVALID, "vstab_create_map: size must be in [1, 32767] (createMap.cl:10-11)");
     if (pitch_x < (size_t)cols * 4 || pitch_y < (size_t)cols * 4 || pitch_x % 4 || pitch_y % 4)
         return fail(VSTAB_ERR_INVALID, "vstab_create_map: bad pitch");
+    if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_RECT_TO_FISH) return fail(VSTAB_ERR_INVALID, "vstab_create_map: unknown map mode");
     const int vec_ok = aligned(map_x, 16) && aligned(map_y, 16) && pitch_x % 16 == 0 && pitch_y % 16 == 0;
     dim3 grid(div_up(div_up(cols, 4), 16), div_up(rows, 16));
-    hipLaunchKernelGGL(k_create_map, grid, dim3(16, 16), 0, static_cast<hipStream_t>(stream), (float *)map_x,
-                       pitch_x, (float *)map_y, pitch_y, cols, rows, to_params(params), vec_ok);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define VSTAB_LAUNCH(K) hipLaunchKernelGGL(K, grid, dim3(16, 16), 0, s, (float *)map_x, pitch_x, (float *)map_y, pitch_y, cols, rows, to_params(params), vec_ok)
+    switch (map_mode) {
+        case VSTAB_MAP_CREATEMAP_CL: VSTAB_LAUNCH(k_create_map); break;
+        case VSTAB_MAP_FISH_TO_RECT: VSTAB_LAUNCH(k_create_map_ex<MAP_FISH_TO_RECT>); break;
+        case VSTAB_MAP_FISH_TO_FISH: VSTAB_LAUNCH(k_create_map_ex<MAP_FISH_TO_FISH>); break;
+        case VSTAB_MAP_RECT_TO_RECT: VSTAB_LAUNCH(k_create_map_ex<MAP_RECT_TO_RECT>); break;
+        default: VSTAB_LAUNCH(k_create_map_ex<MAP_RECT_TO_FISH>); break;
+    }
+#undef VSTAB_LAUNCH
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
+}
+
+vstab_status vstab_create_map(void *map_x, size_t pitch_x, void *map_y, size_t pitch_y, int cols, int rows,
+                              const float params[17], void *stream) {
+    return vstab_create_map_ex(map_x, pitch_x, map_y, pitch_y, cols, rows, params, VSTAB_MAP_CREATEMAP_CL, stream);
 }
 
 vstab_status vstab_remap_bilinear(const void *src, size_t pitch_src, int sw, int sh, int channels,
@@ -541,26 +606,33 @@ vstab_status vstab_remap_bilinear(const void *src, size_t pitch_src, int sw, int
     return VSTAB_OK;
 }
 
-vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh,
-                                 const float params[17], void *dst, size_t pitch_dst, int dw, int dh,
-                                 void *stream) {
-    if (!y || !uv || !dst || !params) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_bgr: null pointer");
+vstab_status vstab_warp_nv12_ex(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh,
+                                const float params[17], int map_mode, int out_format, void *dst, size_t pitch_dst,
+                                void *dst_uv, size_t pitch_dst_uv, int dw, int dh, void *stream) {
+    if (!y || !uv || !dst || !params) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: null pointer");
     if (sw <= 0 || sh <= 0 || (sw & 1) || (sh & 1) || sw > 32767 || sh > 32767)
-        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_bgr: source must be even-sized and <= 32767");
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: source must be even-sized and <= 32767");
     if (dw <= 0 || dh <= 0 || dw > 32767 || dh > 32767)
-        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_bgr: output size must be in [1, 32767]");
-    if (pitch_y < (size_t)sw || pitch_uv < (size_t)sw || pitch_dst < (size_t)dw * 3)
-        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_bgr: pitch smaller than row");
-    if (!aligned(uv, 2) || pitch_uv % 2) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_bgr: chroma plane must be 2-B aligned");
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: output size must be in [1, 32767]");
+    if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_RECT_TO_FISH) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: unknown map mode");
+    if (out_format != VSTAB_OUT_BGR8 && out_format != VSTAB_OUT_NV12) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: unknown output format");
+    const bool nv12_out = out_format == VSTAB_OUT_NV12;
+    if (pitch_y < (size_t)sw || pitch_uv < (size_t)sw || pitch_dst < (size_t)dw * (nv12_out ? 1 : 3))
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: pitch smaller than row");
+    if (nv12_out && (!dst_uv || pitch_dst_uv < (size_t)((dw + 1) / 2) * 2))
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: NV12 output needs a chroma plane of 2*ceil(width/2) bytes per row");
+    if (!aligned(uv, 2) || pitch_uv % 2) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: chroma plane must be 2-B aligned");
     WarpArgs a;
-    a.y = (const uint8_t *)y, a.uv = (const uint8_t *)uv, a.dst = (uint8_t *)dst;
-    a.pitch_y = pitch_y, a.pitch_uv = pitch_uv, a.pitch_dst = pitch_dst;
+    a.y = (const uint8_t *)y, a.uv = (const uint8_t *)uv, a.dst = (uint8_t *)dst, a.dst_uv = (uint8_t *)dst_uv;
+    a.pitch_y = pitch_y, a.pitch_uv = pitch_uv, a.pitch_dst = pitch_dst, a.pitch_dst_uv = pitch_dst_uv;
     a.sw = sw, a.sh = sh, a.dw = dw, a.dh = dh;
     a.p = to_params(params);
-    const int vec_ok = aligned(dst, 4) && pitch_dst % 4 == 0;
+    const int vec_ok = aligned(dst, 4) && pitch_dst % 4 == 0 && (!nv12_out || (aligned(dst_uv, 4) && pitch_dst_uv % 4 == 0));
     static const int variant = getenv("VSTAB_WARP_VARIANT") ? atoi(getenv("VSTAB_WARP_VARIANT")) : 2;
     const bool small_pitch = pitch_y < (1u << 24) && pitch_uv < (1u << 24) && (uint64_t)pitch_y * sh < (1ull << 32);
-    if (variant == 1 || !small_pitch) {  // v1 direct-gather kernel (kept as the in-kernel fallback's twin, for A/B runs)
+    const bool plain = map_mode == VSTAB_MAP_CREATEMAP_CL && !nv12_out;
+    if (!plain && !small_pitch) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: source pitch too large for this mode");
+    if (plain && (variant == 1 || !small_pitch)) {  // v1 direct-gather kernel (kept as the in-kernel fallback's twin, for A/B runs)
         dim3 grid(div_up(dw, WARP_TILE_W), div_up(dh, WARP_TILE_H));
         hipLaunchKernelGGL(k_warp_nv12_bgr, grid, dim3(16, 16), 0, static_cast<hipStream_t>(stream), a, vec_ok);
     } else {
@@ -571,24 +643,46 @@ vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const void *uv, 
         ta.dst_vec_ok = vec_ok;
         static const int dbg = getenv("VSTAB_DEBUG_MODE") ? atoi(getenv("VSTAB_DEBUG_MODE")) : 0;
         ta.debug_mode = dbg;
-        static const int rpt = getenv("VSTAB_RPT") ? atoi(getenv("VSTAB_RPT")) : 2;
-        static const int tyr = getenv("VSTAB_TY") ? atoi(getenv("VSTAB_TY")) : 16;
+        static const int rpt_env = getenv("VSTAB_RPT") ? atoi(getenv("VSTAB_RPT")) : 2;
+        static const int tyr_env = getenv("VSTAB_TY") ? atoi(getenv("VSTAB_TY")) : 16;
+        const int rpt = plain ? rpt_env : 2, tyr = plain ? tyr_env : 16;  // the tile-shape knobs exist for the reference mode only
         static const int lds_kb = getenv("VSTAB_LDS_KB") ? atoi(getenv("VSTAB_LDS_KB")) : 40;
         const size_t lds_bytes = (size_t)lds_kb * 1024;  // 40 KB -> 4 workgroups (16 waves) per CU
         ta.lds_capacity_px = (int)(lds_bytes / 4) - 4;
         ta.tiles_x = (int)div_up(dw, WARP_TILE_W), ta.tiles_y = (int)div_up(dh, tyr * rpt);
         dim3 grid(8 * div_up((unsigned)(ta.tiles_x * ta.tiles_y), 8));
         hipStream_t st = static_cast<hipStream_t>(stream);
-#define VSTAB_LAUNCH(R, T) hipLaunchKernelGGL((k_warp_tiled<R, T>), grid, dim3(16 * T), lds_bytes, st, ta)
-        if (tyr == 8 && rpt == 2) VSTAB_LAUNCH(2, 8);
-        else if (tyr == 8 && rpt == 4) VSTAB_LAUNCH(4, 8);
-        else if (tyr == 4 && rpt == 4) VSTAB_LAUNCH(4, 4);
-        else if (tyr == 16 && rpt == 1) VSTAB_LAUNCH(1, 16);
-        else VSTAB_LAUNCH(2, 16);
+#define VSTAB_LAUNCH(R, T, M, F) hipLaunchKernelGGL((k_warp_tiled<R, T, M, F>), grid, dim3(16 * T), lds_bytes, st, ta)
+        if (plain) {
+            if (tyr == 8 && rpt == 2) VSTAB_LAUNCH(2, 8, MAP_CREATEMAP_CL, 0);
+            else if (tyr == 8 && rpt == 4) VSTAB_LAUNCH(4, 8, MAP_CREATEMAP_CL, 0);
+            else if (tyr == 4 && rpt == 4) VSTAB_LAUNCH(4, 4, MAP_CREATEMAP_CL, 0);
+            else if (tyr == 16 && rpt == 1) VSTAB_LAUNCH(1, 16, MAP_CREATEMAP_CL, 0);
+            else VSTAB_LAUNCH(2, 16, MAP_CREATEMAP_CL, 0);
+        } else {
+            switch (map_mode * 2 + (nv12_out ? 1 : 0)) {
+                case 1: VSTAB_LAUNCH(2, 16, MAP_CREATEMAP_CL, 1); break;
+                case 2: VSTAB_LAUNCH(2, 16, MAP_FISH_TO_RECT, 0); break;
+                case 3: VSTAB_LAUNCH(2, 16, MAP_FISH_TO_RECT, 1); break;
+                case 4: VSTAB_LAUNCH(2, 16, MAP_FISH_TO_FISH, 0); break;
+                case 5: VSTAB_LAUNCH(2, 16, MAP_FISH_TO_FISH, 1); break;
+                case 6: VSTAB_LAUNCH(2, 16, MAP_RECT_TO_RECT, 0); break;
+                case 7: VSTAB_LAUNCH(2, 16, MAP_RECT_TO_RECT, 1); break;
+                case 8: VSTAB_LAUNCH(2, 16, MAP_RECT_TO_FISH, 0); break;
+                default: VSTAB_LAUNCH(2, 16, MAP_RECT_TO_FISH, 1); break;
+            }
+        }
 #undef VSTAB_LAUNCH
     }
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
+}
+
+vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh,
+                                 const float params[17], void *dst, size_t pitch_dst, int dw, int dh,
+                                 void *stream) {
+    return vstab_warp_nv12_ex(y, pitch_y, uv, pitch_uv, sw, sh, params, VSTAB_MAP_CREATEMAP_CL, VSTAB_OUT_BGR8, dst, pitch_dst,
+                              nullptr, 0, dw, dh, stream);
 }
 
 }  // extern "C"
