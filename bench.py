@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--ring", type=int, default=64, help="distinct input frames / output buffers")
     ap.add_argument("--no-tracking", action="store_true",
                     help="BASELINE config 1: undistort only (identity rotations) through the pipeline object")
+    ap.add_argument("--out-format", default="bgr", choices=["bgr", "nv12"],
+                    help="bgr = what FrameSourceWarp emits (the BASELINE metric); nv12 = encoder hand-off mode (SURVEY.md 8(f) row 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo only for rehearsing ranks on one GPU")
@@ -171,7 +173,12 @@ def main():
         mode = "pipeline" if have_pipeline else "warp"
 
     ring = synth_ring(torch, dev, w, h, args.ring, seed=rank) if mode == "warp" else None
-    outs = [torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(args.ring)]
+    nv12_out = args.out_format == "nv12"
+    if nv12_out:
+        outs = [vs.nv12_out_planes(cw, ch, dev) for _ in range(args.ring)]
+    else:
+        outs = [torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(args.ring)]
+    out_name = "NV12" if nv12_out else "BGR"
     stream = torch.cuda.current_stream()
 
     # a fixed per-frame rotation schedule (small smooth shake) so every launch has a different map
@@ -190,11 +197,12 @@ def main():
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-            vs.warp_nv12_bgr(ring[i % args.ring], params[i], cw, ch, out=outs[i % args.ring])
+            vs.warp_nv12(ring[i % args.ring], params[i], cw, ch, vs.MAP_CREATEMAP_CL, vs.OUT_NV12 if nv12_out else vs.OUT_BGR8,
+                         out=outs[i % args.ring])
             if timed:
                 e1.record(stream)
                 kernel_events.append((e0, e1))
-        workload = f"{args.workload} NV12 {w}x{h} -> BGR {cw}x{ch}, fused undistort-remap (createMap+cvtColor+remap), per-frame rotation, tracking/smoothing NOT included"
+        workload = f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, fused undistort-remap (createMap+cvtColor+remap), per-frame rotation, tracking/smoothing NOT included"
     else:
         clip, _ = shaky_ring(torch, dev, w, h, K, args.ring, seed=rank)
         stab = vs.Stabilizer(clip, total=args.warmup + args.steps + 1000, preset=preset, smooth_radius=30, seed=1234 + rank,
@@ -205,11 +213,12 @@ def main():
             if timed and i == args.warmup:
                 stab.profile()               # fold + discard the warm-up stages
                 stab._prof0 = stab.profile()
-            assert stab.pull_into(outs[i % args.ring])
+            assert pull(i)
+        pull = (lambda i: stab.pull_nv12_into(*outs[i % args.ring])) if nv12_out else (lambda i: stab.pull_into(outs[i % args.ring]))
         stab.enable_profiling(1)  # timed region: HIP events around the warp launches only
-        workload = f"{args.workload} NV12 {w}x{h} -> BGR {cw}x{ch}, full pipeline: NV12 ingest, corner detect, pyramidal LK, rotation estimate, SG smoothing (r=30), fused undistort-remap"
+        workload = f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, full pipeline: NV12 ingest, corner detect, pyramidal LK, rotation estimate, SG smoothing (r=30), fused undistort-remap"
         if args.no_tracking:
-            workload = f"{args.workload} NV12 {w}x{h} -> BGR {cw}x{ch}, undistort only (tracking off, identity rotations): NV12 ingest + fused undistort-remap"
+            workload = f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, undistort only (tracking off, identity rotations): NV12 ingest + fused undistort-remap"
 
     for i in range(args.warmup):
         step(i, False)
@@ -234,6 +243,8 @@ def main():
     # then rank 0 writes the stitch list (concat.sh / join.ts format)
     shard = importlib.import_module("video-annotator_amd.shard")
     last = outs[(args.warmup + args.steps - 1) % args.ring]
+    if nv12_out:
+        last = last[0]
     rec = dict(rank=rank, clip=rank, frames=args.steps, elapsed_ns=int(el * 1e9), crc=shard.crc_of(last[:64].cpu().numpy()))
     records = shard.gather_records([rec], device=cdev)
     if rank == 0 and world > 1:
@@ -256,19 +267,21 @@ def main():
             stab.enable_profiling(2)
             q0 = stab.profile()
             for i in range(120):
-                assert stab.pull_into(outs[i % args.ring])
+                assert pull(i)
             q1 = stab.profile()
             dq = {k: q1[k] - q0[k] for k in q1}
             stages = {k.replace("_ms", "_us_per_frame"): round(v / max(1, dq["frames_emitted"]) * 1e3, 2) for k, v in dq.items() if k.endswith("_ms")}
             stages["key_frames_per_120"] = int(dq["key_frames"])
         alg_bytes = w * h * 1.5 + cw * ch * 3  # NV12 read once + BGR8 written once
+        if nv12_out:
+            alg_bytes = w * h * 1.5 + cw * ch + 2 * ((cw + 1) // 2) * ((ch + 1) // 2)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms else None
         traffic = None
         if args.traffic:
             traffic = float(args.traffic)
         else:
             tf = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-            if os.path.exists(tf):
+            if os.path.exists(tf) and not nv12_out:
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
         line = {
             "metric": "stabilized frames/sec at 4K NV12, 1/2/4/8 GPU; remap % HBM roofline",

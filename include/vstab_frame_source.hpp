@@ -43,6 +43,25 @@ using FrameSource = FrameSourceT<BGRFrame>;
 
 using CameraPreset = vstab_camera_preset;  // same enumerators with a VSTAB_ prefix
 
+// NV12 output for the encoder hand-off: two planes in device memory.
+struct NV12Out {
+    void *y = nullptr, *uv = nullptr;
+    size_t pitch_y = 0, pitch_uv = 0;
+    int width = 0, height = 0;
+};
+
+// The option surface of the CLI's libdewobble filter (src/render.ts:611-617,669-683,711-717), field for field.
+struct DewobbleOptions {
+    enum Projection { rect = VSTAB_PROJ_RECT, fish = VSTAB_PROJ_FISH };
+    enum Stab { none, fixed, sg };
+    Projection in_p = fish, out_p = rect;
+    double in_dfov = 0, out_dfov = 0;  // degrees; out_dfov 0 = in_dfov
+    int out_w = 0, out_h = 0;          // 0 = input size
+    double out_fx = -1, out_fy = -1;   // "focal point" = principal point; negative = out_w/2, out_h/2
+    Stab stab = sg;
+    int stab_r = 30;
+};
+
 // opencv/FrameSourceWarp.hpp:40-96.  `out` is caller-provided device storage for the frame returned
 // by pull_frame (the reference allocates a fresh UMat per frame; ownership rules: INTEGRATION.md).
 class FrameSourceWarp : public FrameSource {
@@ -55,6 +74,26 @@ class FrameSourceWarp : public FrameSource {
         vstab_config_default(&cfg);
         cfg.preset = input_camera, cfg.scale = scale, cfg.crop_borders = crop_borders, cfg.zoom = zoom;
         cfg.smooth_radius = smooth_radius, cfg.interpolation = interpolation, cfg.stream = hip_stream;
+        init(cfg);
+    }
+    // The same object configured the way the CLI configures libdewobble (not a reference constructor).
+    FrameSourceWarp(std::shared_ptr<NV12FrameSource> source, const DewobbleOptions &o, void *hip_stream = nullptr)
+        : m_source(std::move(source)) {
+        vstab_config cfg;
+        vstab_config_default(&cfg);
+        cfg.lens_mode = 1, cfg.in_projection = o.in_p, cfg.out_projection = o.out_p, cfg.in_dfov = o.in_dfov, cfg.out_dfov = o.out_dfov;
+        cfg.out_width = o.out_w, cfg.out_height = o.out_h, cfg.out_cx = o.out_fx, cfg.out_cy = o.out_fy;
+        cfg.tracking = o.stab != DewobbleOptions::none;
+        cfg.smoother = o.stab == DewobbleOptions::fixed ? VSTAB_SMOOTHER_FIXED : o.stab == DewobbleOptions::sg ? VSTAB_SMOOTHER_SG : VSTAB_SMOOTHER_NONE;
+        cfg.smooth_radius = o.stab == DewobbleOptions::sg ? o.stab_r : 0, cfg.stream = hip_stream;
+        init(cfg);
+    }
+    ~FrameSourceWarp() override { vstab_destroy(m_handle); }
+    FrameSourceWarp(const FrameSourceWarp &) = delete;
+    FrameSourceWarp &operator=(const FrameSourceWarp &) = delete;
+
+  private:
+    void init(const vstab_config &cfg) {
         vstab_source src{&FrameSourceWarp::pull_cb, &FrameSourceWarp::peek_cb, this};
         const vstab_status st = vstab_create(&cfg, &src, &m_handle);
         if (st != VSTAB_OK) {
@@ -63,10 +102,8 @@ class FrameSourceWarp : public FrameSource {
         }
         vstab_get_output_info(m_handle, &m_out_w, &m_out_h, nullptr, nullptr);
     }
-    ~FrameSourceWarp() override { vstab_destroy(m_handle); }
-    FrameSourceWarp(const FrameSourceWarp &) = delete;
-    FrameSourceWarp &operator=(const FrameSourceWarp &) = delete;
 
+  public:
     int output_width() const { return m_out_w; }
     int output_height() const { return m_out_h; }
     // storage for the next returned frame: width*3 <= pitch, output_height() rows, device memory
@@ -84,6 +121,18 @@ class FrameSourceWarp : public FrameSource {
         return BGRFrame{m_out, m_pitch, m_out_w, m_out_h};
     }
     BGRFrame peek_frame() override { return pull_frame(); }  // :478-480 (destructive in the reference too)
+
+    // the next frame as NV12 (planes provided by the caller: width bytes per luma row, 2*ceil(width/2) per chroma row)
+    NV12Out pull_frame_nv12(void *device_y, size_t pitch_y, void *device_uv, size_t pitch_uv) {
+        const vstab_status st = vstab_pull_frame_nv12(m_handle, device_y, pitch_y, device_uv, pitch_uv);
+        if (st == VSTAB_EOF) throw (int)EOF;
+        if (st == VSTAB_ERR_SOURCE && m_pending_error) throw m_pending_error;
+        if (st != VSTAB_OK) {
+            std::fprintf(stderr, "FrameSourceWarp: %s\n", vstab_last_error());
+            throw (int)st;
+        }
+        return NV12Out{device_y, device_uv, pitch_y, pitch_uv, m_out_w, m_out_h};
+    }
 
   private:
     static int fill(FrameSourceWarp *self, vstab_frame *out, bool advance) {
