@@ -198,8 +198,8 @@ VSTAB_API void vstab_rotation_filter_destroy(vstab_rotation_filter *f);
 
 /* One NV12 frame handed over by the upstream source (what FrameSourceFfmpegOpenCl produces,
  * FrameSourceFfmpegOpenCl.cpp:58-85).  A packed (h*3/2 x w) buffer is uv = y + pitch_y*height.
- * The planes only need to stay valid until the callback is called again or the handle is
- * destroyed: the library copies them into its own HBM ring before returning from pull. */
+ * By default the planes only need to stay valid until the callback is called again (see `hold`) or the
+ * handle is destroyed: the library copies them into its own HBM ring. */
 typedef struct vstab_frame {
     const void *y;
     const void *uv;
@@ -207,6 +207,10 @@ typedef struct vstab_frame {
     int width, height; /* luma size; both even */
     int mem;           /* 0 = device memory, 1 = host memory */
     int64_t pts;
+    int hold;          /* how many FURTHER pull callbacks these planes stay valid and unchanged for.  0 (default): only
+                          until the next callback -- the library then waits for its copy of this frame to finish before
+                          it calls upstream again (a decoder that recycles one output surface).  Ref-counted or pooled
+                          frames can say how deep the pool is and the wait disappears from the frame loop. */
 } vstab_frame;
 
 /* Upstream FrameSource (FrameSource.hpp:14,20): return 0 and fill *out, VSTAB_EOF (-1) at end of
@@ -268,8 +272,8 @@ VSTAB_API vstab_status vstab_get_output_info(const vstab_handle *h, int *width, 
  * VSTAB_EOF when the stream is drained.  The first input frame is never emitted (:403-407).
  * dst is complete once vstab_config.stream is synchronised.  Upstream frames handed to the callbacks
  * must already be complete in memory when the callback returns (they are read on an internal stream).
- * Read-ahead: to overlap copy, pyramid and tracking with the host work, the library pulls upstream up
- * to three frames earlier than the reference's loop would (same frames, same order, same outputs). */
+ * Read-ahead: to overlap copy, pyramid, corner detection and tracking with the host work, the library pulls
+ * upstream up to nine frames earlier than the reference's loop would (same frames, same order, same outputs). */
 VSTAB_API vstab_status vstab_pull_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
 /* pull_frame with NV12 output for the encoder hand-off (render.ts:275-281): the same frame,
  * converted as vstab_warp_nv12_ex(VSTAB_OUT_NV12) defines.  dst_y: width bytes per row; dst_uv: ceil(height/2) rows
@@ -305,8 +309,9 @@ typedef struct vstab_profile {
     double gpu_ingest_ms, gpu_pyramid_ms, gpu_corners_ms, gpu_lk_ms, gpu_warp_ms; /* sums of kernel time */
     double host_corners_ms, host_track_wait_ms, host_estimate_ms, host_smooth_ms;  /* sums of wall time */
     long warp_launches;
+    long warp_timed;     /* warp launches that gpu_warp_ms sums over (level 1 samples every 8th) */
 } vstab_profile;
-/* level 0 = off, 1 = time the warp launches only (two event records per frame), 2 = every GPU stage */
+/* level 0 = off, 1 = time every 8th warp launch only (event records are expensive host calls), 2 = every GPU stage */
 VSTAB_API vstab_status vstab_enable_profiling(vstab_handle *h, int level);
 /* Synchronises the stream, folds all pending event pairs into the sums and returns them. */
 VSTAB_API vstab_status vstab_get_profile(vstab_handle *h, vstab_profile *out);

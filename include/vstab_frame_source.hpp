@@ -21,6 +21,7 @@ struct NV12Frame {
     size_t pitch_y = 0, pitch_uv = 0;
     int width = 0, height = 0;
     bool host = false;
+    int hold = 0;  // vstab_frame.hold: further pulls this frame's memory stays valid for (0 = until the next pull)
 };
 
 // What FrameSourceWarp yields: BGR8 in device memory (cv::UMat CV_8UC3 in the reference).
@@ -139,7 +140,7 @@ class FrameSourceWarp : public FrameSource {
         try {
             const NV12Frame f = advance ? self->m_source->pull_frame() : self->m_source->peek_frame();
             out->y = f.y, out->uv = f.uv, out->pitch_y = f.pitch_y, out->pitch_uv = f.pitch_uv;
-            out->width = f.width, out->height = f.height, out->mem = f.host ? 1 : 0, out->pts = 0;
+            out->width = f.width, out->height = f.height, out->mem = f.host ? 1 : 0, out->pts = 0, out->hold = f.hold;
             return 0;
         } catch (int err) {  // upstream errors are thrown ints (AvFrameSourceFileVaapi.cpp:141)
             if (err != EOF) self->m_pending_error = err;

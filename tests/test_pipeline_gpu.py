@@ -223,6 +223,7 @@ def test_profile_counts_and_stage_times(vs, cuda, clip):
         n += 1
     p = stab.profile()
     assert n == 11 and p["frames_emitted"] == 11 and p["frames_consumed"] == 12 and p["warp_launches"] == 11
+    assert p["warp_timed"] == 11                                   # level 2 times every launch, level 1 every 8th
     assert p["gpu_warp_ms"] > 0 and p["gpu_lk_ms"] > 0 and p["gpu_pyramid_ms"] > 0 and p["host_estimate_ms"] > 0
     assert p["key_frames"] >= 1
 

@@ -2,9 +2,9 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof_${1:-t}
+OUT=$R/gpurun_out/prof_${1:-probe}
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 300 --warmup 64 --no-cpu-baseline $BENCH_ARGS > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/tools/pipe_probe.py > $OUT/trace.log 2>&1
 python3 - <<PY
 import csv,glob
 for f in glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True):
@@ -12,4 +12,4 @@ for f in glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True):
         if "vstab::" in r["Name"]:
             print(f"{r['Name'][:60]:60s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:8.2f} min={float(r['MinNs'])/1e3:8.2f} max={float(r['MaxNs'])/1e3:8.2f}")
 PY
-tail -1 $OUT/trace.log | cut -c1-200
+grep us/frame $OUT/trace.log

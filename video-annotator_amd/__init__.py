@@ -41,7 +41,7 @@ _u8p, _i64, _u64 = _c.POINTER(_c.c_ubyte), _c.c_int64, _c.c_uint64
 
 class Frame(_c.Structure):  # vstab_frame
     _fields_ = [("y", _vp), ("uv", _vp), ("pitch_y", _sz), ("pitch_uv", _sz), ("width", _i), ("height", _i),
-                ("mem", _i), ("pts", _i64)]
+                ("mem", _i), ("pts", _i64), ("hold", _i)]
 
 
 PULL_FN = _c.CFUNCTYPE(_i, _vp, _c.POINTER(Frame))
@@ -67,7 +67,7 @@ class Profile(_c.Structure):  # vstab_profile
     _fields_ = [("frames_consumed", _c.c_long), ("frames_emitted", _c.c_long), ("key_frames", _c.c_long),
                 ("gpu_ingest_ms", _d), ("gpu_pyramid_ms", _d), ("gpu_corners_ms", _d), ("gpu_lk_ms", _d), ("gpu_warp_ms", _d),
                 ("host_corners_ms", _d), ("host_track_wait_ms", _d), ("host_estimate_ms", _d), ("host_smooth_ms", _d),
-                ("warp_launches", _c.c_long)]
+                ("warp_launches", _c.c_long), ("warp_timed", _c.c_long)]
 
 
 SMOOTHER_SG, SMOOTHER_KALMAN, SMOOTHER_NONE, SMOOTHER_FIXED = 0, 1, 2, 3
@@ -420,9 +420,10 @@ class Stabilizer:
                 yp, uvp, pitch, w, h = _planes(f)
                 o = out.contents
                 o.y, o.uv, o.pitch_y, o.pitch_uv, o.width, o.height, o.mem, o.pts = yp, uvp, pitch, pitch, w, h, 0, 0
+                o.hold = 12  # self._keep holds the last 16 tensors alive
                 if advance:
                     self._keep.append(f)
-                    if len(self._keep) > 8:
+                    if len(self._keep) > 16:
                         self._keep.pop(0)
                     state["next"] = None
                 return 0

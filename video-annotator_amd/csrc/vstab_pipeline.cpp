@@ -71,8 +71,10 @@ struct PinnedBuf {  // host memory the device can read and write directly (mappe
 // ---------------------------------------------------------------------------------------------
 // Tracker: device workspace for goodFeaturesToTrack + calcOpticalFlowPyrLK
 // ---------------------------------------------------------------------------------------------
-constexpr int PYR_SETS = 4;       // previous + current (in flight) + two prefetched frames
-constexpr int PREFETCH_DEPTH = 2;  // frames pulled from upstream ahead of the one being tracked
+constexpr int PYR_SETS = 10;       // previous + current (in flight) + the prefetched frames
+// frames pulled from upstream ahead of the one being tracked: deep enough that the speculative corner detection of a
+// key frame (137 us of kernels beside everything else + the host selection) is finished before its turn comes
+constexpr int PREFETCH_DEPTH = 8;
 
 class Tracker {
   public:
@@ -117,6 +119,7 @@ class Tracker {
         const int cell = (int)std::nearbyint(min_distance);
         const int gw = cell >= 1 ? (w_ + cell - 1) / cell : 0, gh = cell >= 1 ? (h_ + cell - 1) / cell : 0;
         const double md2 = min_distance * min_distance;
+        static thread_local std::vector<int> grid_head_, grid_next_;  // min-distance grid: per-cell lists of accepted corners
         if (cell >= 1) grid_head_.assign((size_t)gw * gh, -1), grid_next_.clear();
         // The greedy pass consumes candidates in sorted order and usually stops after a few hundred, so the
         // keys are sorted lazily in chunks: nth_element splits off the next `chunk` largest keys (O(n)),
@@ -195,6 +198,7 @@ class Tracker {
     // pinned memory behind them.  spec_finish() only has to wait for the event and run the host half.
     static constexpr unsigned int SPEC_CAP = 1u << 15;
     vstab_status spec_launch(const uint8_t *gray, size_t pitch, double quality, hipStream_t st, long tag) {
+        spec_join();  // (a previous asynchronous selection still reading the pinned buffer: never in practice)
         VSTAB_TRY(spec_eig_.ensure(sizeof(float) * (size_t)w_ * h_));
         VSTAB_TRY(spec_keys_.ensure(sizeof(unsigned long long) * SPEC_CAP));
         VSTAB_TRY(spec_small_.ensure(256));
@@ -211,8 +215,77 @@ class Tracker {
         return VSTAB_OK;
     }
     long spec_tag() const { return spec_tag_; }
+    // Host half of the speculative detection on a helper thread: waits for the kernels' results and runs the
+    // sort + minimum-distance pass, so that by the time the key frame comes its corners are simply there.
+    void spec_select_async(int max_corners, double min_distance) {
+        spec_join();
+        spec_state_.store(1, std::memory_order_release);
+        if (!spec_thread_started_) {
+            spec_thread_started_ = true;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            spec_thread_ = std::thread([this, dev] {
+                (void)hipSetDevice(dev);  // the handle's device, not the new thread's default
+                std::unique_lock<std::mutex> lk(spec_m_);
+                for (;;) {
+                    spec_cv_.wait(lk, [this] { return spec_job_ || spec_quit_; });
+                    if (spec_quit_) return;
+                    spec_job_ = false;
+                    lk.unlock();
+                    int result = 3;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    if (spec_ev_ && hipEventSynchronize(spec_ev_) == hipSuccess) {
+                        const auto t1 = std::chrono::steady_clock::now();
+                        const unsigned int n = *spec_host_.as<unsigned int>();
+                        if (n <= SPEC_CAP) {
+                            select_corners(reinterpret_cast<unsigned long long *>(spec_host_.as<uint8_t>() + 64), n, spec_max_, spec_dist_, spec_xy_);
+                            result = 2;
+                        }
+                        if (getenv("VSTAB_DEBUG_SPEC"))
+                            std::fprintf(stderr, "async selection: waited %.0f us for the detection, selected %zu of %u candidates in %.0f us\n",
+                                         std::chrono::duration<double, std::micro>(t1 - t0).count(), spec_xy_.size() / 2, n,
+                                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count());
+                    }
+                    spec_state_.store(result, std::memory_order_release);
+                    lk.lock();
+                }
+            });
+        }
+        {
+            std::lock_guard<std::mutex> lk(spec_m_);
+            spec_max_ = max_corners, spec_dist_ = min_distance, spec_job_ = true;
+        }
+        spec_cv_.notify_one();
+    }
+    // 0 = no asynchronous selection, 1 = running, 2 = corners ready, 3 = failed (candidate overflow / device error)
+    int spec_state() const { return spec_state_.load(std::memory_order_acquire); }
+    void spec_join() {
+        while (spec_state_.load(std::memory_order_acquire) == 1) std::this_thread::yield();
+    }
+    // take the asynchronously selected corners (state must be 2)
+    void spec_take(std::vector<float> &xy) {
+        xy = spec_xy_;
+        spec_state_.store(0, std::memory_order_release), spec_tag_ = -1;
+    }
+    ~Tracker() {
+        if (spec_thread_started_) {
+            {
+                std::lock_guard<std::mutex> lk(spec_m_);
+                spec_quit_ = true;
+            }
+            spec_cv_.notify_one();
+            spec_thread_.join();
+        }
+    }
     // returns true and fills xy if the speculative result is usable (candidate count within SPEC_CAP)
     bool spec_finish(int max_corners, double min_distance, std::vector<float> &xy) {
+        if (spec_state() != 0) {  // the helper thread has (or is about to have) the answer
+            spec_join();
+            const bool ok = spec_state() == 2;
+            if (ok) xy = spec_xy_;
+            spec_state_.store(0, std::memory_order_release), spec_tag_ = -1;
+            return ok;
+        }
         spec_tag_ = -1;
         if (!spec_ev_ || hipEventSynchronize(spec_ev_) != hipSuccess) return false;
         const unsigned int n = *spec_host_.as<unsigned int>();
@@ -223,47 +296,79 @@ class Tracker {
 
     // calcOpticalFlowPyrLK(prev, next, pts), split in two so the caller can enqueue more work behind the
     // kernel before blocking.  Points travel through mapped host memory: the kernel reads prev_pts and
-    // writes next_pts / status over the link directly (a few KB), and the host waits on a completion
-    // counter the kernel bumps per feature instead of paying a copy launch + stream-sync round trip.
+    // writes one self-validating record per feature over the link directly (a few KB), and the host polls
+    // the records' sequence tags instead of paying a copy launch + stream-sync round trip.
+    //
+    // Chained launches: the tracker of frame k+1 starts from the points the tracker of frame k ended on
+    // (FrameSourceWarp.cpp:427), so its launch can be enqueued right behind frame k's without waiting for
+    // the host: slot f reads its start point from the device copy of frame k's record f and lost slots stay
+    // lost.  Three record buffers rotate (in flight, chained behind it, being read by the host).
+    struct Launch {
+        int buf = -1, n_slots = 0;
+        uint32_t seq = 0;
+        bool chained = false, timed = false;
+    };
+    static constexpr int REC_BUFS = 3;
+
     vstab_status track_launch(const LkPyramid &I, const LkPyramid &J, const std::vector<float> &prev_xy, hipStream_t st,
-                              bool timed) {
-        pending_n_ = (int)(prev_xy.size() / 2);
-        pending_timed_ = timed;
-        const int n = pending_n_;
+                              bool timed, Launch &L) {
+        L = Launch();
+        L.n_slots = (int)(prev_xy.size() / 2), L.timed = timed;
+        const int n = L.n_slots;
         if (n == 0) return VSTAB_OK;
-        VSTAB_TRY(hpts_.ensure((size_t)n * (sizeof(float2) + 16)));
-        uint8_t *dbase = static_cast<uint8_t *>(hpts_.dev());
-        if (!dbase) return fail(VSTAB_ERR_DEVICE, "hipHostGetDevicePointer failed");
-        // layout: n records of 16 B, then n input points
-        std::memcpy(hpts_.as<uint8_t>() + 16 * (size_t)n, prev_xy.data(), sizeof(float) * prev_xy.size());
-        ++seq_;
+        L.buf = (int)(launches_++ % REC_BUFS), L.seq = ++seq_;
+        VSTAB_TRY(hrec_[L.buf].ensure((size_t)n * 16));
+        VSTAB_TRY(drec_[L.buf].ensure((size_t)n * 16));
+        VSTAB_TRY(hpts_.ensure((size_t)n * sizeof(float2)));
+        if (!hrec_[L.buf].dev() || !hpts_.dev()) return fail(VSTAB_ERR_DEVICE, "hipHostGetDevicePointer failed");
+        std::memcpy(hpts_.p, prev_xy.data(), sizeof(float) * prev_xy.size());
         if (timed && !ev_a_) (void)hipEventCreate(&ev_a_), (void)hipEventCreate(&ev_b_);
         if (timed) (void)hipEventRecord(ev_a_, st);
-        VSTAB_TRY(launch_lk(I, J, reinterpret_cast<const float2 *>(dbase + 16 * (size_t)n), n, nullptr, nullptr, dbase, seq_, st));
+        VSTAB_TRY(launch_lk(I, J, static_cast<const float2 *>(hpts_.dev()), n, nullptr, nullptr, hrec_[L.buf].dev(), L.seq, st, nullptr,
+                            drec_[L.buf].p, clock_slot()));
         if (timed) (void)hipEventRecord(ev_b_, st);
         return VSTAB_OK;
     }
 
-    vstab_status track_wait(std::vector<float> &next_xy, std::vector<uint8_t> &status, hipStream_t st, double *gpu_ms) {
-        const int n = pending_n_;
-        next_xy.assign(2 * (size_t)n, 0.f), status.assign(n, 0);
-        if (n == 0) return VSTAB_OK;
-        const volatile uint32_t *rec = hpts_.as<uint32_t>();
+    // the launch for the NEXT frame pair, chained behind `parent` (same slots; see above)
+    vstab_status track_launch_chained(const LkPyramid &I, const LkPyramid &J, const Launch &parent, hipStream_t st, Launch &L) {
+        L = Launch();
+        if (parent.n_slots == 0 || parent.buf < 0) return VSTAB_OK;
+        L.n_slots = parent.n_slots, L.chained = true;
+        L.buf = (int)(launches_++ % REC_BUFS), L.seq = ++seq_;
+        VSTAB_TRY(hrec_[L.buf].ensure((size_t)L.n_slots * 16));
+        VSTAB_TRY(drec_[L.buf].ensure((size_t)L.n_slots * 16));
+        if (!hrec_[L.buf].dev()) return fail(VSTAB_ERR_DEVICE, "hipHostGetDevicePointer failed");
+        return launch_lk(I, J, nullptr, L.n_slots, nullptr, nullptr, hrec_[L.buf].dev(), L.seq, st, drec_[parent.buf].p, drec_[L.buf].p,
+                         clock_slot());
+    }
+
+    // results of launch L in the order of the (compacted) point list it tracked: expect_n entries
+    vstab_status track_wait(const Launch &L, size_t expect_n, std::vector<float> &next_xy, std::vector<uint8_t> &status, hipStream_t st,
+                            double *gpu_ms) {
+        next_xy.clear(), status.clear();
+        next_xy.reserve(2 * expect_n), status.reserve(expect_n);
+        const int n = L.n_slots;
+        if (n == 0) return expect_n == 0 ? VSTAB_OK : fail(VSTAB_ERR_DEVICE, "tracker bookkeeping mismatch");
+        const volatile uint32_t *rec = hrec_[L.buf].as<uint32_t>();
         const auto t0 = std::chrono::steady_clock::now();
         unsigned long spins = 0;
         for (int i = 0; i < n; i++) {
-            while (__atomic_load_n(&rec[4 * i + 3], __ATOMIC_ACQUIRE) != seq_) {
+            while (__atomic_load_n(&rec[4 * i + 3], __ATOMIC_ACQUIRE) != L.seq) {
                 __builtin_ia32_pause();
                 if ((++spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
                     VSTAB_HIP_TRY(hipStreamSynchronize(st));  // surfaces a launch / execution error if there is one
-                    if (__atomic_load_n(&rec[4 * i + 3], __ATOMIC_ACQUIRE) != seq_) return fail(VSTAB_ERR_DEVICE, "LK kernel did not complete");
+                    if (__atomic_load_n(&rec[4 * i + 3], __ATOMIC_ACQUIRE) != L.seq) return fail(VSTAB_ERR_DEVICE, "LK kernel did not complete");
                 }
             }
-            uint32_t x = rec[4 * i], y = rec[4 * i + 1];
-            std::memcpy(&next_xy[2 * i], &x, 4), std::memcpy(&next_xy[2 * i + 1], &y, 4);
-            status[i] = (uint8_t)rec[4 * i + 2];
+            const uint32_t x = rec[4 * i], y = rec[4 * i + 1], s = rec[4 * i + 2];
+            if (s == 2u) continue;  // lost in an earlier frame of the chain: not part of this frame's point list
+            float fx, fy;
+            std::memcpy(&fx, &x, 4), std::memcpy(&fy, &y, 4);
+            next_xy.push_back(fx), next_xy.push_back(fy), status.push_back((uint8_t)s);
         }
-        if (pending_timed_ && gpu_ms) {
+        if (status.size() != expect_n) return fail(VSTAB_ERR_DEVICE, "tracker bookkeeping mismatch");
+        if (L.timed && gpu_ms) {
             float ms = 0;
             if (hipEventSynchronize(ev_b_) == hipSuccess && hipEventElapsedTime(&ms, ev_a_, ev_b_) == hipSuccess) *gpu_ms += ms;
         }
@@ -272,11 +377,50 @@ class Tracker {
 
     vstab_status track(const LkPyramid &I, const LkPyramid &J, const std::vector<float> &prev_xy, std::vector<float> &next_xy,
                        std::vector<uint8_t> &status, hipStream_t st, double *gpu_ms = nullptr) {
-        VSTAB_TRY(track_launch(I, J, prev_xy, st, gpu_ms != nullptr));
-        return track_wait(next_xy, status, st, gpu_ms);
+        Launch L;
+        VSTAB_TRY(track_launch(I, J, prev_xy, st, gpu_ms != nullptr, L));
+        return track_wait(L, prev_xy.size() / 2, next_xy, status, st, gpu_ms);
     }
 
     int levels() const { return levels_; }
+
+    // VSTAB_LK_CLOCK=1 (development aid): every LK launch stamps its first-workgroup start and last-workgroup end
+    // (100 MHz wall clock) into a slot of a mapped ring; report_clock() prints durations and start-to-start gaps
+    void *clock_slot() {
+        static const bool on = getenv("VSTAB_LK_CLOCK") != nullptr;
+        if (!on) return nullptr;
+        if (!clk_.p) {
+            if (clk_.ensure(sizeof(unsigned long long) * 2 * CLK_N) != VSTAB_OK) return nullptr;
+            std::vector<unsigned long long> init(2 * CLK_N, 0);
+            for (int i = 0; i < CLK_N; i++) init[2 * i] = ~0ull;
+            if (hipMemcpy(clk_.p, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        }
+        if (clk_used_ >= CLK_N) return nullptr;
+        return clk_.as<unsigned long long>() + 2 * (clk_used_++);
+    }
+    void report_clock() {
+        if (!clk_.p || clk_used_ < 200) return;
+        std::vector<unsigned long long> host(2 * CLK_N);
+        if (hipMemcpy(host.data(), clk_.p, sizeof(unsigned long long) * host.size(), hipMemcpyDeviceToHost) != hipSuccess) return;
+        const unsigned long long *c = host.data();
+        double dur = 0, gap = 0, idle = 0;
+        int n = 0;
+        for (int i = clk_used_ - 400 > 0 ? clk_used_ - 400 : 1; i < clk_used_; i++) {
+            if (c[2 * i + 1] == 0 || c[2 * i - 1] == 0) continue;
+            dur += (c[2 * i + 1] - c[2 * i]) * 0.01, gap += ((double)c[2 * i] - (double)c[2 * i - 2]) * 0.01, idle += ((double)c[2 * i] - (double)c[2 * i - 1]) * 0.01;
+            n++;
+        }
+        if (n) std::fprintf(stderr, "LK launches (last %d): duration %.1f us, start-to-start %.1f us, idle before start %.1f us\n", n, dur / n, gap / n, idle / n);
+        std::vector<double> idles, durs;
+        for (int i = clk_used_ - 400 > 0 ? clk_used_ - 400 : 1; i < clk_used_; i++)
+            if (c[2 * i + 1] && c[2 * i - 1]) idles.push_back(((double)c[2 * i] - (double)c[2 * i - 1]) * 0.01), durs.push_back((c[2 * i + 1] - c[2 * i]) * 0.01);
+        std::sort(idles.begin(), idles.end()), std::sort(durs.begin(), durs.end());
+        if (idles.size() > 10) {
+            const size_t m = idles.size();
+            std::fprintf(stderr, "  idle percentiles 10/50/90/99: %.1f %.1f %.1f %.1f   duration 10/50/90/99: %.1f %.1f %.1f %.1f\n", idles[m / 10], idles[m / 2],
+                         idles[m * 9 / 10], idles[m * 99 / 100], durs[m / 10], durs[m / 2], durs[m * 9 / 10], durs[m * 99 / 100]);
+        }
+    }
 
   private:
     int w_ = 0, h_ = 0, levels_ = 1;
@@ -286,12 +430,22 @@ class Tracker {
     PinnedBuf spec_host_;
     hipEvent_t spec_ev_ = nullptr;
     long spec_tag_ = -1;
-    std::vector<int> grid_head_, grid_next_;  // min-distance grid: per-cell singly linked lists of accepted corners
-    PinnedBuf hsmall_, hkeys_, hpts_;
+    std::thread spec_thread_;
+    bool spec_thread_started_ = false, spec_job_ = false, spec_quit_ = false;
+    std::mutex spec_m_;
+    std::condition_variable spec_cv_;
+    std::atomic<int> spec_state_{0};
+    int spec_max_ = 200;
+    double spec_dist_ = 30.0;
+    std::vector<float> spec_xy_;
+    static constexpr int CLK_N = 4096;
+    DevBuf clk_;
+    int clk_used_ = 0;
+    PinnedBuf hsmall_, hkeys_, hpts_, hrec_[REC_BUFS];
+    DevBuf drec_[REC_BUFS];
     unsigned int cap_ = 0;
     hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
-    int pending_n_ = 0;
-    bool pending_timed_ = false;
+    unsigned long launches_ = 0;
     uint32_t seq_ = 0;
 };
 
@@ -375,7 +529,6 @@ struct vstab_handle {
     hipStream_t stream = nullptr;   // caller-visible stream: the warp runs here, dst is complete when it drains
     hipStream_t tstream = nullptr;  // internal stream: corner detection + LK (the per-frame critical path)
     hipStream_t pstream = nullptr;  // internal stream: ingest + pyramid of the NEXT frame (prefetch, overlaps LK)
-    hipEvent_t pyr_done[PYR_SETS] = {};  // recorded on pstream after pyramid set k
     int w = 0, h = 0, ow = 0, oh = 0;
     Mat3 Kin, Kout;
     int map_mode = VSTAB_MAP_CREATEMAP_CL;  // createMap.cl for the preset path, a projection pair in lens mode
@@ -386,10 +539,43 @@ struct vstab_handle {
         DevBuf buf;  // packed NV12, pitch = w
         bool queued = false, last = false;
         long freed_at = 0;               // FIFO reuse: the slot idle the longest is taken first
-        hipEvent_t ingested = nullptr;   // recorded on tstream after the copy into the slot
-        hipEvent_t warped = nullptr;     // recorded on stream after the warp that read the slot
-        bool warp_pending = false;
+        hipEvent_t ingested = nullptr;   // recorded on pstream after the copy into the slot (and its pyramid, when tracking)
+        int warped = -1;                 // index into warp_events of the event recorded behind the warp that read the slot
+        bool warp_pending = false;       // a warp has read the slot since it was last filled
+        unsigned long ingest_serial = 0;  // which copy `ingested` was last recorded for
     };
+    struct PendingCopy {
+        int slot;
+        unsigned long serial;
+        int hold;
+    };
+    // Event operations are the expensive HIP calls here (measured on this runtime: hipEventRecord 4.4 us,
+    // hipStreamWaitEvent 3.4 us, a kernel launch 2.4 us, hipEventQuery 0.08 us), so the frame loop records as
+    // few as it can: one event per ingested frame (behind copy + pyramid), one event per WARP_EVENT_STRIDE
+    // warps (slots freed in between share the next one), and a stream only waits on an event that a host-side
+    // query says is still pending.
+    static constexpr int WARP_EVENT_STRIDE = 4, WARP_EVENT_POOL = 16;
+    hipEvent_t warp_events[WARP_EVENT_POOL] = {};
+    int warp_event_next = 0;
+    std::vector<int> uncovered;  // slots whose warp is enqueued but not yet followed by a recorded event
+    vstab_status cover_warps() {  // record one event behind every warp enqueued so far
+        if (uncovered.empty()) return VSTAB_OK;
+        const int e = warp_event_next++ % WARP_EVENT_POOL;
+        VSTAB_HIP_TRY(hipEventRecord(warp_events[e], stream));
+        for (int sl : uncovered) slots[sl].warped = e;
+        uncovered.clear();
+        return VSTAB_OK;
+    }
+    // make stream `waiter` wait for `ev` unless the host can already see that it has completed
+    static vstab_status wait_if_pending(hipStream_t waiter, hipEvent_t ev) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return VSTAB_OK;
+        if (q != hipErrorNotReady) VSTAB_HIP_TRY(q);
+        VSTAB_HIP_TRY(hipStreamWaitEvent(waiter, ev, 0));
+        return VSTAB_OK;
+    }
+    std::vector<PendingCopy> copies;  // device-frame copies upstream has not been promised to outlive yet
+    unsigned long ingest_serial = 0;
     long free_counter = 0;
     std::vector<Slot> slots;
     int last_slot = -1;  // m_last_input_frame
@@ -435,6 +621,7 @@ struct vstab_handle {
         return e;
     }
     void fold_pending() {
+        if (dstream) (void)hipStreamSynchronize(dstream);
         (void)hipStreamSynchronize(pstream);
         (void)hipStreamSynchronize(tstream);
         (void)hipStreamSynchronize(stream);
@@ -455,6 +642,15 @@ struct vstab_handle {
     };
     Tracked inflight, ready;
     bool have_inflight = false, have_ready = false, src_eof = false;
+    // LK launches: the one whose results the host waits for next, and the one chained behind it for the
+    // following frame (speculative: valid unless that frame turns out to be a key frame, :415)
+    Tracker::Launch inflight_launch, spec_launch;
+    long spec_frame = -1;        // frame index the chained launch tracks into; -1 = none
+    bool spec_is_key = false;    // that launch is a pre-launched key frame (fresh corners from the speculative detection)
+    std::vector<float> pre_corners;
+    hipStream_t dstream = nullptr;  // speculative corner detection (137 us of kernels every 21st frame) beside everything else
+    bool chain_lk = true;        // VSTAB_CHAIN_LK=0 disables chained launches
+    long chained_adopted = 0, chained_discarded = 0, key_prelaunched = 0;
     // a frame that has been pulled from upstream, copied into the ring and whose pyramid is being built
     std::deque<std::pair<int, int>> prefetched;  // (ring slot, pyramid set), oldest first
     long prefetch_count = 0;
@@ -475,7 +671,9 @@ struct GpuStage {  // records an event pair around a stage when profiling is on
     hipStream_t s;
     GpuStage(vstab_handle *h, int st)
         : H(h), stage(st), s(st == vstab_handle::ST_WARP ? h->stream : (st == vstab_handle::ST_INGEST || st == vstab_handle::ST_PYRAMID) ? h->pstream : h->tstream) {
-        if (H->profiling >= 2 || (H->profiling == 1 && st == vstab_handle::ST_WARP)) {
+        // level 1 times every 8th warp launch: two event records cost more host time than the launch itself
+        if (H->profiling >= 2 || (H->profiling == 1 && st == vstab_handle::ST_WARP && (H->prof.warp_launches & 7) == 0)) {
+            if (st == vstab_handle::ST_WARP) H->prof.warp_timed++;
             a = H->get_event();
             (void)hipEventRecord(a, s);
         }
@@ -489,6 +687,29 @@ struct GpuStage {  // records an event pair around a stage when profiling is on
         }
     }
 };
+// VSTAB_HOST_TIMING=1: wall time of the host-side steps of the pull loop, printed by vstab_destroy (development aid)
+struct HostTimers {
+    enum { PULL_CB, INGEST_SYNC, INGEST, PYRAMID, SPEC_DETECT, LK_LAUNCH, LK_CHAIN, WARP, TOTAL, N };
+    double ms[N] = {0};
+    long calls[N] = {0};
+    bool on = getenv("VSTAB_HOST_TIMING") != nullptr;
+    static const char *name(int i) {
+        static const char *n[N] = {"pull_cb", "ingest_sync", "ingest", "pyramid", "spec_detect", "lk_launch", "lk_chain", "warp", "pull_frame_total"};
+        return n[i];
+    }
+};
+static HostTimers g_ht;
+struct HT {
+    int i;
+    std::chrono::steady_clock::time_point t0;
+    explicit HT(int idx) : i(idx) {
+        if (g_ht.on) t0 = std::chrono::steady_clock::now();
+    }
+    ~HT() {
+        if (g_ht.on) g_ht.ms[i] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), g_ht.calls[i]++;
+    }
+};
+
 struct HostStage {
     double *sum;
     std::chrono::steady_clock::time_point t0;
@@ -502,13 +723,17 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
     vstab_handle::Slot &S = H->slots[slot];
     uint8_t *dst = S.buf.as<uint8_t>();
     if (S.warp_pending) {  // the warp that last read this slot runs on another stream
-        VSTAB_HIP_TRY(hipStreamWaitEvent(H->pstream, S.warped, 0));
-        S.warp_pending = false;
+        if (S.warped < 0) VSTAB_TRY(H->cover_warps());
+        VSTAB_TRY(vstab_handle::wait_if_pending(H->pstream, H->warp_events[S.warped]));
+        S.warp_pending = false, S.warped = -1;
     }
     // Copy + pyramid are full-GPU streaming kernels: running them beside the (VALU-bound, full-GPU) warp
     // only makes both slower.  Start them when the last warp has drained; what overlaps the warp is the
     // low-occupancy LK kernel.
-    if (H->last_warp_slot >= 0 && H->serialize_prefetch) VSTAB_HIP_TRY(hipStreamWaitEvent(H->pstream, H->slots[H->last_warp_slot].warped, 0));
+    if (H->last_warp_slot >= 0 && H->serialize_prefetch) {
+        VSTAB_TRY(H->cover_warps());
+        if (H->slots[H->last_warp_slot].warped >= 0) VSTAB_HIP_TRY(hipStreamWaitEvent(H->pstream, H->warp_events[H->slots[H->last_warp_slot].warped], 0));
+    }
     if (f.mem == 0) {
         VSTAB_TRY(vstab_pack_nv12(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->pstream));
     } else {
@@ -516,7 +741,7 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
         VSTAB_HIP_TRY(hipMemcpy2DAsync(dst + (size_t)H->w * H->h, H->w, f.uv, f.pitch_uv, H->w, H->h / 2, hipMemcpyHostToDevice, H->pstream));
         VSTAB_HIP_TRY(hipStreamSynchronize(H->pstream));  // the caller may reuse its host buffer on return
     }
-    VSTAB_HIP_TRY(hipEventRecord(S.ingested, H->pstream));
+    if (!H->cfg.tracking) VSTAB_HIP_TRY(hipEventRecord(S.ingested, H->pstream));  // tracking: recorded behind the pyramid instead
     return VSTAB_OK;
 }
 
@@ -538,8 +763,30 @@ static vstab_status prefetch_next(vstab_handle *H) {
     std::memset(&f, 0, sizeof(f));
     // the previous frame's copy into the ring may still be in flight; upstream is allowed to recycle
     // that frame's memory as soon as it is called again
-    if (H->last_ingest_slot >= 0) VSTAB_HIP_TRY(hipEventSynchronize(H->slots[H->last_ingest_slot].ingested));
-    const int rc = H->src.pull(H->src.user, &f);
+    {
+        // copies of frames whose planes upstream may recycle on this call must have finished (vstab_frame.hold)
+        HT t(HostTimers::INGEST_SYNC);
+        for (auto it = H->copies.begin(); it != H->copies.end();) {
+            if (it->hold > 0) {
+                it->hold--, ++it;
+                continue;
+            }
+            const vstab_handle::Slot &S = H->slots[it->slot];
+            if (S.ingest_serial == it->serial) {  // (a re-used slot's newer copy was enqueued behind this one: also done)
+                int spins = 0;
+                hipError_t q;
+                while ((q = hipEventQuery(S.ingested)) == hipErrorNotReady && ++spins < 20000) __builtin_ia32_pause();
+                if (q == hipErrorNotReady) q = hipEventSynchronize(S.ingested);
+                VSTAB_HIP_TRY(q);
+            }
+            it = H->copies.erase(it);
+        }
+    }
+    int rc;
+    {
+        HT t(HostTimers::PULL_CB);
+        rc = H->src.pull(H->src.user, &f);
+    }
     if (rc == VSTAB_EOF) {
         H->src_eof = true;
         return VSTAB_EOF;
@@ -547,14 +794,21 @@ static vstab_status prefetch_next(vstab_handle *H) {
     if (rc != 0) return fail(VSTAB_ERR_SOURCE, "upstream pull failed with " + std::to_string(rc));
     const int slot = H->acquire_slot();
     if (slot < 0) return fail(VSTAB_ERR_NOMEM, "look-ahead ring exhausted");
-    VSTAB_TRY(ingest(H, f, slot));
+    {
+        HT t(HostTimers::INGEST);
+        VSTAB_TRY(ingest(H, f, slot));
+    }
     H->last_ingest_slot = slot;
+    H->slots[slot].ingest_serial = ++H->ingest_serial;
+    // (frames promised to outlive a whole ring of pulls are not tracked: the ring slot itself is recycled sooner)
+    if (f.mem == 0 && f.hold < (int)H->slots.size()) H->copies.push_back({slot, H->ingest_serial, f.hold < 0 ? 0 : f.hold});
     H->slots[slot].queued = true;  // reserved from now on (released when its warp has been enqueued)
     const int pyr = (int)(H->prefetch_count % PYR_SETS);
     if (H->cfg.tracking) {
+        HT t(HostTimers::PYRAMID);
         GpuStage gs(H, vstab_handle::ST_PYRAMID);
         VSTAB_TRY(H->tracker.build_pyramid(pyr, H->gray(slot), (size_t)H->w, H->pstream));
-        VSTAB_HIP_TRY(hipEventRecord(H->pyr_done[pyr], H->pstream));
+        VSTAB_HIP_TRY(hipEventRecord(H->slots[slot].ingested, H->pstream));  // copy AND pyramid of this frame
     }
     // Key-frame rule, counter half (:415): the frame after this one re-detects corners on THIS frame when
     // (index + 1) - last_key > 20.  That is known now, so the detector runs here, on the prefetch stream,
@@ -565,7 +819,10 @@ static vstab_status prefetch_next(vstab_handle *H) {
     if (H->cfg.tracking && H->speculate && H->last_key != -1 && (H->prefetch_count + 1) - H->last_key == 21)
     {
         if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "spec launch for frame %ld (last_key %ld)\n", H->prefetch_count, H->last_key);
-        VSTAB_TRY(H->tracker.spec_launch(H->gray(slot), (size_t)H->w, 0.01, H->pstream, H->prefetch_count));
+        HT t(HostTimers::SPEC_DETECT);
+        VSTAB_HIP_TRY(hipStreamWaitEvent(H->dstream, H->slots[slot].ingested, 0));
+        VSTAB_TRY(H->tracker.spec_launch(H->gray(slot), (size_t)H->w, 0.01, H->dstream, H->prefetch_count));
+        H->tracker.spec_select_async(200, 30.0);
     }
     H->prefetched.emplace_back(slot, pyr);
     H->prefetch_count++;
@@ -591,7 +848,7 @@ static vstab_status launch_tracking(vstab_handle *H) {
     } else if (H->last_key == -1) {
         // :403-407 the first frame only seeds the corner set
         H->last_key = H->frame_index;
-        VSTAB_HIP_TRY(hipStreamWaitEvent(H->tstream, H->pyr_done[pyr], 0));
+        VSTAB_HIP_TRY(hipStreamWaitEvent(H->tstream, H->slots[slot].ingested, 0));
         {
             HostStage hs(&H->prof.host_corners_ms);
             VSTAB_TRY(H->tracker.good_features(g, pitch, 200, 0.01, 30.0, H->corners, H->tstream));
@@ -603,23 +860,66 @@ static vstab_status launch_tracking(vstab_handle *H) {
         T = vstab_handle::Tracked();
         T.slot = slot;
         const uint8_t *pg = H->gray(H->last_slot);
+        bool used_pre = false;
         // :415-419 key-frame rule; corners are found in the PREVIOUS gray frame
         if (H->frame_index - H->last_key > 20 || H->corners.size() / 2 < 150) {
             H->last_key = H->frame_index - 1;
             HostStage hs(&H->prof.host_corners_ms);
-            // the previous frame is frame_index - 1: use its speculative detection if there is one
-            const bool spec = H->tracker.spec_tag() == H->frame_index - 1 && H->tracker.spec_finish(200, 30.0, H->corners);
-            if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "key frame at %ld: spec_tag %ld used %d\n", H->frame_index, H->tracker.spec_tag(), (int)spec);
-            if (!spec) VSTAB_TRY(H->tracker.good_features(pg, pitch, 200, 0.01, 30.0, H->corners, H->tstream));
+            if (H->spec_frame == H->frame_index && H->spec_is_key) {
+                H->corners = H->pre_corners;  // this key frame's tracker is already running on them
+                used_pre = true;
+                H->key_prelaunched++;
+            } else {
+                // the previous frame is frame_index - 1: use its speculative detection if there is one
+                const bool spec = H->tracker.spec_tag() == H->frame_index - 1 && H->tracker.spec_finish(200, 30.0, H->corners);
+                if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "key frame at %ld: spec_tag %ld used %d\n", H->frame_index, H->tracker.spec_tag(), (int)spec);
+                if (!spec) VSTAB_TRY(H->tracker.good_features(pg, pitch, 200, 0.01, 30.0, H->corners, H->tstream));
+            }
             T.lg.key_frame = 1;
             H->prof.key_frames++;
         }
         T.lg.n_corners = (int)(H->corners.size() / 2);
         T.prev = H->corners;
-        VSTAB_HIP_TRY(hipStreamWaitEvent(H->tstream, H->pyr_done[pyr], 0));  // pyramid (and ring copy) of this frame
-        VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(H->cur_pyr, pg, pitch), H->tracker.pyramid(pyr, g, pitch), H->corners, H->tstream,
-                                          H->profiling >= 2));
+        if (H->spec_frame == H->frame_index && (H->spec_is_key ? used_pre : !T.lg.key_frame)) {
+            // the launch chained behind the previous frame's tracker is this frame's tracker: same points (the
+            // survivors, read on the device), same images
+            H->inflight_launch = H->spec_launch;
+            H->chained_adopted++;
+        } else {
+            if (H->spec_frame == H->frame_index) H->chained_discarded++;  // key frame after all: its results are ignored
+            HT t(HostTimers::LK_LAUNCH);
+            VSTAB_TRY(vstab_handle::wait_if_pending(H->tstream, H->slots[slot].ingested));  // pyramid (and ring copy) of this frame
+            VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(H->cur_pyr, pg, pitch), H->tracker.pyramid(pyr, g, pitch), H->corners,
+                                              H->tstream, H->profiling >= 2, H->inflight_launch));
+        }
+        H->spec_frame = -1, H->spec_is_key = false;
         H->have_inflight = true;
+        // Chain the NEXT frame's tracker behind this one if its frame is already in the ring and the counter
+        // half of the key-frame rule (:415) cannot fire for it; the count half (< 150 survivors) is checked
+        // when that frame's turn comes, and the chained launch is dropped if it does.
+        if (H->chain_lk && H->profiling < 2 && !H->prefetched.empty() && H->inflight_launch.n_slots > 0 &&
+            (H->frame_index + 1) - H->last_key <= 20) {
+            HT t(HostTimers::LK_CHAIN);
+            const int nslot = H->prefetched.front().first, npyr = H->prefetched.front().second;
+            VSTAB_TRY(vstab_handle::wait_if_pending(H->tstream, H->slots[nslot].ingested));
+            VSTAB_TRY(H->tracker.track_launch_chained(H->tracker.pyramid(pyr, g, pitch), H->tracker.pyramid(npyr, H->gray(nslot), pitch),
+                                                      H->inflight_launch, H->tstream, H->spec_launch));
+            H->spec_frame = H->frame_index + 1;
+        } else if (H->chain_lk && H->profiling < 2 && !H->prefetched.empty() && (H->frame_index + 1) - H->last_key > 20 &&
+                   H->tracker.spec_tag() == H->frame_index && H->tracker.spec_state() != 2) {
+            if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "frame %ld: selection not ready (state %d)\n", H->frame_index, H->tracker.spec_state());
+        } else if (H->chain_lk && H->profiling < 2 && !H->prefetched.empty() && (H->frame_index + 1) - H->last_key > 20 &&
+                   H->tracker.spec_tag() == H->frame_index && H->tracker.spec_state() == 2) {
+            // The next frame is a key frame by the counter, its corners (detected on THIS frame, speculatively) are
+            // already selected, and they do not depend on this frame's tracking at all: launch its tracker now.
+            HT t(HostTimers::LK_CHAIN);
+            H->tracker.spec_take(H->pre_corners);
+            const int nslot = H->prefetched.front().first, npyr = H->prefetched.front().second;
+            VSTAB_TRY(vstab_handle::wait_if_pending(H->tstream, H->slots[nslot].ingested));
+            VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(pyr, g, pitch), H->tracker.pyramid(npyr, H->gray(nslot), pitch), H->pre_corners,
+                                              H->tstream, false, H->spec_launch));
+            H->spec_frame = H->frame_index + 1, H->spec_is_key = true;
+        }
     }
     H->cur_pyr = pyr;
     H->prof.frames_consumed++;
@@ -640,7 +940,7 @@ static vstab_status finish_wait(vstab_handle *H) {
     std::vector<uint8_t> st;
     {
         HostStage hs(&H->prof.host_track_wait_ms);
-        VSTAB_TRY(H->tracker.track_wait(nxt, st, H->tstream, H->profiling >= 2 ? &H->prof.gpu_lk_ms : nullptr));
+        VSTAB_TRY(H->tracker.track_wait(H->inflight_launch, T.prev.size() / 2, nxt, st, H->tstream, H->profiling >= 2 ? &H->prof.gpu_lk_ms : nullptr));
     }
     // :261-268 keep pairs with status != 0
     for (size_t i = 0; i < st.size(); i++)
@@ -717,6 +1017,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (const char *e = getenv("VSTAB_SERIALIZE_PREFETCH")) H->serialize_prefetch = atoi(e) != 0;
     if (const char *e = getenv("VSTAB_SPECULATE")) H->speculate = atoi(e) != 0;
     if (const char *e = getenv("VSTAB_THREADED_ESTIMATE")) H->threaded_estimate = atoi(e) != 0;
+    if (const char *e = getenv("VSTAB_CHAIN_LK")) H->chain_lk = atoi(e) != 0;
     H->stream = static_cast<hipStream_t>(cfg->stream);  // NULL = the default stream, as for the stateless operators
     {
         // the tracking chain is the per-frame critical path; the warp only has to finish before the
@@ -727,7 +1028,9 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
         // copy + pyramid of the NEXT frame have a whole frame period of slack: lowest priority, so they fill
         // in behind the warp instead of taking its CUs
         VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, getenv("VSTAB_PSTREAM_HI") ? hi : lo));
-        for (auto &e : H->pyr_done) VSTAB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        // detection has to be ready before its key frame's turn, PREFETCH_DEPTH frame periods after it is enqueued
+        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->dstream, hipStreamNonBlocking, getenv("VSTAB_DSTREAM_LO") ? lo : (lo + hi) / 2));
+        for (auto &e : H->warp_events) VSTAB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // :214-219 peek the first frame for the input size, then derive both cameras
     vstab_frame f;
@@ -755,11 +1058,11 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     }
     if (H->ow <= 0 || H->oh <= 0 || H->ow > 32767 || H->oh > 32767) return fail(VSTAB_ERR_INVALID, "vstab_create: output size out of range");
     if (cfg->smoother == VSTAB_SMOOTHER_SG) H->sg.reset(new RotationFilterSG(cfg->smooth_radius));
-    H->slots.resize((size_t)cfg->smooth_radius + 5 + PREFETCH_DEPTH);  // queue (r+1) + ready + in flight + first/last gray + 2 spare for stream overlap
+    // queue (r+1) + ready + in flight + first/last gray + 2 spare for stream overlap + the slots that wait for a shared warp event
+    H->slots.resize((size_t)cfg->smooth_radius + 5 + PREFETCH_DEPTH + vstab_handle::WARP_EVENT_STRIDE);
     for (auto &s : H->slots) {
         VSTAB_TRY(s.buf.ensure((size_t)H->w * H->h * 3 / 2));
         VSTAB_HIP_TRY(hipEventCreateWithFlags(&s.ingested, hipEventDisableTiming));
-        VSTAB_HIP_TRY(hipEventCreateWithFlags(&s.warped, hipEventDisableTiming));
     }
     if (cfg->tracking) VSTAB_TRY(H->tracker.init(H->w, H->h));
     *out = H.release();
@@ -780,6 +1083,7 @@ vstab_status vstab_get_output_info(const vstab_handle *h, int *width, int *heigh
 // FrameSourceWarp::pull_frame, :452-476
 static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, size_t pitch_dst, void *dst_uv, size_t pitch_dst_uv) {
     if (!H || !dst || (out_format == VSTAB_OUT_NV12 && !dst_uv)) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: null argument");
+    HT t_total(HostTimers::TOTAL);
     while (H->queue.size() <= (size_t)H->cfg.smooth_radius) {  // :453
         // 1. LK results of the frame in flight -> surviving corners; its rotation estimate starts on the
         //    worker thread right away
@@ -831,7 +1135,8 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
     map_params(H->Kin, H->Kout, warp_R, p);
     vstab_handle::Slot &S = H->slots[slot];
     const uint8_t *nv12 = S.buf.as<uint8_t>();
-    VSTAB_HIP_TRY(hipStreamWaitEvent(H->stream, S.ingested, 0));  // the slot was filled on the prefetch stream
+    HT t_warp(HostTimers::WARP);
+    VSTAB_TRY(vstab_handle::wait_if_pending(H->stream, S.ingested));  // the slot was filled on the prefetch stream (long ago, as a rule)
     vstab_status st;
     {
         // the profiling events bracket the launch call and nothing else, so the interval is the kernel
@@ -840,8 +1145,9 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         st = vstab_warp_nv12_ex(nv12, (size_t)H->w, nv12 + (size_t)H->w * H->h, (size_t)H->w, H->w, H->h, p, H->map_mode, out_format, dst,
                                 pitch_dst, dst_uv, pitch_dst_uv, H->ow, H->oh, H->stream);
     }
-    VSTAB_HIP_TRY(hipEventRecord(S.warped, H->stream));  // the next ingest into this slot waits for it
-    S.warp_pending = true, S.queued = false, S.freed_at = ++H->free_counter;
+    S.warp_pending = true, S.warped = -1, S.queued = false, S.freed_at = ++H->free_counter;
+    H->uncovered.push_back(slot);  // the next ingest into this slot waits for an event recorded behind this warp
+    if ((int)H->uncovered.size() >= vstab_handle::WARP_EVENT_STRIDE) VSTAB_TRY(H->cover_warps());
     H->last_warp_slot = slot;
     return st;
 }
@@ -873,6 +1179,16 @@ vstab_status vstab_get_profile(vstab_handle *h, vstab_profile *out) {
 
 void vstab_destroy(vstab_handle *h) {
     if (!h) return;
+    if (g_ht.on) {
+        for (int i = 0; i < HostTimers::N; i++)
+            if (g_ht.calls[i]) std::fprintf(stderr, "host %-18s %8ld calls  %8.2f us/call\n", HostTimers::name(i), g_ht.calls[i], g_ht.ms[i] / g_ht.calls[i] * 1e3);
+        g_ht = HostTimers();
+    }
+    h->fold_pending();
+    h->tracker.report_clock();
+    if (getenv("VSTAB_DEBUG_SPEC"))
+        std::fprintf(stderr, "chained LK launches: adopted %ld, discarded %ld of %ld frames; key frames pre-launched %ld of %ld\n", h->chained_adopted,
+                     h->chained_discarded, h->frame_index, h->key_prelaunched, h->prof.key_frames);
     if (h->estimate_posted) {
         Mat3 r;
         (void)h->worker.join(r);
@@ -881,10 +1197,10 @@ void vstab_destroy(vstab_handle *h) {
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     for (auto &s : h->slots) {
         if (s.ingested) (void)hipEventDestroy(s.ingested);
-        if (s.warped) (void)hipEventDestroy(s.warped);
     }
-    for (auto e : h->pyr_done)
+    for (auto e : h->warp_events)
         if (e) (void)hipEventDestroy(e);
+    if (h->dstream) (void)hipStreamDestroy(h->dstream);
     if (h->pstream) (void)hipStreamDestroy(h->pstream);
     if (h->tstream) (void)hipStreamDestroy(h->tstream);
     delete h;
@@ -919,6 +1235,7 @@ static int ring_fill(vstab_ring_source *s, vstab_frame *out) {
     const uint8_t *p = static_cast<const uint8_t *>(s->frames[(size_t)(s->pos % (long)s->frames.size())]);
     out->y = p, out->uv = p + s->pitch * s->h, out->pitch_y = out->pitch_uv = s->pitch;
     out->width = s->w, out->height = s->h, out->mem = 0, out->pts = s->pos;
+    out->hold = 1 << 30;  // the caller owns the frames for the life of the source and never rewrites them
     return 0;
 }
 static int ring_pull(void *user, vstab_frame *out) {

@@ -251,14 +251,35 @@ __device__ __forceinline__ void lk_block_sums(LkExchange &ex, int parity, int wa
 
 __global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid J, const float2 *__restrict__ prev_pts,
                                                          int n, float2 *__restrict__ next_pts, uint8_t *__restrict__ status,
-                                                         uint4 *__restrict__ host_rec, unsigned int seq) {
+                                                         uint4 *__restrict__ host_rec, unsigned int seq,
+                                                         const uint4 *__restrict__ chain_in, uint4 *__restrict__ dev_rec,
+                                                         unsigned long long *__restrict__ clk) {
     __shared__ int regI[LKR * LKR];
     __shared__ int derx[LKT * LKT], dery[LKT * LKT];
     __shared__ int regJ[LKJR * LKJR];
     __shared__ LkExchange ex;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (f >= n) return;
-    const float2 pp = prev_pts[f];
+    // development aid (VSTAB_LK_CLOCK): first workgroup start / last workgroup end on the 100 MHz wall clock
+    if (clk && tid == 0) atomicMin(&clk[0], wall_clock64());
+    float2 pp;
+    if (chain_in) {
+        // chained launch: this slot's input is the record the previous launch wrote for it -- the point it
+        // tracked to, if it survived (status 1).  Slots that were lost earlier stay lost (status 2) and are
+        // skipped by the host, which is exactly the status filter of FrameSourceWarp.cpp:261-268.
+        const uint4 r = chain_in[f];
+        if (r.z != 1u) {  // uniform for the workgroup, before any barrier
+            if (tid == 0) {
+                const uint4 dead = make_uint4(0u, 0u, 2u, seq);
+                if (dev_rec) dev_rec[f] = dead;
+                if (host_rec) host_rec[f] = dead;
+            }
+            return;
+        }
+        pp = make_float2(__uint_as_float(r.x), __uint_as_float(r.y));
+    } else {
+        pp = prev_pts[f];
+    }
     float2 np = make_float2(0.f, 0.f);
     int st = 1, parity = 0;
     const float half = (LKW - 1) * 0.5f;
@@ -401,8 +422,11 @@ __global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid 
         if (host_rec) {
             // one self-validating 16-byte record per feature in coherent (uncached) host memory: data and
             // sequence tag leave in a single store, so no fence or counter is needed and the host simply
-            // polls the tags
-            host_rec[f] = make_uint4(__float_as_uint(np.x), __float_as_uint(np.y), (unsigned int)st, seq);
+            // polls the tags.  The device copy feeds a chained launch for the next frame.
+            const uint4 rec = make_uint4(__float_as_uint(np.x), __float_as_uint(np.y), (unsigned int)st, seq);
+            if (dev_rec) dev_rec[f] = rec;
+            host_rec[f] = rec;
+            if (clk) atomicMax(&clk[1], wall_clock64());
         } else {
             next_pts[f] = np;
             status[f] = (uint8_t)st;
@@ -444,9 +468,12 @@ vstab_status launch_corner_candidates(const float *eig, int w, int h, const int 
 }
 
 vstab_status launch_lk(const LkPyramid &I, const LkPyramid &J, const float2 *prev_pts, int n, float2 *next_pts,
-                       uint8_t *status, void *host_records, unsigned int seq, hipStream_t s) {
+                       uint8_t *status, void *host_records, unsigned int seq, hipStream_t s, const void *chain_in,
+                       void *dev_records, void *clock_pair) {
     if (n <= 0) return VSTAB_OK;
-    hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(LK_THREADS), 0, s, I, J, prev_pts, n, next_pts, status, static_cast<uint4 *>(host_records), seq);
+    if (!prev_pts && !chain_in) return fail(VSTAB_ERR_INVALID, "launch_lk: no input points");
+    hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(LK_THREADS), 0, s, I, J, prev_pts, n, next_pts, status, static_cast<uint4 *>(host_records), seq,
+                       static_cast<const uint4 *>(chain_in), static_cast<uint4 *>(dev_records), static_cast<unsigned long long *>(clock_pair));
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }

@@ -34,7 +34,11 @@ vstab_status launch_corner_candidates(const float *eig, int w, int h, const int 
                                       unsigned long long *keys, unsigned int *count, unsigned int cap, hipStream_t s);
 // host_records (may be NULL): n 16-byte records {x, y, status, seq} in mapped host memory, written instead
 // of next_pts / status so the host can poll for completion without a stream synchronisation
+// chain_in (may be NULL): the device records of the previous frame's launch; slot f then starts from the point that
+// launch tracked it to (status 1) or reports status 2 ("lost earlier") without tracking.  dev_records (may be NULL):
+// device copy of the records for the launch chained behind this one.
 vstab_status launch_lk(const LkPyramid &I, const LkPyramid &J, const float2 *prev_pts, int n, float2 *next_pts,
-                       uint8_t *status, void *host_records, unsigned int seq, hipStream_t s);
+                       uint8_t *status, void *host_records, unsigned int seq, hipStream_t s, const void *chain_in = nullptr,
+                       void *dev_records = nullptr, void *clock_pair = nullptr);
 
 }  // namespace vstab
