@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=600)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--workload", default="4k", choices=["4k", "1080p"])
     ap.add_argument("--mode", default="auto", choices=["auto", "warp", "pipeline"])
     ap.add_argument("--ring", type=int, default=64, help="distinct input frames / output buffers")

@@ -536,7 +536,12 @@ struct vstab_handle {
     Tracker tracker;
 
     struct Slot {
-        DevBuf buf;  // packed NV12, pitch = w
+        DevBuf buf;  // packed NV12, pitch = w (allocated on the first copy into the slot)
+        // where the frame's planes are: in buf, or still in upstream's memory when upstream promised (vstab_frame.hold)
+        // that they outlive the frame's whole stay in the pipeline -- then nothing is copied at all
+        const uint8_t *y = nullptr, *uv = nullptr;
+        size_t pitch_y = 0, pitch_uv = 0;
+        bool borrowed = false;
         bool queued = false, last = false;
         long freed_at = 0;               // FIFO reuse: the slot idle the longest is taken first
         hipEvent_t ingested = nullptr;   // recorded on pstream after the copy into the slot (and its pyramid, when tracking)
@@ -661,7 +666,10 @@ struct vstab_handle {
             if (!slots[i].queued && !slots[i].last && (best < 0 || slots[i].freed_at < slots[best].freed_at)) best = (int)i;
         return best;
     }
-    const uint8_t *gray(int s) const { return slots[s].buf.as<uint8_t>(); }
+    const uint8_t *gray(int s) const { return slots[s].y; }
+    size_t gpitch(int s) const { return slots[s].pitch_y; }
+    int borrow_hold = 0;  // vstab_frame.hold from which a device frame is used in place (set in vstab_create)
+    long frames_borrowed = 0, frames_copied = 0;
 };
 
 struct GpuStage {  // records an event pair around a stage when profiling is on
@@ -721,7 +729,17 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
     GpuStage gs(H, vstab_handle::ST_INGEST);
     if (f.width != H->w || f.height != H->h) return fail(VSTAB_ERR_INVALID, "frame size changed mid-stream");
     vstab_handle::Slot &S = H->slots[slot];
+    if (f.mem == 0 && f.hold >= H->borrow_hold) {
+        // zero copy: track, build the pyramid from and warp upstream's planes where they are
+        S.y = static_cast<const uint8_t *>(f.y), S.uv = static_cast<const uint8_t *>(f.uv), S.pitch_y = f.pitch_y, S.pitch_uv = f.pitch_uv;
+        S.borrowed = true, S.warp_pending = false, S.warped = -1;
+        H->frames_borrowed++;
+        return VSTAB_OK;  // (S.ingested keeps its completed state from the slot's previous use; tracking records it behind the pyramid)
+    }
+    VSTAB_TRY(S.buf.ensure((size_t)H->w * H->h * 3 / 2));
     uint8_t *dst = S.buf.as<uint8_t>();
+    S.y = dst, S.uv = dst + (size_t)H->w * H->h, S.pitch_y = S.pitch_uv = (size_t)H->w, S.borrowed = false;
+    H->frames_copied++;
     if (S.warp_pending) {  // the warp that last read this slot runs on another stream
         if (S.warped < 0) VSTAB_TRY(H->cover_warps());
         VSTAB_TRY(vstab_handle::wait_if_pending(H->pstream, H->warp_events[S.warped]));
@@ -801,13 +819,14 @@ static vstab_status prefetch_next(vstab_handle *H) {
     H->last_ingest_slot = slot;
     H->slots[slot].ingest_serial = ++H->ingest_serial;
     // (frames promised to outlive a whole ring of pulls are not tracked: the ring slot itself is recycled sooner)
-    if (f.mem == 0 && f.hold < (int)H->slots.size()) H->copies.push_back({slot, H->ingest_serial, f.hold < 0 ? 0 : f.hold});
+    if (f.mem == 0 && !H->slots[slot].borrowed && f.hold < (int)H->slots.size())
+        H->copies.push_back({slot, H->ingest_serial, f.hold < 0 ? 0 : f.hold});
     H->slots[slot].queued = true;  // reserved from now on (released when its warp has been enqueued)
     const int pyr = (int)(H->prefetch_count % PYR_SETS);
     if (H->cfg.tracking) {
         HT t(HostTimers::PYRAMID);
         GpuStage gs(H, vstab_handle::ST_PYRAMID);
-        VSTAB_TRY(H->tracker.build_pyramid(pyr, H->gray(slot), (size_t)H->w, H->pstream));
+        VSTAB_TRY(H->tracker.build_pyramid(pyr, H->gray(slot), H->gpitch(slot), H->pstream));
         VSTAB_HIP_TRY(hipEventRecord(H->slots[slot].ingested, H->pstream));  // copy AND pyramid of this frame
     }
     // Key-frame rule, counter half (:415): the frame after this one re-detects corners on THIS frame when
@@ -821,7 +840,7 @@ static vstab_status prefetch_next(vstab_handle *H) {
         if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "spec launch for frame %ld (last_key %ld)\n", H->prefetch_count, H->last_key);
         HT t(HostTimers::SPEC_DETECT);
         VSTAB_HIP_TRY(hipStreamWaitEvent(H->dstream, H->slots[slot].ingested, 0));
-        VSTAB_TRY(H->tracker.spec_launch(H->gray(slot), (size_t)H->w, 0.01, H->dstream, H->prefetch_count));
+        VSTAB_TRY(H->tracker.spec_launch(H->gray(slot), H->gpitch(slot), 0.01, H->dstream, H->prefetch_count));
         H->tracker.spec_select_async(200, 30.0);
     }
     H->prefetched.emplace_back(slot, pyr);
@@ -834,7 +853,7 @@ static vstab_status prefetch_next(vstab_handle *H) {
 static vstab_status launch_tracking(vstab_handle *H) {
     const int slot = H->prefetched.front().first, pyr = H->prefetched.front().second;
     H->prefetched.pop_front();
-    const size_t pitch = (size_t)H->w;
+    const size_t pitch = H->gpitch(slot);
     const uint8_t *g = H->gray(slot);
     if (!H->cfg.tracking) {
         // undistort-only mode (BASELINE config 1): every frame gets the identity rotation
@@ -860,6 +879,7 @@ static vstab_status launch_tracking(vstab_handle *H) {
         T = vstab_handle::Tracked();
         T.slot = slot;
         const uint8_t *pg = H->gray(H->last_slot);
+        const size_t ppitch = H->gpitch(H->last_slot);
         bool used_pre = false;
         // :415-419 key-frame rule; corners are found in the PREVIOUS gray frame
         if (H->frame_index - H->last_key > 20 || H->corners.size() / 2 < 150) {
@@ -873,7 +893,7 @@ static vstab_status launch_tracking(vstab_handle *H) {
                 // the previous frame is frame_index - 1: use its speculative detection if there is one
                 const bool spec = H->tracker.spec_tag() == H->frame_index - 1 && H->tracker.spec_finish(200, 30.0, H->corners);
                 if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "key frame at %ld: spec_tag %ld used %d\n", H->frame_index, H->tracker.spec_tag(), (int)spec);
-                if (!spec) VSTAB_TRY(H->tracker.good_features(pg, pitch, 200, 0.01, 30.0, H->corners, H->tstream));
+                if (!spec) VSTAB_TRY(H->tracker.good_features(pg, ppitch, 200, 0.01, 30.0, H->corners, H->tstream));
             }
             T.lg.key_frame = 1;
             H->prof.key_frames++;
@@ -889,7 +909,7 @@ static vstab_status launch_tracking(vstab_handle *H) {
             if (H->spec_frame == H->frame_index) H->chained_discarded++;  // key frame after all: its results are ignored
             HT t(HostTimers::LK_LAUNCH);
             VSTAB_TRY(vstab_handle::wait_if_pending(H->tstream, H->slots[slot].ingested));  // pyramid (and ring copy) of this frame
-            VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(H->cur_pyr, pg, pitch), H->tracker.pyramid(pyr, g, pitch), H->corners,
+            VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(H->cur_pyr, pg, ppitch), H->tracker.pyramid(pyr, g, pitch), H->corners,
                                               H->tstream, H->profiling >= 2, H->inflight_launch));
         }
         H->spec_frame = -1, H->spec_is_key = false;
@@ -902,7 +922,7 @@ static vstab_status launch_tracking(vstab_handle *H) {
             HT t(HostTimers::LK_CHAIN);
             const int nslot = H->prefetched.front().first, npyr = H->prefetched.front().second;
             VSTAB_TRY(vstab_handle::wait_if_pending(H->tstream, H->slots[nslot].ingested));
-            VSTAB_TRY(H->tracker.track_launch_chained(H->tracker.pyramid(pyr, g, pitch), H->tracker.pyramid(npyr, H->gray(nslot), pitch),
+            VSTAB_TRY(H->tracker.track_launch_chained(H->tracker.pyramid(pyr, g, pitch), H->tracker.pyramid(npyr, H->gray(nslot), H->gpitch(nslot)),
                                                       H->inflight_launch, H->tstream, H->spec_launch));
             H->spec_frame = H->frame_index + 1;
         } else if (H->chain_lk && H->profiling < 2 && !H->prefetched.empty() && (H->frame_index + 1) - H->last_key > 20 &&
@@ -916,7 +936,7 @@ static vstab_status launch_tracking(vstab_handle *H) {
             H->tracker.spec_take(H->pre_corners);
             const int nslot = H->prefetched.front().first, npyr = H->prefetched.front().second;
             VSTAB_TRY(vstab_handle::wait_if_pending(H->tstream, H->slots[nslot].ingested));
-            VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(pyr, g, pitch), H->tracker.pyramid(npyr, H->gray(nslot), pitch), H->pre_corners,
+            VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(pyr, g, pitch), H->tracker.pyramid(npyr, H->gray(nslot), H->gpitch(nslot)), H->pre_corners,
                                               H->tstream, false, H->spec_launch));
             H->spec_frame = H->frame_index + 1, H->spec_is_key = true;
         }
@@ -1061,9 +1081,10 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     // queue (r+1) + ready + in flight + first/last gray + 2 spare for stream overlap + the slots that wait for a shared warp event
     H->slots.resize((size_t)cfg->smooth_radius + 5 + PREFETCH_DEPTH + vstab_handle::WARP_EVENT_STRIDE);
     for (auto &s : H->slots) {
-        VSTAB_TRY(s.buf.ensure((size_t)H->w * H->h * 3 / 2));
         VSTAB_HIP_TRY(hipEventCreateWithFlags(&s.ingested, hipEventDisableTiming));
     }
+    // a frame stays in the pipeline from its pull until its warp: read-ahead + look-ahead queue + the frames in between
+    H->borrow_hold = getenv("VSTAB_ALWAYS_COPY") ? (1 << 30) + 1 : cfg->smooth_radius + PREFETCH_DEPTH + 6;
     if (cfg->tracking) VSTAB_TRY(H->tracker.init(H->w, H->h));
     *out = H.release();
     return VSTAB_OK;
@@ -1134,7 +1155,7 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
     float p[17];
     map_params(H->Kin, H->Kout, warp_R, p);
     vstab_handle::Slot &S = H->slots[slot];
-    const uint8_t *nv12 = S.buf.as<uint8_t>();
+
     HT t_warp(HostTimers::WARP);
     VSTAB_TRY(vstab_handle::wait_if_pending(H->stream, S.ingested));  // the slot was filled on the prefetch stream (long ago, as a rule)
     vstab_status st;
@@ -1142,12 +1163,15 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         // the profiling events bracket the launch call and nothing else, so the interval is the kernel
         // (plus its dispatch), not host work between two API calls
         GpuStage gs(H, vstab_handle::ST_WARP);
-        st = vstab_warp_nv12_ex(nv12, (size_t)H->w, nv12 + (size_t)H->w * H->h, (size_t)H->w, H->w, H->h, p, H->map_mode, out_format, dst,
+        st = vstab_warp_nv12_ex(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, p, H->map_mode, out_format, dst,
                                 pitch_dst, dst_uv, pitch_dst_uv, H->ow, H->oh, H->stream);
     }
-    S.warp_pending = true, S.warped = -1, S.queued = false, S.freed_at = ++H->free_counter;
-    H->uncovered.push_back(slot);  // the next ingest into this slot waits for an event recorded behind this warp
-    if ((int)H->uncovered.size() >= vstab_handle::WARP_EVENT_STRIDE) VSTAB_TRY(H->cover_warps());
+    S.queued = false, S.freed_at = ++H->free_counter;
+    if (!S.borrowed) {
+        S.warp_pending = true, S.warped = -1;
+        H->uncovered.push_back(slot);  // the next copy into this slot waits for an event recorded behind this warp
+        if ((int)H->uncovered.size() >= vstab_handle::WARP_EVENT_STRIDE) VSTAB_TRY(H->cover_warps());
+    }
     H->last_warp_slot = slot;
     return st;
 }
@@ -1186,6 +1210,8 @@ void vstab_destroy(vstab_handle *h) {
     }
     h->fold_pending();
     h->tracker.report_clock();
+    if (getenv("VSTAB_DEBUG_SPEC"))
+        std::fprintf(stderr, "frames used in place %ld, copied into the ring %ld\n", h->frames_borrowed, h->frames_copied);
     if (getenv("VSTAB_DEBUG_SPEC"))
         std::fprintf(stderr, "chained LK launches: adopted %ld, discarded %ld of %ld frames; key frames pre-launched %ld of %ld\n", h->chained_adopted,
                      h->chained_discarded, h->frame_index, h->key_prelaunched, h->prof.key_frames);
