@@ -249,3 +249,69 @@ def test_pipeline_at_1080p_baseline_config(vs, cuda):
     for i in range(n - 1):
         p = oracle.map_params(K, Ko, stab.warp_rotation(i))
         assert np.array_equal(outs[i], oracle.warp_nv12(frames[i + 1], p, cw, ch)), i
+
+
+def _run_raw_device_source(vs, cuda, frames, hold, recycle, **cfg_kw):
+    """Drive the raw C ABI with a device-frame source.  recycle: upstream owns ONE surface and overwrites it with
+    the next frame inside every pull callback (a decoder recycling its output surface)."""
+    import ctypes
+    import torch
+    n = len(frames)
+    dev = [torch.from_numpy(f).to(cuda) for f in frames]
+    surface = torch.empty_like(dev[0])
+    state = {"i": 0, "loaded": -1}
+
+    def fill(out, advance):
+        i = state["i"]
+        if i >= n:
+            return vs.EOF
+        if recycle:
+            if state["loaded"] != i:
+                surface.copy_(dev[i])                       # rewrites the memory handed out by the previous callback
+                torch.cuda.synchronize()
+                state["loaded"] = i
+            t = surface
+        else:
+            t = dev[i]
+        o = out.contents
+        o.y, o.uv = t.data_ptr(), t.data_ptr() + H * t.stride(0)
+        o.pitch_y = o.pitch_uv = t.stride(0)
+        o.width, o.height, o.mem, o.pts, o.hold = W, H, 0, i, hold
+        if advance:
+            state["i"] += 1
+        return 0
+    pull = vs.PULL_FN(lambda u, o: fill(o, True))
+    peek = vs.PULL_FN(lambda u, o: fill(o, False))
+    src = vs.Source(pull, peek, None)
+    cfg = vs.default_config(**cfg_kw)
+    h = ctypes.c_void_p()
+    assert vs.lib.vstab_create(ctypes.byref(cfg), ctypes.byref(src), ctypes.byref(h)) == vs.OK
+    ow, oh = ctypes.c_int(), ctypes.c_int()
+    assert vs.lib.vstab_get_output_info(h, ctypes.byref(ow), ctypes.byref(oh), None, None) == vs.OK
+    outs = []
+    while True:
+        o = torch.empty((oh.value, ow.value, 3), dtype=torch.uint8, device=cuda)
+        st = vs.lib.vstab_pull_frame(h, o.data_ptr(), o.stride(0))
+        if st == vs.EOF:
+            break
+        assert st == vs.OK, vs.lib.vstab_last_error()
+        outs.append(o.cpu().numpy())
+    vs.lib.vstab_destroy(h)
+    return outs
+
+
+def test_frame_lifetime_promise_hold(vs, cuda, clip):
+    """vstab_frame.hold: a source that recycles one surface every pull (hold = 0, the default contract) and a source
+    that keeps every frame alive (frames used in place, never copied) must produce the same stream."""
+    K, frames, _ = clip
+    n = 16
+    ref_stab, ref = run_product(vs, cuda, frames[:n], smooth_radius=3, seed=9)      # ring source: frames used in place
+    for hold, recycle in [(0, True), (2, False), (1 << 20, False)]:
+        outs = _run_raw_device_source(vs, cuda, frames[:n], hold, recycle, smooth_radius=3, seed=9)
+        assert len(outs) == len(ref) == n - 1, (hold, recycle)
+        for i, (a, b) in enumerate(zip(outs, ref)):
+            assert np.array_equal(a, b), (hold, recycle, i)
+    # tracking off: nothing but the copy orders the stages
+    ref_stab, ref = run_product(vs, cuda, frames[:n], smooth_radius=3, tracking=0)
+    outs = _run_raw_device_source(vs, cuda, frames[:n], 0, True, smooth_radius=3, tracking=0)
+    assert len(outs) == len(ref) and all(np.array_equal(a, b) for a, b in zip(outs, ref))
