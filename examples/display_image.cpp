@@ -33,7 +33,8 @@ class SyntheticSource : public vstab::NV12FrameSource {  // stands in for FrameS
     vstab::NV12Frame peek_frame() override {
         if (left_ <= 0) throw (int)EOF;
         const unsigned char *p = static_cast<const unsigned char *>(frames_[idx_ % frames_.size()]);
-        return vstab::NV12Frame{p, p + (size_t)w_ * h_, (size_t)w_, (size_t)w_, w_, h_, false};
+        // hold: these frames live as long as the source, so the library uses them in place (no copy into its ring)
+        return vstab::NV12Frame{p, p + (size_t)w_ * h_, (size_t)w_, (size_t)w_, w_, h_, false, 1 << 20};
     }
     vstab::NV12Frame pull_frame() override {
         vstab::NV12Frame f = peek_frame();

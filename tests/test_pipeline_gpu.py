@@ -315,3 +315,17 @@ def test_frame_lifetime_promise_hold(vs, cuda, clip):
     ref_stab, ref = run_product(vs, cuda, frames[:n], smooth_radius=3, tracking=0)
     outs = _run_raw_device_source(vs, cuda, frames[:n], 0, True, smooth_radius=3, tracking=0)
     assert len(outs) == len(ref) and all(np.array_equal(a, b) for a, b in zip(outs, ref))
+
+
+def test_cpp_adapter_example_runs(vs, cuda):
+    """examples/display_image.cpp: the reference's DisplayImage loop on include/vstab_frame_source.hpp (same class
+    name, constructor arguments and thrown-int EOF).  Built by __graft_entry__.build(); exit code 0 = n - 1 frames."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "display_image")
+    if not os.path.exists(exe):
+        pytest.skip("examples/display_image not built (run __graft_entry__.build())")
+    r = subprocess.run([exe, "50"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "49 frames of" in r.stderr and "opencv-warped:" in r.stderr          # Profiler.cpp:25-34 output format
