@@ -34,7 +34,9 @@ class SyntheticSource : public vstab::NV12FrameSource {  // stands in for FrameS
         if (left_ <= 0) throw (int)EOF;
         const unsigned char *p = static_cast<const unsigned char *>(frames_[idx_ % frames_.size()]);
         // hold: these frames live as long as the source, so the library uses them in place (no copy into its ring)
-        return vstab::NV12Frame{p, p + (size_t)w_ * h_, (size_t)w_, (size_t)w_, w_, h_, false, 1 << 20};
+        vstab::NV12Frame f{p, p + (size_t)w_ * h_, (size_t)w_, (size_t)w_, w_, h_};
+        f.hold = 1 << 20;
+        return f;
     }
     vstab::NV12Frame pull_frame() override {
         vstab::NV12Frame f = peek_frame();

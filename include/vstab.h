@@ -84,6 +84,11 @@ VSTAB_API vstab_status vstab_pack_nv12(const void *y, size_t pitch_y, const void
 
 /* Replaces cvtColor(COLOR_YUV2BGR_NV12), FrameSourceWarp.cpp:401.  dst is BGR8, pitch_dst bytes
  * per row (>= 3*width). */
+/* 10-bit input (BASELINE config 5): P010 / P016 planes -- 16-bit little-endian samples, significant bits at the top,
+ * pitches in bytes -- narrowed to packed 8-bit NV12 (byte = sample >> 8), which the rest of the path works on.
+ * No reference counterpart: the reference only accepts 8-bit NV12 (FrameSourceFfmpegOpenCl.cpp:53-56). */
+VSTAB_API vstab_status vstab_pack_p010(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv,
+                                       int width, int height, void *dst_packed_nv12, void *stream);
 VSTAB_API vstab_status vstab_cvt_nv12_bgr(const void *y, size_t pitch_y, const void *uv,
                                           size_t pitch_uv, int width, int height, void *dst_bgr,
                                           size_t pitch_dst, void *stream);
@@ -207,6 +212,8 @@ typedef struct vstab_frame {
     int width, height; /* luma size; both even */
     int mem;           /* 0 = device memory, 1 = host memory */
     int64_t pts;
+    int bit_depth;     /* 0 or 8: 8-bit NV12.  10 / 12 / 16: P010-style planes (16-bit little-endian samples, significant
+                          bits at the top, pitches in bytes), narrowed to 8 bits on ingest (vstab_pack_p010). */
     int hold;          /* how many FURTHER pull callbacks these planes stay valid and unchanged for.  0 (default): only
                           until the next callback -- the library then waits for its copy of this frame to finish before
                           it calls upstream again (a decoder that recycles one output surface).  Ref-counted or pooled

@@ -47,6 +47,8 @@ def lib():
         L.vo_set_num_threads.argtypes = [c.c_int]
         L.vo_pack_nv12.argtypes = [u8p, c.c_size_t, u8p, c.c_size_t, c.c_int, c.c_int, u8p]
         L.vo_pack_nv12.restype = c.c_int
+        L.vo_pack_p010.argtypes = [u8p, c.c_size_t, u8p, c.c_size_t, c.c_int, c.c_int, u8p]
+        L.vo_pack_p010.restype = c.c_int
         L.vo_cvt_nv12_bgr.argtypes = [u8p, c.c_int, c.c_int, u8p]
         L.vo_atanf.argtypes = [c.c_float]
         L.vo_atanf.restype = c.c_float
@@ -116,6 +118,18 @@ def pack_nv12(y, uv):
     uu, up = _u8(uv)
     dst = np.empty((h * 3 // 2, w), np.uint8)
     rc = lib().vo_pack_nv12(yp, yy.strides[0], up, uu.strides[0], w, h, _p(dst, ctypes.c_uint8))
+    if rc:
+        raise ValueError("Mismatched image dimensions")
+    return dst
+
+
+def pack_p010(y16, uv16):
+    """P010-style planes ((h, >=w) and (h/2, >=w) uint16 views) -> packed 8-bit NV12 by truncation."""
+    h, w = y16.shape
+    a = np.ascontiguousarray(y16, dtype=np.uint16)
+    b = np.ascontiguousarray(uv16, dtype=np.uint16)
+    dst = np.empty((h * 3 // 2, w), np.uint8)
+    rc = lib().vo_pack_p010(_p(a, ctypes.c_uint8), a.strides[0], _p(b, ctypes.c_uint8), b.strides[0], w, h, _p(dst, ctypes.c_uint8))
     if rc:
         raise ValueError("Mismatched image dimensions")
     return dst

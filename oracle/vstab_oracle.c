@@ -101,6 +101,18 @@ VO_API void vo_cvt_nv12_bgr(const uint8_t *nv12, int w, int h, uint8_t *bgr) {
     }
 }
 
+/* 10-bit input (BASELINE config 5, no reference counterpart): P010 / P016 planes -- 16-bit little-endian
+ * samples with the significant bits at the top, pitches in bytes -- narrowed to packed 8-bit NV12 by
+ * truncation (sample >> 8).  DEFINED here; the rest of the path is the reference's 8-bit path. */
+VO_API int vo_pack_p010(const uint8_t *y, size_t pitch_y, const uint8_t *uv, size_t pitch_uv, int w, int h, uint8_t *dst) {
+    if (w <= 0 || h <= 0 || (w & 1) || (h & 1)) return -1;
+    for (int r = 0; r < h + h / 2; r++) {
+        const uint8_t *s = r < h ? y + (size_t)r * pitch_y : uv + (size_t)(r - h) * pitch_uv;
+        for (int c = 0; c < w; c++) dst[(size_t)r * w + c] = (uint8_t)(((unsigned)s[2 * c] | ((unsigned)s[2 * c + 1] << 8)) >> 8);
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * atan used by the map.  OpenCL leaves atan() implementation defined (<= 5 ulp); the x86
  * build of the reference kernel (oracle/_ref) uses libm atanf.  To let a GPU kernel match

@@ -219,3 +219,13 @@ def test_state_machine_output_count_and_lag():
         outs.append(o)
     assert outs == list(range(1, n))
     assert sm.frame_index == n
+
+
+def test_pack_p010_is_truncation_to_the_high_byte():
+    rng = np.random.default_rng(1)
+    y = rng.integers(0, 65536, (6, 12), dtype=np.uint16)
+    uv = rng.integers(0, 65536, (3, 12), dtype=np.uint16)
+    out = oracle.pack_p010(y[:, 2:10], uv[:, 2:10])              # pitched views
+    assert np.array_equal(out[:6], (y[:, 2:10] >> 8).astype(np.uint8)) and np.array_equal(out[6:], (uv[:, 2:10] >> 8).astype(np.uint8))
+    with pytest.raises(ValueError):
+        oracle.pack_p010(y[:, :7], uv[:, :7])

@@ -251,14 +251,20 @@ def test_pipeline_at_1080p_baseline_config(vs, cuda):
         assert np.array_equal(outs[i], oracle.warp_nv12(frames[i + 1], p, cw, ch)), i
 
 
-def _run_raw_device_source(vs, cuda, frames, hold, recycle, **cfg_kw):
+def _run_raw_device_source(vs, cuda, frames, hold, recycle, p010=False, **cfg_kw):
     """Drive the raw C ABI with a device-frame source.  recycle: upstream owns ONE surface and overwrites it with
     the next frame inside every pull callback (a decoder recycling its output surface)."""
     import ctypes
     import torch
     n = len(frames)
-    dev = [torch.from_numpy(f).to(cuda) for f in frames]
+    if p010:   # 10 significant bits at the top of 16-bit samples, low 6 bits filled with junk that must be ignored
+        rng = np.random.default_rng(0)
+        wide = [((f.astype(np.uint16) << 8) | rng.integers(0, 256, f.shape, dtype=np.uint16)).view(np.int16) for f in frames]
+        dev = [torch.from_numpy(x).to(cuda) for x in wide]
+    else:
+        dev = [torch.from_numpy(f).to(cuda) for f in frames]
     surface = torch.empty_like(dev[0])
+    esz = 2 if p010 else 1
     state = {"i": 0, "loaded": -1}
 
     def fill(out, advance):
@@ -274,9 +280,9 @@ def _run_raw_device_source(vs, cuda, frames, hold, recycle, **cfg_kw):
         else:
             t = dev[i]
         o = out.contents
-        o.y, o.uv = t.data_ptr(), t.data_ptr() + H * t.stride(0)
-        o.pitch_y = o.pitch_uv = t.stride(0)
-        o.width, o.height, o.mem, o.pts, o.hold = W, H, 0, i, hold
+        o.y, o.uv = t.data_ptr(), t.data_ptr() + H * t.stride(0) * esz
+        o.pitch_y = o.pitch_uv = t.stride(0) * esz
+        o.width, o.height, o.mem, o.pts, o.hold, o.bit_depth = W, H, 0, i, hold, (10 if p010 else 8)
         if advance:
             state["i"] += 1
         return 0
@@ -329,3 +335,12 @@ def test_cpp_adapter_example_runs(vs, cuda):
     r = subprocess.run([exe, "50"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "49 frames of" in r.stderr and "opencv-warped:" in r.stderr          # Profiler.cpp:25-34 output format
+
+
+def test_p010_input_equals_8bit_input_of_the_truncated_frames(vs, cuda, clip):
+    """BASELINE config 5 input format: 16-bit planes are narrowed (sample >> 8) on ingest, then the 8-bit path runs."""
+    K, frames, _ = clip
+    n = 12
+    ref_stab, ref = run_product(vs, cuda, frames[:n], smooth_radius=3, seed=9)
+    outs = _run_raw_device_source(vs, cuda, frames[:n], 1 << 20, False, p010=True, smooth_radius=3, seed=9)
+    assert len(outs) == len(ref) and all(np.array_equal(a, b) for a, b in zip(outs, ref))

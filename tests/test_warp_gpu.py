@@ -37,6 +37,19 @@ def test_pack_nv12_pitched_and_unaligned(vs, cuda):
         assert np.array_equal(out, oracle.pack_nv12(ybuf[:, off:off + w], uvbuf[:, off:off + w]))
 
 
+def test_pack_p010_narrowing(vs, cuda):
+    import torch
+    rng = np.random.default_rng(3)
+    for w, h, pitch, off in [(64, 36, 64, 0), (1920, 1080, 1920, 0), (30, 18, 37, 3), (72, 20, 80, 4)]:
+        yb = rng.integers(0, 65536, (h, pitch + off), dtype=np.uint16)
+        ub = rng.integers(0, 65536, (h // 2, pitch + off), dtype=np.uint16)
+        yd, ud = torch.from_numpy(yb.view(np.int16)).to(cuda), torch.from_numpy(ub.view(np.int16)).to(cuda)
+        got = vs.pack_p010(yd[:, off:off + w], ud[:, off:off + w]).cpu().numpy()
+        assert np.array_equal(got, oracle.pack_p010(yb[:, off:off + w], ub[:, off:off + w])), (w, h, pitch, off)
+    with pytest.raises(vs.VstabError):
+        vs.pack_p010(yd[:, :31], ud[:, :31])
+
+
 def test_cvt_nv12_bgr_bit_exact(vs, cuda):
     kat = np.load(os.path.join(GOLD, "oracle_kat.npz"))
     assert np.array_equal(vs.cvt_nv12_bgr(dev(kat["cvt_nv12"], cuda)).cpu().numpy(), kat["cvt_bgr"])

@@ -41,7 +41,7 @@ _u8p, _i64, _u64 = _c.POINTER(_c.c_ubyte), _c.c_int64, _c.c_uint64
 
 class Frame(_c.Structure):  # vstab_frame
     _fields_ = [("y", _vp), ("uv", _vp), ("pitch_y", _sz), ("pitch_uv", _sz), ("width", _i), ("height", _i),
-                ("mem", _i), ("pts", _i64), ("hold", _i)]
+                ("mem", _i), ("pts", _i64), ("bit_depth", _i), ("hold", _i)]
 
 
 PULL_FN = _c.CFUNCTYPE(_i, _vp, _c.POINTER(Frame))
@@ -86,6 +86,7 @@ SIGNATURES = {
     "vstab_fisheye_undistort_points": (_i, [_dp, _i, _dp, _dp, _dp, _dp]),
     "vstab_map_params": (None, [_dp, _dp, _dp, _fp]),
     "vstab_pack_nv12": (_i, [_vp, _sz, _vp, _sz, _i, _i, _vp, _vp]),
+    "vstab_pack_p010": (_i, [_vp, _sz, _vp, _sz, _i, _i, _vp, _vp]),
     "vstab_cvt_nv12_bgr": (_i, [_vp, _sz, _vp, _sz, _i, _i, _vp, _sz, _vp]),
     "vstab_create_map": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _vp]),
     "vstab_remap_bilinear": (_i, [_vp, _sz, _i, _i, _i, _vp, _sz, _vp, _sz, _vp, _sz, _i, _i, _vp]),
@@ -221,6 +222,17 @@ def pack_nv12(y, uv):
     dst = torch.empty((h * 3 // 2, w), dtype=torch.uint8, device=y.device)
     _check(_L.vstab_pack_nv12(y.data_ptr(), y.stride(0), uv.data_ptr(), uv.stride(0), w, h, dst.data_ptr(),
                               _stream()), "vstab_pack_nv12")
+    return dst
+
+
+def pack_p010(y16, uv16):
+    """y16: (h, >=w) uint16/int16 view of the luma plane, uv16: (h/2, >=w) view of the interleaved chroma plane
+    (P010: significant bits at the top) -> packed 8-bit NV12 (h*3/2, w)."""
+    import torch
+    h, w = y16.shape
+    dst = torch.empty((h * 3 // 2, w), dtype=torch.uint8, device=y16.device)
+    _check(_L.vstab_pack_p010(y16.data_ptr(), y16.stride(0) * 2, uv16.data_ptr(), uv16.stride(0) * 2, w, h, dst.data_ptr(),
+                              _stream()), "vstab_pack_p010")
     return dst
 
 

@@ -729,7 +729,11 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
     GpuStage gs(H, vstab_handle::ST_INGEST);
     if (f.width != H->w || f.height != H->h) return fail(VSTAB_ERR_INVALID, "frame size changed mid-stream");
     vstab_handle::Slot &S = H->slots[slot];
-    if (f.mem == 0 && f.hold >= H->borrow_hold) {
+    const bool wide = f.bit_depth > 8;
+    if (f.bit_depth != 0 && f.bit_depth != 8 && f.bit_depth != 10 && f.bit_depth != 12 && f.bit_depth != 16)
+        return fail(VSTAB_ERR_INVALID, "vstab_frame.bit_depth must be 8, 10, 12 or 16");
+    if (wide && f.mem != 0) return fail(VSTAB_ERR_INVALID, "16-bit frames must be in device memory");
+    if (f.mem == 0 && !wide && f.hold >= H->borrow_hold) {
         // zero copy: track, build the pyramid from and warp upstream's planes where they are
         S.y = static_cast<const uint8_t *>(f.y), S.uv = static_cast<const uint8_t *>(f.uv), S.pitch_y = f.pitch_y, S.pitch_uv = f.pitch_uv;
         S.borrowed = true, S.warp_pending = false, S.warped = -1;
@@ -752,7 +756,9 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
         VSTAB_TRY(H->cover_warps());
         if (H->slots[H->last_warp_slot].warped >= 0) VSTAB_HIP_TRY(hipStreamWaitEvent(H->pstream, H->warp_events[H->slots[H->last_warp_slot].warped], 0));
     }
-    if (f.mem == 0) {
+    if (wide) {
+        VSTAB_TRY(vstab_pack_p010(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->pstream));
+    } else if (f.mem == 0) {
         VSTAB_TRY(vstab_pack_nv12(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->pstream));
     } else {
         VSTAB_HIP_TRY(hipMemcpy2DAsync(dst, H->w, f.y, f.pitch_y, H->w, H->h, hipMemcpyHostToDevice, H->pstream));

@@ -35,6 +35,32 @@ __global__ void __launch_bounds__(256) k_pack_nv12(const uint8_t *__restrict__ y
 }
 
 // =============================================================================================
+// k_pack_p010 -- 10-bit input (BASELINE config 5: P010 / P016 planes, 16-bit little-endian samples with the
+// significant bits at the top) narrowed to the 8-bit packed NV12 the reference path works on: byte = sample >> 8.
+// No reference counterpart (the reference only ever sees 8-bit NV12, FrameSourceFfmpegOpenCl.cpp:53-56).
+// One thread narrows 8 samples (one 16-B load, one 8-B store) when everything is aligned, else one sample.
+// =============================================================================================
+template <bool VEC>
+__global__ void __launch_bounds__(256) k_pack_p010(const uint8_t *__restrict__ y, size_t pitch_y,
+                                                   const uint8_t *__restrict__ uv, size_t pitch_uv, int row_units,
+                                                   int h, uint8_t *__restrict__ dst, size_t pitch_dst) {
+    const int rows = h + h / 2;
+    const long total = (long)rows * row_units;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(e / row_units), i = (int)(e - (long)row * row_units);
+        const uint8_t *s = row < h ? y + (size_t)row * pitch_y : uv + (size_t)(row - h) * pitch_uv;
+        uint8_t *d = dst + (size_t)row * pitch_dst;
+        if constexpr (VEC) {
+            const uint4 v = reinterpret_cast<const uint4 *>(s)[i];
+            const uint32_t lo = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u), hi = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u);
+            reinterpret_cast<uint2 *>(d)[i] = make_uint2(lo, hi);
+        } else {
+            d[i] = s[2 * i + 1];  // high byte of the little-endian sample
+        }
+    }
+}
+
+// =============================================================================================
 // k_cvt_nv12_bgr -- cvtColor(COLOR_YUV2BGR_NV12), FrameSourceWarp.cpp:401.  Compatibility /
 // parity kernel (the fused path never materialises the BGR frame).  One thread converts an
 // 8 x 2 luma block: two 8-B luma loads, one 8-B chroma load, two 24-B BGR stores.
@@ -531,6 +557,28 @@ vstab_status vstab_pack_nv12(const void *y, size_t pitch_y, const void *uv, size
         dim3 grid(std::min<unsigned>(div_up((unsigned)((long)width * rows), 256), 1024));
         hipLaunchKernelGGL(k_pack_nv12<uint8_t>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y,
                            (const uint8_t *)uv, pitch_uv, width, height, (uint8_t *)dst, (size_t)width);
+    }
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+vstab_status vstab_pack_p010(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width, int height,
+                             void *dst, void *stream) {
+    if (!y || !uv || !dst) return fail(VSTAB_ERR_INVALID, "vstab_pack_p010: null pointer");
+    if (width <= 0 || height <= 0 || (width & 1) || (height & 1)) return fail(VSTAB_ERR_INVALID, "Mismatched image dimensions");
+    if (pitch_y < (size_t)width * 2 || pitch_uv < (size_t)width * 2) return fail(VSTAB_ERR_INVALID, "vstab_pack_p010: pitch smaller than row");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rows = height + height / 2;
+    const bool vec = aligned(y, 16) && aligned(uv, 16) && aligned(dst, 8) && pitch_y % 16 == 0 && pitch_uv % 16 == 0 && width % 8 == 0;
+    if (vec) {
+        const int units = width / 8;
+        dim3 grid(std::min<unsigned>(div_up((unsigned)((long)units * rows), 256), 2048));
+        hipLaunchKernelGGL(k_pack_p010<true>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y, (const uint8_t *)uv, pitch_uv, units, height,
+                           (uint8_t *)dst, (size_t)width);
+    } else {
+        dim3 grid(std::min<unsigned>(div_up((unsigned)((long)width * rows), 256), 2048));
+        hipLaunchKernelGGL(k_pack_p010<false>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y, (const uint8_t *)uv, pitch_uv, width, height,
+                           (uint8_t *)dst, (size_t)width);
     }
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
