@@ -344,3 +344,30 @@ def test_p010_input_equals_8bit_input_of_the_truncated_frames(vs, cuda, clip):
     ref_stab, ref = run_product(vs, cuda, frames[:n], smooth_radius=3, seed=9)
     outs = _run_raw_device_source(vs, cuda, frames[:n], 1 << 20, False, p010=True, smooth_radius=3, seed=9)
     assert len(outs) == len(ref) and all(np.array_equal(a, b) for a, b in zip(outs, ref))
+
+
+def test_two_handles_interleaved_are_independent(vs, cuda, clip):
+    """One handle = one clip; handles share nothing: pulling two clips alternately gives
+    each the stream it gives alone."""
+    import torch
+    K, frames, _ = clip
+    a_frames, b_frames = frames[:14], [np.ascontiguousarray(f[:, ::-1]) for f in frames[3:17]]   # second clip: mirrored, shifted in time
+    _, ref_a = run_product(vs, cuda, a_frames, smooth_radius=3, seed=1)
+    _, ref_b = run_product(vs, cuda, b_frames, smooth_radius=4, seed=2)
+    sa = vs.Stabilizer([torch.from_numpy(f).to(cuda) for f in a_frames], total=len(a_frames), smooth_radius=3, seed=1)
+    sb = vs.Stabilizer([torch.from_numpy(f).to(cuda) for f in b_frames], total=len(b_frames), smooth_radius=4, seed=2)
+    outs_a, outs_b = [], []
+    done_a = done_b = False
+    while not (done_a and done_b):
+        if not done_a:
+            o = sa.pull()
+            done_a = o is None
+            if o is not None:
+                outs_a.append(o.cpu().numpy())
+        if not done_b:
+            o = sb.pull()
+            done_b = o is None
+            if o is not None:
+                outs_b.append(o.cpu().numpy())
+    assert len(outs_a) == len(ref_a) and all(np.array_equal(x, y) for x, y in zip(outs_a, ref_a))
+    assert len(outs_b) == len(ref_b) and all(np.array_equal(x, y) for x, y in zip(outs_b, ref_b))
