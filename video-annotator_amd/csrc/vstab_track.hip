@@ -249,14 +249,43 @@ __device__ __forceinline__ void lk_block_sums(LkExchange &ex, int parity, int wa
     }
 }
 
+// Staging in two phases -- every global load of a block is issued before the first LDS store waits for one -- so
+// a block costs ONE memory latency instead of one per loop trip.  The tracker is a dependent chain at one
+// workgroup per CU: exposed latency is what it is made of (measured: staging was half of a workgroup's time).
+template <int SIDE>
+struct LkStage {
+    static constexpr int N = (SIDE * SIDE + LK_THREADS - 1) / LK_THREADS;
+    int v[N];
+    __device__ __forceinline__ void load(const uint8_t *img, uint32_t pitch, int w, int h, int x0, int y0, int tid) {
+        const bool interior = x0 >= 0 && y0 >= 0 && x0 + SIDE <= w && y0 + SIDE <= h;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const int e = tid + LK_THREADS * k;
+            v[k] = 0;
+            if (e < SIDE * SIDE) {
+                const int ry = e / SIDE, rx = e - ry * SIDE;
+                v[k] = interior ? img[(uint32_t)(y0 + ry) * pitch + (uint32_t)(x0 + rx)]
+                                : img[(uint32_t)reflect101(y0 + ry, h) * pitch + (uint32_t)reflect101(x0 + rx, w)];
+            }
+        }
+    }
+    __device__ __forceinline__ void store(int *dst, int tid) const {
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const int e = tid + LK_THREADS * k;
+            if (e < SIDE * SIDE) dst[e] = v[k];
+        }
+    }
+};
+
 __global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid J, const float2 *__restrict__ prev_pts,
                                                          int n, float2 *__restrict__ next_pts, uint8_t *__restrict__ status,
                                                          uint4 *__restrict__ host_rec, unsigned int seq,
                                                          const uint4 *__restrict__ chain_in, uint4 *__restrict__ dev_rec,
                                                          unsigned long long *__restrict__ clk) {
-    __shared__ int regI[LKR * LKR];
+    __shared__ int regI[LK_MAX_LEVELS][LKR * LKR];
     __shared__ int derx[LKT * LKT], dery[LKT * LKT];
-    __shared__ int regJ[LKJR * LKJR];
+    __shared__ int regJ[2][LKJR * LKJR];
     __shared__ LkExchange ex;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (f >= n) return;
@@ -292,131 +321,168 @@ __global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid 
         const int wy = k / LKW, wx = k - wy * LKW;
         woff[m] = k < LKW * LKW ? (wy << 8) | wx : -1;
     }
-    for (int level = max_level; level >= 0; level--) {
-        const uint8_t *img = I.img[level], *jmg = J.img[level];
-        const int w = I.w[level], h = I.h[level];
-        const uint32_t ipitch = (uint32_t)I.pitch[level], jpitch = (uint32_t)J.pitch[level];
-        const float lscale = (float)(1.0 / (double)(1 << level));
-        float ppx = pp.x * lscale, ppy = pp.y * lscale;
-        float npx, npy;
-        if (level == max_level)
-            npx = ppx, npy = ppy;
-        else
-            npx = np.x * 2.0f, npy = np.y * 2.0f;
-        np = make_float2(npx, npy);
-        ppx -= half, ppy -= half;
-        const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
-        if (ipx < -LKW || ipx >= w || ipy < -LKW || ipy >= h) {
-            if (level == 0) st = 0;
-            continue;
-        }
-        float a = ppx - (float)ipx, b = ppy - (float)ipy;
-        int iw00 = (int)rintf((1.f - a) * (1.f - b) * 16384.f);
-        int iw01 = (int)rintf(a * (1.f - b) * 16384.f);
-        int iw10 = (int)rintf((1.f - a) * b * 16384.f);
-        int iw11 = 16384 - iw00 - iw01 - iw10;
-        __syncthreads();  // previous level's readers are done with LDS
-        {
-            const bool interior = ipx >= 1 && ipy >= 1 && ipx + LKR - 1 <= w && ipy + LKR - 1 <= h;
-            for (int e = tid; e < LKR * LKR; e += LK_THREADS) {
-                const int ry = e / LKR, rx = e - ry * LKR;
-                const int Y = ipy - 1 + ry, X = ipx - 1 + rx;
-                regI[e] = interior ? img[(uint32_t)Y * ipitch + (uint32_t)X]
-                                   : img[(uint32_t)reflect101(Y, h) * ipitch + (uint32_t)reflect101(X, w)];
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < LKT * LKT; e += LK_THREADS) {
-            const int tyy = e / LKT, txx = e - tyy * LKT;
-            const int X = ipx + txx, Y = ipy + tyy;
-            int dx = 0, dy = 0;
-            if (X >= 0 && Y >= 0 && X < w && Y < h) {
-                const int *c = &regI[(tyy + 1) * LKR + (txx + 1)];
-                const int t0m = (c[-LKR - 1] + c[LKR - 1]) * 3 + c[-1] * 10, t0p = (c[-LKR + 1] + c[LKR + 1]) * 3 + c[1] * 10;
-                const int t1m = c[LKR - 1] - c[-LKR - 1], t1c = c[LKR] - c[-LKR], t1p = c[LKR + 1] - c[-LKR + 1];
-                dx = (short)(t0p - t0m), dy = (short)((t1p + t1m) * 3 + t1c * 10);
-            }
-            derx[e] = dx, dery[e] = dy;
-        }
-        __syncthreads();
-        short Iw[2], Ixw[2], Iyw[2];
-        int pA[3] = {0, 0, 0};  // per-lane partial sums: 2 * 4080^2 < 2^26
+    // Everything whose address is known now is loaded now, in one exposed latency: the previous-image neighbourhood
+    // of EVERY level (it depends on the feature position only) and the top level's next-image block.  The block of
+    // each lower level is fetched one level ahead, while the level above computes, around the zero-flow position;
+    // if the Gauss-Newton window ends up outside it, the block is staged again around the window (as before).
+    // Where a block is staged never changes a value: it holds image bytes either way.
+    int jb = 0;                                   // regJ[jb] holds the block staged for the level about to run
+    int jorg_x = INT_MIN / 2, jorg_y = INT_MIN / 2;  // its origin (none yet)
+    {
+        LkStage<LKR> si[LK_MAX_LEVELS];
+        LkStage<LKJR> sj;
+        bool iok[LK_MAX_LEVELS];
 #pragma unroll
-        for (int m = 0; m < 2; m++) {
-            Iw[m] = Ixw[m] = Iyw[m] = 0;
-            if (woff[m] >= 0) {
-                const int wy = woff[m] >> 8, wx = woff[m] & 255;
-                const int *c = &regI[(wy + 1) * LKR + (wx + 1)];
-                const int ival = LK_DESCALE(c[0] * iw00 + c[1] * iw01 + c[LKR] * iw10 + c[LKR + 1] * iw11, 9);
-                const int d = wy * LKT + wx;
-                const int ixval = LK_DESCALE(derx[d] * iw00 + derx[d + 1] * iw01 + derx[d + LKT] * iw10 + derx[d + LKT + 1] * iw11, 14);
-                const int iyval = LK_DESCALE(dery[d] * iw00 + dery[d + 1] * iw01 + dery[d + LKT] * iw10 + dery[d + LKT + 1] * iw11, 14);
-                Iw[m] = (short)ival, Ixw[m] = (short)ixval, Iyw[m] = (short)iyval;
-                pA[0] += ixval * ixval, pA[1] += ixval * iyval, pA[2] += iyval * iyval;
+        for (int l = 0; l < LK_MAX_LEVELS; l++) {
+            iok[l] = false;
+            if (l > max_level) continue;
+            const float lscale = (float)(1.0 / (double)(1 << l));
+            const int ipx = (int)floorf(pp.x * lscale - half), ipy = (int)floorf(pp.y * lscale - half);
+            if (ipx < -LKW || ipx >= I.w[l] || ipy < -LKW || ipy >= I.h[l]) continue;  // the level loop skips it too
+            iok[l] = true;
+            si[l].load(I.img[l], (uint32_t)I.pitch[l], I.w[l], I.h[l], ipx - 1, ipy - 1, tid);
+            if (l == max_level) {  // the top level starts at the feature position itself
+                jorg_x = ipx - LKJM, jorg_y = ipy - LKJM;
+                sj.load(J.img[l], (uint32_t)J.pitch[l], I.w[l], I.h[l], jorg_x, jorg_y, tid);
             }
         }
-        float sA[3];
-        lk_block_sums<3>(ex, parity, wave, lane, pA, sA);
-        parity ^= 1;
-        const float FLT_SCALE = 1.0f / (1 << 20);
-        const float A11 = sA[0] * FLT_SCALE, A12 = sA[1] * FLT_SCALE, A22 = sA[2] * FLT_SCALE;
-        float D = A11 * A22 - A12 * A12;
-        const float minEig = ((A22 + A11) - sqrtf((A11 - A22) * (A11 - A22) + (4.f * A12) * A12)) / (float)(2 * LKW * LKW);
-        if (minEig < 1e-4f || D < 1.1920928955078125e-7f) {
-            if (level == 0) st = 0;
-            continue;
+#pragma unroll
+        for (int l = 0; l < LK_MAX_LEVELS; l++)
+            if (iok[l]) si[l].store(regI[l], tid);
+        if (jorg_x != INT_MIN / 2) sj.store(regJ[0], tid);
+    }
+    for (int level = max_level; level >= 0; level--) {
+        const uint8_t *jmg = J.img[level];
+        const int w = I.w[level], h = I.h[level];
+        const uint32_t jpitch = (uint32_t)J.pitch[level];
+        const float lscale = (float)(1.0 / (double)(1 << level));
+        // fetch the next (finer) level's next-image block now; it lands while this level computes
+        LkStage<LKJR> sn;
+        int nx0 = INT_MIN / 2, ny0 = INT_MIN / 2;
+        if (level > 0) {
+            const float ls1 = (float)(1.0 / (double)(1 << (level - 1)));
+            const int nipx = (int)floorf(pp.x * ls1 - half), nipy = (int)floorf(pp.y * ls1 - half);
+            if (!(nipx < -LKW || nipx >= I.w[level - 1] || nipy < -LKW || nipy >= I.h[level - 1])) {
+                nx0 = nipx - LKJM, ny0 = nipy - LKJM;
+                sn.load(J.img[level - 1], (uint32_t)J.pitch[level - 1], I.w[level - 1], I.h[level - 1], nx0, ny0, tid);
+            }
         }
-        D = 1.f / D;
-        npx -= half, npy -= half;
-        float pdx = 0.f, pdy = 0.f;
-        int jx0 = INT_MIN / 2, jy0 = INT_MIN / 2;  // origin of the staged next-image region (none yet)
-        for (int j = 0; j < 30; j++) {
-            const int inx = (int)floorf(npx), iny = (int)floorf(npy);
-            if (inx < -LKW || inx >= w || iny < -LKW || iny >= h) {
+        do {  // one pyramid level ("break" = the reference's "continue")
+            float ppx = pp.x * lscale, ppy = pp.y * lscale;
+            float npx, npy;
+            if (level == max_level)
+                npx = ppx, npy = ppy;
+            else
+                npx = np.x * 2.0f, npy = np.y * 2.0f;
+            np = make_float2(npx, npy);
+            ppx -= half, ppy -= half;
+            const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
+            if (ipx < -LKW || ipx >= w || ipy < -LKW || ipy >= h) {
                 if (level == 0) st = 0;
                 break;
             }
-            a = npx - (float)inx, b = npy - (float)iny;
-            iw00 = (int)rintf((1.f - a) * (1.f - b) * 16384.f);
-            iw01 = (int)rintf(a * (1.f - b) * 16384.f);
-            iw10 = (int)rintf((1.f - a) * b * 16384.f);
-            iw11 = 16384 - iw00 - iw01 - iw10;
-            if (inx < jx0 || iny < jy0 || inx + LKT > jx0 + LKJR || iny + LKT > jy0 + LKJR) {
-                // (re)stage a 32x32 block of the next image centred on the window; block-uniform branch
-                jx0 = inx - LKJM, jy0 = iny - LKJM;
-                const bool interior = jx0 >= 0 && jy0 >= 0 && jx0 + LKJR <= w && jy0 + LKJR <= h;
-                __syncthreads();
-                for (int e = tid; e < LKJR * LKJR; e += LK_THREADS) {
-                    const int ry = e / LKJR, rx = e - ry * LKJR;
-                    regJ[e] = interior ? jmg[(uint32_t)(jy0 + ry) * jpitch + (uint32_t)(jx0 + rx)]
-                                       : jmg[(uint32_t)reflect101(jy0 + ry, h) * jpitch + (uint32_t)reflect101(jx0 + rx, w)];
+            float a = ppx - (float)ipx, b = ppy - (float)ipy;
+            int iw00 = (int)rintf((1.f - a) * (1.f - b) * 16384.f);
+            int iw01 = (int)rintf(a * (1.f - b) * 16384.f);
+            int iw10 = (int)rintf((1.f - a) * b * 16384.f);
+            int iw11 = 16384 - iw00 - iw01 - iw10;
+            const int *rI = regI[level];
+            int *rJ = regJ[jb];
+            int jx0 = jorg_x, jy0 = jorg_y;  // origin of the next-image block staged for this level
+            __syncthreads();  // staged blocks visible; previous level's readers are done with derx / dery
+            for (int e = tid; e < LKT * LKT; e += LK_THREADS) {
+                const int tyy = e / LKT, txx = e - tyy * LKT;
+                const int X = ipx + txx, Y = ipy + tyy;
+                int dx = 0, dy = 0;
+                if (X >= 0 && Y >= 0 && X < w && Y < h) {
+                    const int *c = &rI[(tyy + 1) * LKR + (txx + 1)];
+                    const int t0m = (c[-LKR - 1] + c[LKR - 1]) * 3 + c[-1] * 10, t0p = (c[-LKR + 1] + c[LKR + 1]) * 3 + c[1] * 10;
+                    const int t1m = c[LKR - 1] - c[-LKR - 1], t1c = c[LKR] - c[-LKR], t1p = c[LKR + 1] - c[-LKR + 1];
+                    dx = (short)(t0p - t0m), dy = (short)((t1p + t1m) * 3 + t1c * 10);
                 }
-                __syncthreads();
+                derx[e] = dx, dery[e] = dy;
             }
-            const int jbase = (iny - jy0) * LKJR + (inx - jx0);
-            int pb[2] = {0, 0};  // per-lane partial sums: 2 * 16320 * 4080 < 2^28
+            __syncthreads();
+            short Iw[2], Ixw[2], Iyw[2];
+            int pA[3] = {0, 0, 0};  // per-lane partial sums: 2 * 4080^2 < 2^26
 #pragma unroll
             for (int m = 0; m < 2; m++) {
+                Iw[m] = Ixw[m] = Iyw[m] = 0;
                 if (woff[m] >= 0) {
-                    const int *c = &regJ[jbase + (woff[m] >> 8) * LKJR + (woff[m] & 255)];
-                    const int diff = LK_DESCALE(c[0] * iw00 + c[1] * iw01 + c[LKJR] * iw10 + c[LKJR + 1] * iw11, 9) - Iw[m];
-                    pb[0] += diff * Ixw[m], pb[1] += diff * Iyw[m];
+                    const int wy = woff[m] >> 8, wx = woff[m] & 255;
+                    const int *c = &rI[(wy + 1) * LKR + (wx + 1)];
+                    const int ival = LK_DESCALE(c[0] * iw00 + c[1] * iw01 + c[LKR] * iw10 + c[LKR + 1] * iw11, 9);
+                    const int d = wy * LKT + wx;
+                    const int ixval = LK_DESCALE(derx[d] * iw00 + derx[d + 1] * iw01 + derx[d + LKT] * iw10 + derx[d + LKT + 1] * iw11, 14);
+                    const int iyval = LK_DESCALE(dery[d] * iw00 + dery[d + 1] * iw01 + dery[d + LKT] * iw10 + dery[d + LKT + 1] * iw11, 14);
+                    Iw[m] = (short)ival, Ixw[m] = (short)ixval, Iyw[m] = (short)iyval;
+                    pA[0] += ixval * ixval, pA[1] += ixval * iyval, pA[2] += iyval * iyval;
                 }
             }
-            float sb[2];
-            lk_block_sums<2>(ex, parity, wave, lane, pb, sb);
+            float sA[3];
+            lk_block_sums<3>(ex, parity, wave, lane, pA, sA);
             parity ^= 1;
-            const float b1 = sb[0] * FLT_SCALE, b2 = sb[1] * FLT_SCALE;
-            const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
-            npx += dx, npy += dy;
-            np = make_float2(npx + half, npy + half);
-            if ((double)dx * dx + (double)dy * dy <= 0.01 * 0.01) break;
-            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
-                np.x -= dx * 0.5f, np.y -= dy * 0.5f;
+            const float FLT_SCALE = 1.0f / (1 << 20);
+            const float A11 = sA[0] * FLT_SCALE, A12 = sA[1] * FLT_SCALE, A22 = sA[2] * FLT_SCALE;
+            float D = A11 * A22 - A12 * A12;
+            const float minEig = ((A22 + A11) - sqrtf((A11 - A22) * (A11 - A22) + (4.f * A12) * A12)) / (float)(2 * LKW * LKW);
+            if (minEig < 1e-4f || D < 1.1920928955078125e-7f) {
+                if (level == 0) st = 0;
                 break;
             }
-            pdx = dx, pdy = dy;
-        }
+            D = 1.f / D;
+            npx -= half, npy -= half;
+            float pdx = 0.f, pdy = 0.f;
+            for (int j = 0; j < 30; j++) {
+                const int inx = (int)floorf(npx), iny = (int)floorf(npy);
+                if (inx < -LKW || inx >= w || iny < -LKW || iny >= h) {
+                    if (level == 0) st = 0;
+                    break;
+                }
+                a = npx - (float)inx, b = npy - (float)iny;
+                iw00 = (int)rintf((1.f - a) * (1.f - b) * 16384.f);
+                iw01 = (int)rintf(a * (1.f - b) * 16384.f);
+                iw10 = (int)rintf((1.f - a) * b * 16384.f);
+                iw11 = 16384 - iw00 - iw01 - iw10;
+                if (inx < jx0 || iny < jy0 || inx + LKT > jx0 + LKJR || iny + LKT > jy0 + LKJR) {
+                    // the window is outside the staged block: stage a block centred on the window; block-uniform branch
+                    jx0 = inx - LKJM, jy0 = iny - LKJM;
+                    LkStage<LKJR> sj;
+                    sj.load(jmg, jpitch, w, h, jx0, jy0, tid);
+                    __syncthreads();
+                    sj.store(rJ, tid);
+                    __syncthreads();
+                }
+                const int jbase = (iny - jy0) * LKJR + (inx - jx0);
+                int pb[2] = {0, 0};  // per-lane partial sums: 2 * 16320 * 4080 < 2^28
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    if (woff[m] >= 0) {
+                        const int *c = &rJ[jbase + (woff[m] >> 8) * LKJR + (woff[m] & 255)];
+                        const int diff = LK_DESCALE(c[0] * iw00 + c[1] * iw01 + c[LKJR] * iw10 + c[LKJR + 1] * iw11, 9) - Iw[m];
+                        pb[0] += diff * Ixw[m], pb[1] += diff * Iyw[m];
+                    }
+                }
+                float sb[2];
+                lk_block_sums<2>(ex, parity, wave, lane, pb, sb);
+                parity ^= 1;
+                const float b1 = sb[0] * FLT_SCALE, b2 = sb[1] * FLT_SCALE;
+                const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+                npx += dx, npy += dy;
+                np = make_float2(npx + half, npy + half);
+                if ((double)dx * dx + (double)dy * dy <= 0.01 * 0.01) break;
+                if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                    np.x -= dx * 0.5f, np.y -= dy * 0.5f;
+                    break;
+                }
+                pdx = dx, pdy = dy;
+            }
+        } while (false);
+        // the block fetched for the next level goes into the other buffer (its last readers left at the barrier of
+        // the level before this one; the next level's first barrier publishes it)
+        jb ^= 1;
+        jorg_x = nx0, jorg_y = ny0;
+        if (nx0 != INT_MIN / 2) sn.store(regJ[jb], tid);
     }
     if (tid == 0) {
         if (host_rec) {
