@@ -1050,7 +1050,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
         // caller looks at dst, so the tracking stream gets the highest priority the device offers
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->tstream, hipStreamNonBlocking, hi));
+        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->tstream, hipStreamNonBlocking, getenv("VSTAB_TSTREAM_NORMAL") ? (lo + hi) / 2 : hi));
         // copy + pyramid of the NEXT frame have a whole frame period of slack: lowest priority, so they fill
         // in behind the warp instead of taking its CUs
         VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, getenv("VSTAB_PSTREAM_HI") ? hi : lo));
