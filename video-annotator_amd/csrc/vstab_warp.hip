@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
 
     // ---------------- phase 1: map + quantise + classify -------------------------------------
     int sx[RPT][4], sy[RPT][4];
-    uint32_t in_bits = 0, border_bits = 0;  // bit (j*4+i): pixel samples fully inside / crosses the source border
+    uint32_t in_bits = 0, live_bits = 0;  // bit (j*4+i): all four taps inside the source / pixel exists in the output
     int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
     {
         // column / row terms with ONE refined reciprocal per axis (createMap.cl:16-17 divisions)
@@ -384,17 +384,21 @@ __global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
                 // outside any source <= 32767 wide after >> 5); only NaN (-> 0) needs an explicit test,
                 // and one ordered compare covers both coordinates.  Equivalent to cv::remap's cvRound
                 // -> INT_MIN -> "outside" (see quantise()).
+                // A NaN pixel gets sx = INT_MIN, i.e. a column far to the left of any source: every later test
+                // then classifies it as outside without looking at the flag again.
                 const bool ok = !__builtin_isunordered(ax, ay);
-                const int qx = (int)__builtin_rintf(ax), qy = (int)__builtin_rintf(ay);
+                const int qx = ok ? (int)__builtin_rintf(ax) : INT_MIN, qy = (int)__builtin_rintf(ay);
                 const int X = qx >> 5, Y = qy >> 5;
                 sx[j][i] = qx, sy[j][i] = qy;
-                const bool inside = ok && (uint32_t)X < sw1 && (uint32_t)Y < sh1;
-                if (inside) {
-                    in_bits |= 1u << (j * 4 + i);
-                    mnx = min(mnx, X), mxx = max(mxx, X), mny = min(mny, Y), mxy = max(mxy, Y);
-                } else if (ok && X < a.sw && X + 1 >= 0 && Y < a.sh && Y + 1 >= 0) {
-                    border_bits |= 1u << (j * 4 + i);
-                }
+                const bool inside = (uint32_t)X < sw1 && (uint32_t)Y < sh1;
+                in_bits |= (inside ? 1u : 0u) << (j * 4 + i);
+                // bounding box over ALL pixels with the coordinates clamped to one step outside the source: a
+                // superset of the inside pixels' box (pixels outside pull it to the nearest edge only), without
+                // a select per bound
+                int Xc, Yc;
+                asm("v_med3_i32 %0, %1, -1, %2" : "=v"(Xc) : "v"(X), "s"(a.sw));
+                asm("v_med3_i32 %0, %1, -1, %2" : "=v"(Yc) : "v"(Y), "s"(a.sh));
+                mnx = min(mnx, Xc), mxx = max(mxx, Xc), mny = min(mny, Yc), mxy = max(mxy, Yc);
             }
         }
     }
@@ -406,7 +410,7 @@ __global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
         for (int i = 0; i < 4; i++) cols |= (x0 + i < a.dw ? 1u : 0u) << i;
 #pragma unroll
         for (int j = 0; j < RPT; j++) live |= (ybase + TY * j < a.dh ? cols : 0u) << (4 * j);
-        in_bits &= live, border_bits &= live;
+        in_bits &= live, live_bits = live;
     }
     // bounding box: DPP reduction inside each 16-lane row (4 steps), then one LDS atomic per row.
     // (same-address LDS atomics from all 64 lanes serialise badly; shuffles cost 6 steps + bpermutes)
@@ -417,15 +421,17 @@ __global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
     mxy = max(mxy, __builtin_amdgcn_update_dpp(INT_MIN, mxy, 0x110 + n, 0xf, 0xf, false));
     VSTAB_ROW_STEP(1) VSTAB_ROW_STEP(2) VSTAB_ROW_STEP(4) VSTAB_ROW_STEP(8)
 #undef VSTAB_ROW_STEP
-    if (tx == 15 && mnx <= mxx) {  // lane 15 of each row holds the row's bounds
+    if (tx == 15) {  // lane 15 of each row holds the row's bounds
         atomicMin(&bbox[0], mnx), atomicMin(&bbox[1], mny), atomicMax(&bbox[2], mxx), atomicMax(&bbox[3], mxy);
     }
     __syncthreads();
 
     // ---------------- phase 2: stage the source bounding box as BGRx --------------------------
-    const int bx0 = bbox[0] & ~3, by0 = bbox[1] & ~1;
-    const int wb = (bbox[2] + 2 - bx0 + 3) & ~3, hb = (bbox[3] + 2 - by0 + 1) & ~1;  // taps reach max+1
-    const bool have = bbox[0] <= bbox[2];
+    // back inside the range of top-left taps of inside pixels: [0, sw - 2] x [0, sh - 2]
+    const int bmnx = max(bbox[0], 0), bmny = max(bbox[1], 0), bmxx = min(bbox[2], a.sw - 2), bmxy = min(bbox[3], a.sh - 2);
+    const int bx0 = bmnx & ~3, by0 = bmny & ~1;
+    const int wb = (bmxx + 2 - bx0 + 3) & ~3, hb = (bmxy + 2 - by0 + 1) & ~1;  // taps reach max+1
+    const bool have = bmnx <= bmxx && bmny <= bmxy;
     const bool use_lds = have && wb * hb <= ta.lds_capacity_px;
     const int dbg = ta.debug_mode;
     if (use_lds && dbg != 1 && dbg != 3) {
@@ -477,8 +483,10 @@ __global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
             } else if ((in_bits & bit) && use_lds) {
                 const uint32_t *t = tile + (__mul24(sy[j][i] >> 5, wb) + (sx[j][i] >> 5) - lds_origin);
                 v = blend_bgrx(t[0], t[1], t[wb], t[wb + 1], sx[j][i] & 31, sy[j][i] & 31);
-            } else if ((in_bits | border_bits) & bit) {
-                v = gather_pixel(a, sx[j][i], sy[j][i]);
+            } else if (live_bits & bit) {
+                // rare: the 2x2 footprint crosses the source border (per-tap zeroing) or the tile's box did not fit
+                const int X = sx[j][i] >> 5, Y = sy[j][i] >> 5;
+                if (X < a.sw && X + 1 >= 0 && Y < a.sh && Y + 1 >= 0) v = gather_pixel(a, sx[j][i], sy[j][i]);
             }
             px[i] = v;
         }
