@@ -829,7 +829,8 @@ static vstab_status prefetch_next(vstab_handle *H) {
         H->copies.push_back({slot, H->ingest_serial, f.hold < 0 ? 0 : f.hold});
     H->slots[slot].queued = true;  // reserved from now on (released when its warp has been enqueued)
     const int pyr = (int)(H->prefetch_count % PYR_SETS);
-    if (H->cfg.tracking) {
+    static const bool force_pyr = getenv("VSTAB_FORCE_PYRAMID") != nullptr;  // experiment: pyramid cost without the tracker
+    if (H->cfg.tracking || force_pyr) {
         HT t(HostTimers::PYRAMID);
         GpuStage gs(H, vstab_handle::ST_PYRAMID);
         VSTAB_TRY(H->tracker.build_pyramid(pyr, H->gray(slot), H->gpitch(slot), H->pstream));
@@ -1091,7 +1092,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     }
     // a frame stays in the pipeline from its pull until its warp: read-ahead + look-ahead queue + the frames in between
     H->borrow_hold = getenv("VSTAB_ALWAYS_COPY") ? (1 << 30) + 1 : cfg->smooth_radius + PREFETCH_DEPTH + 6;
-    if (cfg->tracking) VSTAB_TRY(H->tracker.init(H->w, H->h));
+    if (cfg->tracking || getenv("VSTAB_FORCE_PYRAMID")) VSTAB_TRY(H->tracker.init(H->w, H->h));
     *out = H.release();
     return VSTAB_OK;
 }
