@@ -212,6 +212,11 @@ typedef struct vstab_frame {
     int width, height; /* luma size; both even */
     int mem;           /* 0 = device memory, 1 = host memory */
     int64_t pts;
+    const double *delta_rotation; /* optional (NULL = none): 3x3 row-major rotation of the camera since the previous
+                          frame from an external sensor -- the gyro path the reference stubs (gpmf.cpp:5-11,
+                          AvFrameSourceFileVaapi.cpp:121-123).  Used in place of the optical-flow
+                          estimate (guess_camera_rotation's return value, FrameSourceWarp.cpp:429) when
+                          vstab_config.tracking == 0; read during the callback only. */
     int bit_depth;     /* 0 or 8: 8-bit NV12.  10 / 12 / 16: P010-style planes (16-bit little-endian samples, significant
                           bits at the top, pitches in bytes), narrowed to 8 bits on ingest (vstab_pack_p010). */
     int hold;          /* how many FURTHER pull callbacks these planes stay valid and unchanged for.  0 (default): only
@@ -249,7 +254,8 @@ typedef struct vstab_config {
     int smooth_radius;   /* 30 */
     int interpolation;   /* 1 = INTER_LINEAR (only mode the reference ever passes) */
     int smoother;        /* VSTAB_SMOOTHER_SG (reference behaviour) */
-    int tracking;        /* 1; 0 = undistort only: rotations are identity (BASELINE config 1) */
+    int tracking;        /* 1; 0 = no optical flow: rotations are identity (BASELINE config 1: undistort only) or the
+                            upstream-supplied vstab_frame.delta_rotation (external gyro), smoothed the same way */
     uint64_t seed;       /* PCG32 seed replacing the reference's un-seeded rand() */
     void *stream;        /* hipStream_t the warp (and so dst) is enqueued on; NULL = default stream.  Ingest and
                             tracking run on an internal stream that overlaps it; ordering is by events. */

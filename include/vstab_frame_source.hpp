@@ -21,6 +21,7 @@ struct NV12Frame {
     size_t pitch_y = 0, pitch_uv = 0;
     int width = 0, height = 0;
     bool host = false;
+    const double *delta_rotation = nullptr;  // optional external (gyro) rotation since the previous frame, 3x3 row-major
     int bit_depth = 8;  // 10 / 12 / 16: P010-style 16-bit samples (device memory), narrowed on ingest
     int hold = 0;  // vstab_frame.hold: further pulls this frame's memory stays valid for (0 = until the next pull)
 };
@@ -141,7 +142,7 @@ class FrameSourceWarp : public FrameSource {
         try {
             const NV12Frame f = advance ? self->m_source->pull_frame() : self->m_source->peek_frame();
             out->y = f.y, out->uv = f.uv, out->pitch_y = f.pitch_y, out->pitch_uv = f.pitch_uv;
-            out->width = f.width, out->height = f.height, out->mem = f.host ? 1 : 0, out->pts = 0, out->bit_depth = f.bit_depth, out->hold = f.hold;
+            out->width = f.width, out->height = f.height, out->mem = f.host ? 1 : 0, out->pts = 0, out->delta_rotation = f.delta_rotation, out->bit_depth = f.bit_depth, out->hold = f.hold;
             return 0;
         } catch (int err) {  // upstream errors are thrown ints (AvFrameSourceFileVaapi.cpp:141)
             if (err != EOF) self->m_pending_error = err;

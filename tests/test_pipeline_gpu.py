@@ -371,3 +371,69 @@ def test_two_handles_interleaved_are_independent(vs, cuda, clip):
                 outs_b.append(o.cpu().numpy())
     assert len(outs_a) == len(ref_a) and all(np.array_equal(x, y) for x, y in zip(outs_a, ref_a))
     assert len(outs_b) == len(ref_b) and all(np.array_equal(x, y) for x, y in zip(outs_b, ref_b))
+
+
+def test_external_rotation_source_replaces_optical_flow(vs, cuda, clip):
+    """SURVEY.md 8(f) row 4 (the gyro path the reference stubs): with tracking off, upstream's per-frame rotation is
+    accumulated (:441), smoothed (:444, :471) and corrected (:472-475) exactly as an optical-flow estimate would be."""
+    import ctypes
+    import torch
+    K, frames, rots = clip
+    n, r = 14, 3
+    dev = [torch.from_numpy(f).to(cuda) for f in frames[:n]]
+    deltas = [np.eye(3)] + [rots[k] @ rots[k - 1].T for k in range(1, n)]     # what a gyro integrates between frames
+    keep = [np.ascontiguousarray(d, np.float64) for d in deltas]
+    state = {"i": 0}
+
+    def fill(out, advance):
+        i = state["i"]
+        if i >= n:
+            return vs.EOF
+        t = dev[i]
+        o = out.contents
+        o.y, o.uv = t.data_ptr(), t.data_ptr() + H * t.stride(0)
+        o.pitch_y = o.pitch_uv = t.stride(0)
+        o.width, o.height, o.mem, o.pts, o.hold, o.bit_depth = W, H, 0, i, 1 << 20, 8
+        o.delta_rotation = keep[i].ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        if advance:
+            state["i"] += 1
+        return 0
+    pull = vs.PULL_FN(lambda u, o: fill(o, True))
+    peek = vs.PULL_FN(lambda u, o: fill(o, False))
+    src = vs.Source(pull, peek, None)
+    cfg = vs.default_config(smooth_radius=r, tracking=0)
+    h = ctypes.c_void_p()
+    assert vs.lib.vstab_create(ctypes.byref(cfg), ctypes.byref(src), ctypes.byref(h)) == vs.OK
+    Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
+    outs, warp_R = [], []
+    while True:
+        o = torch.empty((ch, cw, 3), dtype=torch.uint8, device=cuda)
+        st = vs.lib.vstab_pull_frame(h, o.data_ptr(), o.stride(0))
+        if st == vs.EOF:
+            break
+        assert st == vs.OK, vs.lib.vstab_last_error()
+        outs.append(o.cpu().numpy())
+        R = np.zeros(9)
+        assert vs.lib.vstab_get_warp_rotation(h, len(outs) - 1, R.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == vs.OK
+        warp_R.append(R.reshape(3, 3))
+    vs.lib.vstab_destroy(h)
+    assert len(outs) == n - 1
+    # the oracle's state machine fed the same rotations
+    it = iter(deltas[1:])
+    rec = []
+    sm = oracle.WarpStateMachine(frames[:n], r, lambda g: np.zeros((200, 2), np.float32), lambda p, c, pts: (pts, pts),
+                                 lambda pp, cp: (next(it), 100), lambda f, R: (rec.append(R), f)[1])
+    exp_frames = []
+    while True:
+        o = sm.pull_frame()
+        if o is None:
+            break
+        exp_frames.append(o)
+    assert len(rec) == n - 1
+    for i in range(n - 1):
+        assert np.allclose(warp_R[i], rec[i], atol=1e-11), i
+    for i in (0, 5, n - 2):
+        p = oracle.map_params(K, Ko, warp_R[i])
+        assert np.array_equal(outs[i], oracle.warp_nv12(exp_frames[i], p, cw, ch)), i
+    # the correction really follows the sensor: it is not the identity
+    assert max(oracle.rotation_angle(R) for R in warp_R) > 1e-3

@@ -542,6 +542,8 @@ struct vstab_handle {
         const uint8_t *y = nullptr, *uv = nullptr;
         size_t pitch_y = 0, pitch_uv = 0;
         bool borrowed = false;
+        bool have_delta = false;  // upstream supplied this frame's rotation since the previous frame (vstab_frame.delta_rotation)
+        Mat3 delta;
         bool queued = false, last = false;
         long freed_at = 0;               // FIFO reuse: the slot idle the longest is taken first
         hipEvent_t ingested = nullptr;   // recorded on pstream after the copy into the slot (and its pyramid, when tracking)
@@ -823,6 +825,8 @@ static vstab_status prefetch_next(vstab_handle *H) {
         VSTAB_TRY(ingest(H, f, slot));
     }
     H->last_ingest_slot = slot;
+    H->slots[slot].have_delta = f.delta_rotation != nullptr;
+    if (f.delta_rotation) std::memcpy(H->slots[slot].delta.m, f.delta_rotation, sizeof(double) * 9);
     H->slots[slot].ingest_serial = ++H->ingest_serial;
     // (frames promised to outlive a whole ring of pulls are not tracked: the ring slot itself is recycled sooner)
     if (f.mem == 0 && !H->slots[slot].borrowed && f.hold < (int)H->slots.size())
@@ -868,6 +872,7 @@ static vstab_status launch_tracking(vstab_handle *H) {
             H->last_key = H->frame_index;
             H->slots[slot].queued = false;  // the first frame is never emitted (:403-407)
         } else {
+            if (H->slots[slot].have_delta) H->measured = H->slots[slot].delta * H->measured;  // :441 with the sensor's rotation
             if (H->sg) H->sg->add(H->measured);
             H->queue.emplace_back(slot, H->measured);
         }
@@ -1122,7 +1127,11 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
             const vstab_status st = prefetch_next(H);
             if (st != VSTAB_OK && st != VSTAB_EOF) return st;
         }
-        if (!H->prefetched.empty() && !H->have_inflight) VSTAB_TRY(launch_tracking(H));
+        if (!H->prefetched.empty() && !H->have_inflight) {
+            const size_t queued = H->queue.size();
+            VSTAB_TRY(launch_tracking(H));
+            if (H->queue.size() != queued) continue;  // (tracking off: the frame is queued at once) re-check :453 before :456
+        }
         // 3. read ahead: pull + copy + pyramid of the following frames (prefetch stream)
         while ((int)H->prefetched.size() < PREFETCH_DEPTH && !H->src_eof) {
             const vstab_status st = prefetch_next(H);
