@@ -51,6 +51,9 @@ VSTAB_API const char *vstab_last_error(void);
 VSTAB_API const char *vstab_version(void);
 /* Number of HIP devices visible, or a negative vstab_status. */
 VSTAB_API int vstab_device_count(void);
+/* sizeof() of the ABI structs as this library was compiled, for bindings to check their mirrors against:
+ * 0 vstab_frame, 1 vstab_source, 2 vstab_config, 3 vstab_frame_log, 4 vstab_profile; -1 for any other index. */
+VSTAB_API int vstab_struct_size(int which);
 
 /* ------------------------------------------------------------------------------------------
  * Cameras (host, fp64).  Replaces get_preset_camera / get_output_camera,

@@ -96,3 +96,9 @@ def test_undistort_points_and_map_params_match_oracle(vs):
     R = oracle.rodrigues([0.01, 0.02, -0.03])
     assert np.allclose(vs.fisheye_undistort_points(pts, K, R, Ko), oracle.fisheye_undistort_points(pts, K, R, Ko), atol=1e-9)
     assert np.array_equal(vs.map_params(K, Ko, R), oracle.map_params(K, Ko, R))
+
+
+def test_ctypes_mirrors_have_the_compiled_struct_sizes(vs):
+    for k, t in enumerate((vs.Frame, vs.Source, vs.Config, vs.FrameLog, vs.Profile)):
+        assert vs.lib.vstab_struct_size(k) == ctypes.sizeof(t), t.__name__
+    assert vs.lib.vstab_struct_size(99) == -1

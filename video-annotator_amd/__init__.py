@@ -81,6 +81,7 @@ SIGNATURES = {
     "vstab_last_error": (_c.c_char_p, []),
     "vstab_version": (_c.c_char_p, []),
     "vstab_device_count": (_i, []),
+    "vstab_struct_size": (_i, [_i]),
     "vstab_get_preset_camera": (_i, [_i, _i, _i, _dp]),
     "vstab_get_output_camera": (_i, [_dp, _i, _i, _d, _i, _d, _dp, _ip, _ip]),
     "vstab_fisheye_undistort_points": (_i, [_dp, _i, _dp, _dp, _dp, _dp]),
@@ -124,6 +125,9 @@ for _name, (_res, _args) in SIGNATURES.items():
     _f.restype, _f.argtypes = _res, _args
 
 lib = _L
+for _k, _t in enumerate((Frame, Source, Config, FrameLog, Profile)):  # the ctypes mirrors must match the compiled structs
+    if _L.vstab_struct_size(_k) != _c.sizeof(_t):
+        raise ImportError(f"video-annotator_amd: ctypes mirror of {_t.__name__} is {_c.sizeof(_t)} bytes, libvstab.so has {_L.vstab_struct_size(_k)}")
 
 
 class VstabError(RuntimeError):

@@ -1026,6 +1026,17 @@ static void finish_estimate(vstab_handle *H) {
 
 extern "C" {
 
+int vstab_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(vstab_frame);
+        case 1: return (int)sizeof(vstab_source);
+        case 2: return (int)sizeof(vstab_config);
+        case 3: return (int)sizeof(vstab_frame_log);
+        case 4: return (int)sizeof(vstab_profile);
+        default: return -1;
+    }
+}
+
 void vstab_config_default(vstab_config *cfg) {
     if (!cfg) return;
     std::memset(cfg, 0, sizeof(*cfg));
