@@ -437,3 +437,63 @@ def test_external_rotation_source_replaces_optical_flow(vs, cuda, clip):
         assert np.array_equal(outs[i], oracle.warp_nv12(exp_frames[i], p, cw, ch)), i
     # the correction really follows the sensor: it is not the identity
     assert max(oracle.rotation_angle(R) for R in warp_R) > 1e-3
+
+
+def _check_against_oracle_state_machine(vs, cuda, frames, K, w, h, r, seed):
+    """Whole-pipeline equivalence on an arbitrary clip: decisions, counts, rotations handed to the warp, pixels."""
+    stab, outs = run_product(vs, cuda, frames, smooth_radius=r, seed=seed)
+    log = stab.frame_log()
+    n = len(frames)
+    assert len(outs) == max(n - 1, 0) and len(log) == max(n - 1, 0)
+    Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
+    it = iter(log)
+    counts, warp_rots = [], []
+
+    def track(prev, cur, corners):
+        if len(corners) == 0:
+            counts.append((0, 0))
+            return corners, corners
+        nxt, st = oracle.pyr_lk(prev, cur, corners)
+        counts.append((len(corners), int((st > 0).sum())))
+        return corners[st > 0], nxt[st > 0]
+
+    sm = oracle.WarpStateMachine(frames, r, lambda g: oracle.good_features(np.ascontiguousarray(g)), track,
+                                 lambda pp, cp: (next(it)["R"], 100), lambda f, R: (warp_rots.append(R), f)[1])
+    exp = []
+    while True:
+        o = sm.pull_frame()
+        if o is None:
+            break
+        exp.append(o)
+    assert [l["key"] for l in log] == [l["key"] for l in sm.log]
+    assert [(l["n_corners"], l["n_tracked"]) for l in log] == counts
+    for i in range(len(outs)):
+        assert np.allclose(stab.warp_rotation(i), warp_rots[i], atol=1e-10), i
+        p = oracle.map_params(K, Ko, stab.warp_rotation(i))
+        assert np.array_equal(outs[i], oracle.warp_nv12(exp[i], p, cw, ch)), i
+    return log
+
+
+def test_pipeline_degenerate_clips(vs, cuda):
+    """Featureless frames (no corners at all: every frame is a key frame, every estimate falls back), a clip with a
+    handful of corners, sizes that are even but not multiples of four, and a two-frame clip."""
+    w, h = 322, 182
+    K = oracle.get_preset_camera(4, w, h)
+    black = [np.full((h * 3 // 2, w), 128, np.uint8) for _ in range(7)]
+    for f in black:
+        f[:h] = 16
+    log = _check_against_oracle_state_machine(vs, cuda, black, K, w, h, 2, 1)
+    assert all(l["key"] and l["n_corners"] == 0 and l["fallback"] for l in log)
+    few = []
+    for k in range(8):
+        f = np.full((h * 3 // 2, w), 128, np.uint8)
+        f[:h] = 40
+        for (x, y) in [(60, 40), (200, 90), (120, 140)]:
+            f[y + k:y + k + 25, x + 2 * k:x + 2 * k + 30] = 220          # three moving rectangles: a dozen corners
+        few.append(f)
+    log = _check_against_oracle_state_machine(vs, cuda, few, K, w, h, 2, 2)
+    assert all(0 < l["n_corners"] < 40 and l["fallback"] for l in log)
+    frames, _ = synth.shaky_clip(5, K, w, h, 9, sigma=0.004)
+    _check_against_oracle_state_machine(vs, cuda, frames, K, w, h, 3, 3)
+    _check_against_oracle_state_machine(vs, cuda, frames[:2], K, w, h, 3, 4)
+    _check_against_oracle_state_machine(vs, cuda, frames[:1], K, w, h, 3, 5)
