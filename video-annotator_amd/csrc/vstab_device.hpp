@@ -315,20 +315,29 @@ __device__ __forceinline__ uint32_t pack_bgrx(int Y, const ChromaTerm &c) {
 
 // cv::remap fixed-point bilinear blend of four BGRx taps:
 //   out_c = (p00*(32-fx)(32-fy) + p01*fx(32-fy) + p10*(32-fx)fy + p11*fx*fy + 512) >> 10
-// evaluated as an exact two-stage integer lerp (vertical on packed (B,R) 16-bit lanes, which
-// cannot overflow: 255*32 < 65536; then horizontal per channel).  Integer arithmetic is
-// distributive, so this equals the four-product sum bit for bit.  Returns 0x00RRGGBB.
+// evaluated as an exact two-stage integer lerp (vertical per column with v_dot4_u32_u8 on byte pairs gathered by
+// v_perm_b32, then horizontal per channel).  Integer arithmetic is distributive, so this equals the four-product
+// sum bit for bit.  Returns 0x00RRGGBB.
 __device__ __forceinline__ uint32_t blend_bgrx(uint32_t t00, uint32_t t01, uint32_t t10, uint32_t t11,
                                                uint32_t fx, uint32_t fy) {
-    const uint32_t gx = 32u - fx, gy = 32u - fy;
-    const uint32_t br0 = __umul24(t00 & 0x00FF00FFu, gy) + __umul24(t10 & 0x00FF00FFu, fy);
-    const uint32_t br1 = __umul24(t01 & 0x00FF00FFu, gy) + __umul24(t11 & 0x00FF00FFu, fy);
-    const uint32_t g0 = __umul24((t00 >> 8) & 255u, gy) + __umul24((t10 >> 8) & 255u, fy);
-    const uint32_t g1 = __umul24((t01 >> 8) & 255u, gy) + __umul24((t11 >> 8) & 255u, fy);
-    const uint32_t B = (__umul24(br0 & 0xFFFFu, gx) + __umul24(br1 & 0xFFFFu, fx) + 512u) >> 10;
-    const uint32_t R = (__umul24(br0 >> 16, gx) + __umul24(br1 >> 16, fx) + 512u) >> 10;
-    const uint32_t G = (__umul24(g0, gx) + __umul24(g1, fx) + 512u) >> 10;
-    return B | (G << 8) | (R << 16);
+    // vertical lerp per column and channel as byte dot products: v = top * (32 - fy) + bottom * fy  (<= 255 * 32)
+    const uint32_t gy = 32u - fy;
+    const uint32_t w_lo = gy | (fy << 8), w_hi = w_lo << 16;  // weights against bytes (0,1) / bytes (2,3)
+    const uint32_t bg_l = __builtin_amdgcn_perm(t10, t00, 0x05010400u);  // [top.B, bottom.B, top.G, bottom.G]
+    const uint32_t r_l = __builtin_amdgcn_perm(t10, t00, 0x0c0c0602u);   // [top.R, bottom.R, 0, 0]
+    const uint32_t bg_r = __builtin_amdgcn_perm(t11, t01, 0x05010400u);
+    const uint32_t r_r = __builtin_amdgcn_perm(t11, t01, 0x0c0c0602u);
+    const uint32_t vb_l = __builtin_amdgcn_udot4(bg_l, w_lo, 0u, false), vg_l = __builtin_amdgcn_udot4(bg_l, w_hi, 0u, false);
+    const uint32_t vr_l = __builtin_amdgcn_udot4(r_l, w_lo, 0u, false);
+    const uint32_t vb_r = __builtin_amdgcn_udot4(bg_r, w_lo, 0u, false), vg_r = __builtin_amdgcn_udot4(bg_r, w_hi, 0u, false);
+    const uint32_t vr_r = __builtin_amdgcn_udot4(r_r, w_lo, 0u, false);
+    // horizontal lerp with the weights scaled by 64: (l * gx + r * fx + 512) << 6 has the result byte at bits 16..23
+    const uint32_t fx6 = fx << 6, gx6 = 2048u - fx6;
+    const uint32_t sb = __umul24(vb_l, gx6) + (__umul24(vb_r, fx6) + 32768u);
+    const uint32_t sg = __umul24(vg_l, gx6) + (__umul24(vg_r, fx6) + 32768u);
+    const uint32_t sr = __umul24(vr_l, gx6) + (__umul24(vr_r, fx6) + 32768u);
+    const uint32_t bg = __builtin_amdgcn_perm(sg, sb, 0x0c0c0602u);  // [B, G, 0, 0]
+    return __builtin_amdgcn_perm(sr, bg, 0x0c060100u);               // [B, G, R, 0]
 }
 
 }  // namespace vstab
