@@ -438,30 +438,46 @@ __global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
         const int ux_n = wb >> 2, units = ux_n * (hb >> 1);
         const uint32_t magic = (1u << 18) / (uint32_t)ux_n + 1u;  // u / ux_n == (u * magic) >> 18 for u < 2048
         const uint32_t pitch_y = (uint32_t)a.pitch_y, pitch_uv = (uint32_t)a.pitch_uv;  // < 2^24 (host check)
-        for (int u = tid; u < units; u += NT) {
-            const uint32_t uy = ((uint32_t)u * magic) >> 18, ux = (uint32_t)u - __umul24(uy, (uint32_t)ux_n);
-            const uint32_t gx = (uint32_t)bx0 + 4u * ux, gy = (uint32_t)by0 + 2u * uy;
-            const uint32_t oy = __umul24(gy, pitch_y) + gx, ouv = __umul24(gy >> 1, pitch_uv) + gx;  // frame < 4 GiB
-            uint32_t y0w, y1w, uvw;
-            if (ta.src_vec_ok && (int)gx + 4 <= a.sw) {
-                y0w = *reinterpret_cast<const uint32_t *>(a.y + oy);
-                y1w = *reinterpret_cast<const uint32_t *>(a.y + oy + pitch_y);
-                uvw = *reinterpret_cast<const uint32_t *>(a.uv + ouv);
-            } else {
-                const int valid = min(4, a.sw - (int)gx);
-                y0w = load_u32_bytes(a.y + oy, valid), y1w = load_u32_bytes(a.y + oy + pitch_y, valid);
-                uvw = load_u32_bytes(a.uv + ouv, valid);
+        // All loads of this thread's units are issued before the first conversion waits for one: the box holds at
+        // most lds_capacity_px / 8 units, i.e. STAGE_MAX trips per thread, so staging costs one exposed memory
+        // latency instead of one per trip (measured: phase 2 was 22 % of the kernel for 14 % of its instructions).
+        constexpr int STAGE_MAX = 5;  // 5 * NT * 8 >= 10236 pixels (40 KB of LDS); the launcher checks the budget
+        uint32_t y0w[STAGE_MAX], y1w[STAGE_MAX], uvw[STAGE_MAX];
+#pragma unroll
+        for (int it = 0; it < STAGE_MAX; it++) {
+            const int u = tid + it * NT;
+            y0w[it] = y1w[it] = uvw[it] = 0;
+            if (u < units) {
+                const uint32_t uy = ((uint32_t)u * magic) >> 18, ux = (uint32_t)u - __umul24(uy, (uint32_t)ux_n);
+                const uint32_t gx = (uint32_t)bx0 + 4u * ux, gy = (uint32_t)by0 + 2u * uy;
+                const uint32_t oy = __umul24(gy, pitch_y) + gx, ouv = __umul24(gy >> 1, pitch_uv) + gx;  // frame < 4 GiB
+                if (ta.src_vec_ok && (int)gx + 4 <= a.sw) {
+                    y0w[it] = *reinterpret_cast<const uint32_t *>(a.y + oy);
+                    y1w[it] = *reinterpret_cast<const uint32_t *>(a.y + oy + pitch_y);
+                    uvw[it] = *reinterpret_cast<const uint32_t *>(a.uv + ouv);
+                } else {
+                    const int valid = min(4, a.sw - (int)gx);
+                    y0w[it] = load_u32_bytes(a.y + oy, valid), y1w[it] = load_u32_bytes(a.y + oy + pitch_y, valid);
+                    uvw[it] = load_u32_bytes(a.uv + ouv, valid);
+                }
             }
-            const ChromaTerm c0 = chroma_term_folded(uvw & 255, (uvw >> 8) & 255);
-            const ChromaTerm c1 = chroma_term_folded((uvw >> 16) & 255, uvw >> 24);
-            uint4 r0, r1;
-            r0.x = pack_bgrx(y0w & 255, c0), r0.y = pack_bgrx((y0w >> 8) & 255, c0);
-            r0.z = pack_bgrx((y0w >> 16) & 255, c1), r0.w = pack_bgrx(y0w >> 24, c1);
-            r1.x = pack_bgrx(y1w & 255, c0), r1.y = pack_bgrx((y1w >> 8) & 255, c0);
-            r1.z = pack_bgrx((y1w >> 16) & 255, c1), r1.w = pack_bgrx(y1w >> 24, c1);
-            uint32_t *d = tile + __umul24(2u * uy, (uint32_t)wb) + 4u * ux;
-            *reinterpret_cast<uint4 *>(d) = r0;
-            *reinterpret_cast<uint4 *>(d + wb) = r1;
+        }
+#pragma unroll
+        for (int it = 0; it < STAGE_MAX; it++) {
+            const int u = tid + it * NT;
+            if (u < units) {
+                const uint32_t uy = ((uint32_t)u * magic) >> 18, ux = (uint32_t)u - __umul24(uy, (uint32_t)ux_n);
+                const ChromaTerm c0 = chroma_term_folded(uvw[it] & 255, (uvw[it] >> 8) & 255);
+                const ChromaTerm c1 = chroma_term_folded((uvw[it] >> 16) & 255, uvw[it] >> 24);
+                uint4 r0, r1;
+                r0.x = pack_bgrx(y0w[it] & 255, c0), r0.y = pack_bgrx((y0w[it] >> 8) & 255, c0);
+                r0.z = pack_bgrx((y0w[it] >> 16) & 255, c1), r0.w = pack_bgrx(y0w[it] >> 24, c1);
+                r1.x = pack_bgrx(y1w[it] & 255, c0), r1.y = pack_bgrx((y1w[it] >> 8) & 255, c0);
+                r1.z = pack_bgrx((y1w[it] >> 16) & 255, c1), r1.w = pack_bgrx(y1w[it] >> 24, c1);
+                uint32_t *d = tile + __umul24(2u * uy, (uint32_t)wb) + 4u * ux;
+                *reinterpret_cast<uint4 *>(d) = r0;
+                *reinterpret_cast<uint4 *>(d + wb) = r1;
+            }
         }
     }
     __syncthreads();
@@ -704,7 +720,8 @@ vstab_status vstab_warp_nv12_ex(const void *y, size_t pitch_y, const void *uv, s
         const int rpt = plain ? rpt_env : 2, tyr = plain ? tyr_env : 16;  // the tile-shape knobs exist for the reference mode only
         static const int lds_kb = getenv("VSTAB_LDS_KB") ? atoi(getenv("VSTAB_LDS_KB")) : 40;
         const size_t lds_bytes = (size_t)lds_kb * 1024;  // 40 KB -> 4 workgroups (16 waves) per CU
-        ta.lds_capacity_px = (int)(lds_bytes / 4) - 4;
+        // the staging loop keeps at most 5 trips x 8 pixels per thread in flight (STAGE_MAX in k_warp_tiled)
+        ta.lds_capacity_px = std::min((int)(lds_bytes / 4) - 4, 5 * 8 * 16 * tyr);
         ta.tiles_x = (int)div_up(dw, WARP_TILE_W), ta.tiles_y = (int)div_up(dh, tyr * rpt);
         dim3 grid(8 * div_up((unsigned)(ta.tiles_x * ta.tiles_y), 8));
         hipStream_t st = static_cast<hipStream_t>(stream);
