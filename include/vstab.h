@@ -296,6 +296,9 @@ VSTAB_API vstab_status vstab_pull_frame(vstab_handle *h, void *dst_bgr, size_t p
  * of 2*ceil(width/2) bytes.  BGR and NV12 pulls may be mixed freely on one handle. */
 VSTAB_API vstab_status vstab_pull_frame_nv12(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv,
                                              size_t pitch_uv);
+/* pull_frame into HOST memory (what a cv::Mat / imshow consumer of DisplayImage.cpp:63-65 needs): the frame is warped
+ * into a buffer of the handle and copied out; returns when the copy has completed. */
+VSTAB_API vstab_status vstab_pull_frame_host(vstab_handle *h, void *dst_bgr_host, size_t pitch_dst);
 /* FrameSourceWarp::peek_frame (:478-480) IS pull_frame in the reference (destructive); kept. */
 VSTAB_API vstab_status vstab_peek_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
 VSTAB_API void vstab_destroy(vstab_handle *h);

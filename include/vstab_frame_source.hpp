@@ -125,6 +125,18 @@ class FrameSourceWarp : public FrameSource {
     }
     BGRFrame peek_frame() override { return pull_frame(); }  // :478-480 (destructive in the reference too)
 
+    // the next frame in HOST memory (e.g. the data of a cv::Mat for imshow, DisplayImage.cpp:63-65)
+    BGRFrame pull_frame_host(void *host_bgr, size_t pitch) {
+        const vstab_status st = vstab_pull_frame_host(m_handle, host_bgr, pitch);
+        if (st == VSTAB_EOF) throw (int)EOF;
+        if (st == VSTAB_ERR_SOURCE && m_pending_error) throw m_pending_error;
+        if (st != VSTAB_OK) {
+            std::fprintf(stderr, "FrameSourceWarp: %s\n", vstab_last_error());
+            throw (int)st;
+        }
+        return BGRFrame{host_bgr, pitch, m_out_w, m_out_h};
+    }
+
     // the next frame as NV12 (planes provided by the caller: width bytes per luma row, 2*ceil(width/2) per chroma row)
     NV12Out pull_frame_nv12(void *device_y, size_t pitch_y, void *device_uv, size_t pitch_uv) {
         const vstab_status st = vstab_pull_frame_nv12(m_handle, device_y, pitch_y, device_uv, pitch_uv);

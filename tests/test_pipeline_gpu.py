@@ -497,3 +497,17 @@ def test_pipeline_degenerate_clips(vs, cuda):
     _check_against_oracle_state_machine(vs, cuda, frames, K, w, h, 3, 3)
     _check_against_oracle_state_machine(vs, cuda, frames[:2], K, w, h, 3, 4)
     _check_against_oracle_state_machine(vs, cuda, frames[:1], K, w, h, 3, 5)
+
+
+def test_pull_into_host_memory_equals_device_pull(vs, cuda, clip):
+    import torch
+    K, frames, _ = clip
+    _, ref = run_product(vs, cuda, frames[:9], smooth_radius=2, seed=6)
+    stab = vs.Stabilizer([torch.from_numpy(f).to(cuda) for f in frames[:9]], total=9, smooth_radius=2, seed=6)
+    outs = []
+    while True:
+        o = stab.pull_host()
+        if o is None:
+            break
+        outs.append(o)
+    assert len(outs) == len(ref) and all(np.array_equal(a, b) for a, b in zip(outs, ref))

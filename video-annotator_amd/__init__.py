@@ -109,6 +109,7 @@ SIGNATURES = {
     "vstab_get_output_info": (_i, [_vp, _ip, _ip, _dp, _dp]),
     "vstab_pull_frame": (_i, [_vp, _vp, _sz]),
     "vstab_pull_frame_nv12": (_i, [_vp, _vp, _sz, _vp, _sz]),
+    "vstab_pull_frame_host": (_i, [_vp, _vp, _sz]),
     "vstab_lens_camera": (_i, [_i, _d, _i, _i, _d, _d, _dp]),
     "vstab_peek_frame": (_i, [_vp, _vp, _sz]),
     "vstab_destroy": (None, [_vp]),
@@ -469,6 +470,15 @@ class Stabilizer:
         import torch
         out = torch.empty((self.out_size[1], self.out_size[0], 3), dtype=torch.uint8, device="cuda")
         return out if self.pull_into(out) else None
+
+    def pull_host(self):
+        """-> (h, w, 3) numpy array in host memory, or None at end of stream."""
+        out = np.empty((self.out_size[1], self.out_size[0], 3), np.uint8)
+        st = _L.vstab_pull_frame_host(self._h, out.ctypes.data, out.strides[0])
+        if st == EOF:
+            return None
+        _check(st, "vstab_pull_frame_host")
+        return out
 
     def pull_nv12_into(self, y, uv):
         st = _L.vstab_pull_frame_nv12(self._h, y.data_ptr(), y.stride(0), uv.data_ptr(), uv.stride(0))

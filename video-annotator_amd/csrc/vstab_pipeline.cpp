@@ -655,6 +655,7 @@ struct vstab_handle {
     long spec_frame = -1;        // frame index the chained launch tracks into; -1 = none
     bool spec_is_key = false;    // that launch is a pre-launched key frame (fresh corners from the speculative detection)
     std::vector<float> pre_corners;
+    DevBuf host_out;                // staging buffer of vstab_pull_frame_host
     hipStream_t dstream = nullptr;  // speculative corner detection (137 us of kernels every 21st frame) beside everything else
     bool chain_lk = true;        // VSTAB_CHAIN_LK=0 disables chained launches
     long chained_adopted = 0, chained_discarded = 0, key_prelaunched = 0;
@@ -1207,6 +1208,17 @@ extern "C" {
 
 vstab_status vstab_pull_frame(vstab_handle *h, void *dst, size_t pitch_dst) {
     return pull_frame_impl(h, VSTAB_OUT_BGR8, dst, pitch_dst, nullptr, 0);
+}
+
+vstab_status vstab_pull_frame_host(vstab_handle *h, void *dst, size_t pitch_dst) {
+    if (!h || !dst || pitch_dst < (size_t)h->ow * 3) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame_host: bad argument");
+    const size_t dpitch = ((size_t)h->ow * 3 + 255) & ~(size_t)255;
+    VSTAB_TRY(h->host_out.ensure(dpitch * h->oh));
+    const vstab_status st = pull_frame_impl(h, VSTAB_OUT_BGR8, h->host_out.p, dpitch, nullptr, 0);
+    if (st != VSTAB_OK) return st;
+    VSTAB_HIP_TRY(hipMemcpy2DAsync(dst, pitch_dst, h->host_out.p, dpitch, (size_t)h->ow * 3, h->oh, hipMemcpyDeviceToHost, h->stream));
+    VSTAB_HIP_TRY(hipStreamSynchronize(h->stream));
+    return VSTAB_OK;
 }
 
 vstab_status vstab_pull_frame_nv12(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv) {
