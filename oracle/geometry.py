@@ -210,6 +210,47 @@ class RotationFilter:
         return U @ Vt
 
 
+def rodrigues_inv(R):
+    """Rotation matrix -> rotation vector (cv::Rodrigues, matrix input), angles below pi."""
+    R = np.asarray(R, np.float64)
+    c = min(max((np.trace(R) - 1) / 2, -1.0), 1.0)
+    th = math.acos(c)
+    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    if th < 1e-12:
+        return v / 2
+    return v * (th / (2 * math.sin(th)))
+
+
+class KalmanRotationFilter:
+    """The optional Kalman smoother (SURVEY.md F2): one cv::KalmanFilter(2, 1, 0) per rotation-vector axis with the
+    constants of init_filter (FrameSourceWarp.cpp:167-175 == kalman/kalman.cpp:43-48): F = [[1,1],[0,1]], H = [1 0],
+    Q = 1e-5 I, R = 1e-1, P0 = I, x0 = 0; every frame predict() then correct(measured angle), output = corrected
+    state.  Written in the general matrix form of cv::KalmanFilter::predict / correct.  The reference never calls
+    init_filter, so this mode has no reference output."""
+
+    def __init__(self):
+        self.F = np.array([[1.0, 1.0], [0.0, 1.0]])
+        self.H = np.array([[1.0, 0.0]])
+        self.Q = 1e-5 * np.eye(2)
+        self.Rn = np.array([[1e-1]])
+        self.x = [np.zeros((2, 1)) for _ in range(3)]
+        self.P = [np.eye(2) for _ in range(3)]
+
+    def update(self, measured):
+        rv = rodrigues_inv(measured)
+        out = np.zeros(3)
+        for a in range(3):
+            x = self.F @ self.x[a]                                   # predict
+            P = self.F @ self.P[a] @ self.F.T + self.Q
+            S = self.H @ P @ self.H.T + self.Rn                      # correct
+            K = P @ self.H.T @ np.linalg.inv(S)
+            x = x + K @ (np.array([[rv[a]]]) - self.H @ x)
+            P = P - K @ self.H @ P
+            self.x[a], self.P[a] = x, P
+            out[a] = x[0, 0]
+        return rodrigues(out)
+
+
 class WarpStateMachine:
     """consume_frame / pull_frame control flow, FrameSourceWarp.cpp:397-476, with the pixel and
     estimation steps injected so the same state machine can be driven by oracle or by recorded

@@ -511,3 +511,17 @@ def test_pull_into_host_memory_equals_device_pull(vs, cuda, clip):
             break
         outs.append(o)
     assert len(outs) == len(ref) and all(np.array_equal(a, b) for a, b in zip(outs, ref))
+
+
+def test_kalman_smoother_mode_matches_its_definition(vs, cuda, clip):
+    """the Kalman mode (constants of init_filter / kalman.cpp, never called by the reference) --
+    product vs the oracle's matrix-form cv::KalmanFilter on the product's own accumulated rotations."""
+    K, frames, _ = clip
+    stab, outs = run_product(vs, cuda, frames[:16], smooth_radius=2, smoother=vs.SMOOTHER_KALMAN, seed=3)
+    log = stab.frame_log()
+    kf = oracle.KalmanRotationFilter()
+    for i, lg in enumerate(log):
+        corrected = kf.update(lg["R_accum"])
+        expect = np.linalg.inv(corrected @ np.linalg.inv(lg["R_accum"]))      # :472, :475
+        assert np.allclose(stab.warp_rotation(i), expect, atol=1e-10), i
+    assert oracle.rotation_angle(stab.warp_rotation(10)) > 1e-4               # it does smooth: the correction is not the identity
