@@ -587,12 +587,10 @@ struct vstab_handle {
     std::vector<Slot> slots;
     int last_slot = -1;  // m_last_input_frame
     int last_ingest_slot = -1;
-    int last_warp_slot = -1;
     EstimateWorker worker;            // runs estimate_rotation beside the launch calls of the next frame
     bool estimate_posted = false;
     bool threaded_estimate = true;    // VSTAB_THREADED_ESTIMATE=0: estimate on the calling thread
     bool speculate = true;            // VSTAB_SPECULATE=0 disables speculative corner detection
-    bool serialize_prefetch = false;  // VSTAB_SERIALIZE_PREFETCH=1: start copy+pyramid only after the last warp (measured slower)
     int cur_pyr = 0;     // pyramid set holding the last tracked frame's pyramid (frame index mod 3)
 
     long frame_index = 0, last_key = -1;       // m_frame_index, m_last_key_frame_index
@@ -752,13 +750,6 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
         VSTAB_TRY(vstab_handle::wait_if_pending(H->pstream, H->warp_events[S.warped]));
         S.warp_pending = false, S.warped = -1;
     }
-    // Copy + pyramid are full-GPU streaming kernels: running them beside the (VALU-bound, full-GPU) warp
-    // only makes both slower.  Start them when the last warp has drained; what overlaps the warp is the
-    // low-occupancy LK kernel.
-    if (H->last_warp_slot >= 0 && H->serialize_prefetch) {
-        VSTAB_TRY(H->cover_warps());
-        if (H->slots[H->last_warp_slot].warped >= 0) VSTAB_HIP_TRY(hipStreamWaitEvent(H->pstream, H->warp_events[H->slots[H->last_warp_slot].warped], 0));
-    }
     if (wide) {
         VSTAB_TRY(vstab_pack_p010(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->pstream));
     } else if (f.mem == 0) {
@@ -834,8 +825,7 @@ static vstab_status prefetch_next(vstab_handle *H) {
         H->copies.push_back({slot, H->ingest_serial, f.hold < 0 ? 0 : f.hold});
     H->slots[slot].queued = true;  // reserved from now on (released when its warp has been enqueued)
     const int pyr = (int)(H->prefetch_count % PYR_SETS);
-    static const bool force_pyr = getenv("VSTAB_FORCE_PYRAMID") != nullptr;  // experiment: pyramid cost without the tracker
-    if (H->cfg.tracking || force_pyr) {
+    if (H->cfg.tracking) {
         HT t(HostTimers::PYRAMID);
         GpuStage gs(H, vstab_handle::ST_PYRAMID);
         VSTAB_TRY(H->tracker.build_pyramid(pyr, H->gray(slot), H->gpitch(slot), H->pstream));
@@ -1058,7 +1048,6 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     std::unique_ptr<vstab_handle> H(new vstab_handle);
     H->cfg = *cfg, H->src = *src;
     H->rng = Pcg32(cfg->seed);
-    if (const char *e = getenv("VSTAB_SERIALIZE_PREFETCH")) H->serialize_prefetch = atoi(e) != 0;
     if (const char *e = getenv("VSTAB_SPECULATE")) H->speculate = atoi(e) != 0;
     if (const char *e = getenv("VSTAB_THREADED_ESTIMATE")) H->threaded_estimate = atoi(e) != 0;
     if (const char *e = getenv("VSTAB_CHAIN_LK")) H->chain_lk = atoi(e) != 0;
@@ -1068,12 +1057,12 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
         // caller looks at dst, so the tracking stream gets the highest priority the device offers
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->tstream, hipStreamNonBlocking, getenv("VSTAB_TSTREAM_NORMAL") ? (lo + hi) / 2 : hi));
+        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->tstream, hipStreamNonBlocking, hi));
         // copy + pyramid of the NEXT frame have a whole frame period of slack: lowest priority, so they fill
         // in behind the warp instead of taking its CUs
-        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, getenv("VSTAB_PSTREAM_HI") ? hi : lo));
+        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, lo));
         // detection has to be ready before its key frame's turn, PREFETCH_DEPTH frame periods after it is enqueued
-        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->dstream, hipStreamNonBlocking, getenv("VSTAB_DSTREAM_LO") ? lo : (lo + hi) / 2));
+        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->dstream, hipStreamNonBlocking, (lo + hi) / 2));
         for (auto &e : H->warp_events) VSTAB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // :214-219 peek the first frame for the input size, then derive both cameras
@@ -1109,7 +1098,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     }
     // a frame stays in the pipeline from its pull until its warp: read-ahead + look-ahead queue + the frames in between
     H->borrow_hold = getenv("VSTAB_ALWAYS_COPY") ? (1 << 30) + 1 : cfg->smooth_radius + PREFETCH_DEPTH + 6;
-    if (cfg->tracking || getenv("VSTAB_FORCE_PYRAMID")) VSTAB_TRY(H->tracker.init(H->w, H->h));
+    if (cfg->tracking) VSTAB_TRY(H->tracker.init(H->w, H->h));
     *out = H.release();
     return VSTAB_OK;
 }
@@ -1200,7 +1189,6 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         H->uncovered.push_back(slot);  // the next copy into this slot waits for an event recorded behind this warp
         if ((int)H->uncovered.size() >= vstab_handle::WARP_EVENT_STRIDE) VSTAB_TRY(H->cover_warps());
     }
-    H->last_warp_slot = slot;
     return st;
 }
 
