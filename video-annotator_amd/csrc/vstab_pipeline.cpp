@@ -764,13 +764,16 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// consume_frame (FrameSourceWarp.cpp:397-450) split into four steps so that, per pull, the copy + pyramid
-// of frames k+2, k+3 and the LK tracking of frame k+1 run on the GPU while the host estimates the rotation
-// of frame k (PREFETCH_DEPTH frames of upstream read-ahead; three HIP streams ordered by events):
-//   prefetch_next    pull the next upstream frame, copy it into the ring, build its pyramid (pstream)
-//   launch_tracking  key-frame rule (:415-419), LK launch (tstream)
+// consume_frame (FrameSourceWarp.cpp:397-450) split into steps so that the copy + pyramid of the frames read ahead,
+// the (chained) LK tracking of frames k+1 and k+2 and the speculative corner detection run on the GPU while the host
+// estimates the rotation of frame k (PREFETCH_DEPTH frames of upstream read-ahead; four HIP streams ordered by events;
+// DESIGN.md section 5b):
+//   prefetch_next    pull the next upstream frame, copy it into the ring unless upstream holds it, build its pyramid
+//                    (pstream); start the speculative corner detection when the counter says a key frame is coming
+//   launch_tracking  key-frame rule (:415-419); adopt the launch chained behind the previous frame's tracker or launch
+//                    one; chain the next frame's tracker (tstream)
 //   finish_wait      LK results -> surviving pairs (:422-427)
-//   finish_estimate  rotation + fallback + accumulation + filter.add + queue push (:429-446)
+//   post_estimate / finish_estimate  rotation (worker thread) + fallback + accumulation + filter.add + queue push (:429-446)
 // Every step runs in frame order, so every decision, random draw and queue entry is the one the
 // reference makes; only WHEN the upstream callback is called moves (up to PREFETCH_DEPTH + 1 frames earlier).
 // ---------------------------------------------------------------------------------------------
@@ -779,8 +782,6 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
 static vstab_status prefetch_next(vstab_handle *H) {
     vstab_frame f;
     std::memset(&f, 0, sizeof(f));
-    // the previous frame's copy into the ring may still be in flight; upstream is allowed to recycle
-    // that frame's memory as soon as it is called again
     {
         // copies of frames whose planes upstream may recycle on this call must have finished (vstab_frame.hold)
         HT t(HostTimers::INGEST_SYNC);
