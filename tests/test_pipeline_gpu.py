@@ -525,3 +525,23 @@ def test_kalman_smoother_mode_matches_its_definition(vs, cuda, clip):
         expect = np.linalg.inv(corrected @ np.linalg.inv(lg["R_accum"]))      # :472, :475
         assert np.allclose(stab.warp_rotation(i), expect, atol=1e-10), i
     assert oracle.rotation_angle(stab.warp_rotation(10)) > 1e-4               # it does smooth: the correction is not the identity
+
+
+def test_pipeline_at_4k_baseline_config(vs, cuda):
+    """BASELINE config 3 geometry (3840x2160, WIDE169_MEASURED -> 3524x1999, the headline workload) end to end against
+    the oracle's state machine: key-frame decisions, corner and track counts, warp rotations, every emitted frame
+    bit-exact; rotations close to ground truth; NV12 pull of the same clip = converted BGR."""
+    w, h, r, n = 3840, 2160, 1, 4
+    K = oracle.get_preset_camera(4, w, h)
+    frames, rots = synth.shaky_clip(11, K, w, h, n, sigma=0.002)
+    log = _check_against_oracle_state_machine(vs, cuda, frames, K, w, h, r, 2)
+    for k, lg in enumerate(log, start=1):
+        assert lg["inliers"] >= 40 and oracle.rotation_angle(lg["R"] @ (rots[k] @ rots[k - 1].T).T) < 3e-3
+    import torch
+    Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
+    assert (cw, ch) == (3524, 1999)
+    s2 = vs.Stabilizer([torch.from_numpy(f).to(cuda) for f in frames], total=n, smooth_radius=r, seed=2)
+    y, uv = s2.pull_nv12()
+    bgr = oracle.warp_nv12(frames[1], oracle.map_params(K, Ko, s2.warp_rotation(0)), cw, ch)
+    ey, euv = oracle.cvt_bgr_nv12(bgr)
+    assert np.array_equal(y.cpu().numpy(), ey) and np.array_equal(uv.cpu().numpy().reshape(euv.shape), euv)
