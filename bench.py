@@ -12,7 +12,8 @@ Rank 0 prints ONE JSON line with the driver's contract plus
   "roofline":     the fused undistort-remap kernel's algorithmic bytes / measured launch time
                   (HIP events on the launch stream) against the 8 TB/s HBM peak, and
   "cpu_baseline": the CPU oracle (a port of the reference's cvtColor -> createMap -> remap path)
-                  timed on a bounded sample on this host's cores.
+                  timed on a bounded sample on this host's cores, and
+  "cpu_baseline_full_pipeline": the oracle's whole consume_frame / pull_frame loop (detector, LK, smoothing, warp).
 """
 import argparse
 import importlib
@@ -139,6 +140,34 @@ def cpu_baseline(w, h, K, Ko, cw, ch, budget_s=10.0):
     return {"value": round(n / el, 3), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{n} frames of {w}x{h} NV12 -> {cw}x{ch} BGR, undistort-remap only "
                       f"(cvtColor+createMap+remap, identity rotation), OpenMP over rows, {el:.1f} s"}
+
+
+def cpu_baseline_full(frames, K, Ko, cw, ch, w, h, budget_s=12.0):
+    """The whole reference loop on the host, restated (oracle): key-frame corner detection, pyramidal LK, SG smoothing,
+    cvtColor -> createMap -> remap -- consume_frame / pull_frame of FrameSourceWarp.cpp:397-476 on frames copied back
+    from the GPU ring.  The rotation estimate itself (a5, microseconds of fp64 work) is left out: identity rotations."""
+    import oracle
+    threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    oracle.lib().vo_set_num_threads(threads)
+
+    def track(prev, cur, corners):
+        if len(corners) == 0:
+            return corners, corners
+        nxt, st = oracle.pyr_lk(prev, cur, corners)
+        return corners[st > 0], nxt[st > 0]
+
+    r = 2  # look-ahead only delays the first output; it does not change the per-frame work
+    sm = oracle.WarpStateMachine(frames, r, lambda g: oracle.good_features(np.ascontiguousarray(g)), track,
+                                 lambda pp, cp: (np.eye(3), 100), lambda f, R: oracle.warp_nv12(f, oracle.map_params(K, Ko, R), cw, ch))
+    n, t0 = 0, time.perf_counter()
+    while sm.pull_frame() is not None:
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    return {"value": round(n / el, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n} frames of {w}x{h}: corner detection on key frames, pyramids + LK (single-threaded per call), SG filter, "
+                      f"cvtColor+createMap+remap (OpenMP), {el:.1f} s"}
 
 
 def main():
@@ -307,6 +336,10 @@ def main():
             line["stages_timed_region"] = timed_stages  # host waits + warp launches as they were in the timed region
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, h, K, Ko, cw, ch)
+            if mode == "pipeline" and not args.no_tracking:
+                host_ring = [f.cpu().numpy() for f in clip]
+                host_frames = [host_ring[i % len(host_ring)] for i in range(400)]  # bounded by the time budget inside
+                line["cpu_baseline_full_pipeline"] = cpu_baseline_full(host_frames, K, Ko, cw, ch, w, h)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
