@@ -314,6 +314,7 @@ typedef struct vstab_frame_log {
     double R_frame[9];   /* rotation since last frame actually used */
     double R_accum[9];   /* accumulated measured rotation (:441-442) */
 } vstab_frame_log;
+/* Indices are absolute (frames since the start); only the most recent 65536 entries are retained. */
 VSTAB_API int vstab_frame_log_count(const vstab_handle *h);
 VSTAB_API vstab_status vstab_get_frame_log(const vstab_handle *h, int index, vstab_frame_log *out);
 /* The rotation handed to the warp for the index-th emitted frame (rotation_correction.inv(), :475). */

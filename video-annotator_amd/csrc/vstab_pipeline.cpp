@@ -602,8 +602,11 @@ struct vstab_handle {
     RotationFilterKalman kalman;
     std::deque<std::pair<int, Mat3>> queue;    // m_buffered_frames + m_buffered_rotations
     Pcg32 rng;
-    std::vector<vstab_frame_log> log;
-    std::vector<Mat3> warp_log;
+    std::deque<vstab_frame_log> log;
+    std::deque<Mat3> warp_log;
+    // the introspection logs keep the most recent LOG_KEEP entries (indices stay absolute)
+    static constexpr size_t LOG_KEEP = 1 << 16;
+    long log_base = 0, warp_log_base = 0;
 
     // profiler
     int profiling = 0;  // 0 off, 1 warp launches only (cheap), 2 every GPU stage
@@ -1013,6 +1016,7 @@ static void finish_estimate(vstab_handle *H) {
     std::memcpy(lg.R_frame, R.m, sizeof(R.m));
     std::memcpy(lg.R_accum, H->measured.m, sizeof(R.m));
     H->log.push_back(lg);
+    if (H->log.size() > vstab_handle::LOG_KEEP) H->log.pop_front(), H->log_base++;
     H->have_ready = false;
 }
 
@@ -1169,6 +1173,7 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         warp_R = correction.inv();                           // :475
     }
     H->warp_log.push_back(warp_R);
+    if (H->warp_log.size() > vstab_handle::LOG_KEEP) H->warp_log.pop_front(), H->warp_log_base++;
     H->prof.frames_emitted++, H->prof.warp_launches++;
     float p[17];
     map_params(H->Kin, H->Kout, warp_R, p);
@@ -1260,17 +1265,19 @@ void vstab_destroy(vstab_handle *h) {
     delete h;
 }
 
-int vstab_frame_log_count(const vstab_handle *h) { return h ? (int)h->log.size() : 0; }
+int vstab_frame_log_count(const vstab_handle *h) { return h ? (int)(h->log_base + (long)h->log.size()) : 0; }
 
 vstab_status vstab_get_frame_log(const vstab_handle *h, int index, vstab_frame_log *out) {
-    if (!h || !out || index < 0 || index >= (int)h->log.size()) return fail(VSTAB_ERR_INVALID, "vstab_get_frame_log: bad index");
-    *out = h->log[index];
+    if (!h || !out || index < h->log_base || index >= h->log_base + (long)h->log.size())
+        return fail(VSTAB_ERR_INVALID, "vstab_get_frame_log: bad index (only the most recent 65536 entries are kept)");
+    *out = h->log[(size_t)(index - h->log_base)];
     return VSTAB_OK;
 }
 
 vstab_status vstab_get_warp_rotation(const vstab_handle *h, int index, double R[9]) {
-    if (!h || !R || index < 0 || index >= (int)h->warp_log.size()) return fail(VSTAB_ERR_INVALID, "vstab_get_warp_rotation: bad index");
-    std::memcpy(R, h->warp_log[index].m, sizeof(double) * 9);
+    if (!h || !R || index < h->warp_log_base || index >= h->warp_log_base + (long)h->warp_log.size())
+        return fail(VSTAB_ERR_INVALID, "vstab_get_warp_rotation: bad index (only the most recent 65536 entries are kept)");
+    std::memcpy(R, h->warp_log[(size_t)(index - h->warp_log_base)].m, sizeof(double) * 9);
     return VSTAB_OK;
 }
 
