@@ -234,7 +234,14 @@ class Tracker {
                     lk.unlock();
                     int result = 3;
                     const auto t0 = std::chrono::steady_clock::now();
-                    if (spec_ev_ && hipEventSynchronize(spec_ev_) == hipSuccess) {
+                    // poll instead of a blocking wait: the wake-up latency of hipEventSynchronize (hundreds of microseconds
+                    // on this runtime) would eat the lead the detection was given
+                    hipError_t q = hipErrorNotReady;
+                    if (spec_ev_) {
+                        for (long spins = 0; (q = hipEventQuery(spec_ev_)) == hipErrorNotReady && spins < 4000000; spins++) __builtin_ia32_pause();
+                        if (q == hipErrorNotReady) q = hipEventSynchronize(spec_ev_);
+                    }
+                    if (q == hipSuccess) {
                         const auto t1 = std::chrono::steady_clock::now();
                         const unsigned int n = *spec_host_.as<unsigned int>();
                         if (n <= SPEC_CAP) {
@@ -1066,8 +1073,8 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
         // copy + pyramid of the NEXT frame have a whole frame period of slack: lowest priority, so they fill
         // in behind the warp instead of taking its CUs
         VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, lo));
-        // detection has to be ready before its key frame's turn, PREFETCH_DEPTH frame periods after it is enqueued
-        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->dstream, hipStreamNonBlocking, (lo + hi) / 2));
+        // (this runtime offers two priority levels; beside a saturating warp the detection takes ~500 us at either)
+        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->dstream, hipStreamNonBlocking, lo));
         for (auto &e : H->warp_events) VSTAB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // :214-219 peek the first frame for the input size, then derive both cameras
