@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo only for rehearsing ranks on one GPU")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: initialise torch.distributed and run the collectives even with one rank (exercises the RCCL path on one GPU)")
     ap.add_argument("--traffic", default=None, help="measured HBM bytes per launch from PMC passes (profiles/)")
     return ap.parse_args()
 
@@ -185,11 +187,28 @@ def main():
     dev = torch.device("cuda", local)
     vs = importlib.import_module("video-annotator_amd")  # raises if libvstab.so is missing: no fallback
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where collective payloads live
-    if world > 1:
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL prints a version banner on stdout when the communicator is created; stdout is reserved for the one JSON
+        # line, so the banner is sent to stderr (fd-level redirect: it comes from C code)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()  # creates the communicator now
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     w, h = (3840, 2160) if args.workload == "4k" else (1920, 1080)
     preset = vs.GOPRO_H4B_WIDE169_MEASURED
@@ -252,18 +271,18 @@ def main():
     for i in range(args.warmup):
         step(i, False)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i, True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -341,7 +360,7 @@ def main():
                 host_frames = [host_ring[i % len(host_ring)] for i in range(400)]  # bounded by the time budget inside
                 line["cpu_baseline_full_pipeline"] = cpu_baseline_full(host_frames, K, Ko, cw, ch, w, h)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

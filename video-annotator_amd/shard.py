@@ -31,7 +31,7 @@ def gather_records(records, device=None):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return sorted(records, key=lambda r: r["clip"])
     n_local = torch.tensor([len(records)], dtype=torch.int64, device=device)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
