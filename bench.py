@@ -323,6 +323,23 @@ def main():
             dq = {k: q1[k] - q0[k] for k in q1}
             stages = {k.replace("_ms", "_us_per_frame"): round(v / max(1, dq["frames_emitted"]) * 1e3, 2) for k, v in dq.items() if k.endswith("_ms")}
             stages["key_frames_per_120"] = int(dq["key_frames"])
+        # the same kernel with nothing beside it (no tracker / pyramid / detection kernels on other streams): back-to-back
+        # launches on this stream bracketed by one event pair -- the figure that isolates kernel quality from co-scheduling
+        alone_us = None
+        if mode == "pipeline":
+            pa = vs.map_params(K, Ko, rot(7))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            run_alone = lambda i: vs.warp_nv12(clip[i % len(clip)], pa, cw, ch, vs.MAP_CREATEMAP_CL, vs.OUT_NV12 if nv12_out else vs.OUT_BGR8,
+                                               out=outs[i % args.ring])  # cycling inputs and outputs: nothing stays in the caches
+            for i in range(10):
+                run_alone(i)
+            torch.cuda.synchronize()
+            e0.record(stream)
+            for i in range(100):
+                run_alone(10 + i)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            alone_us = e0.elapsed_time(e1) / 100 * 1e3
         alg_bytes = w * h * 1.5 + cw * ch * 3  # NV12 read once + BGR8 written once
         if nv12_out:
             alg_bytes = w * h * 1.5 + cw * ch + 2 * ((cw + 1) // 2) * ((ch + 1) // 2)
@@ -348,7 +365,10 @@ def main():
                          "avg_launch_us": round(avg_ms * 1e3, 2) if avg_ms else None,
                          # the committed rocprofv3 --kernel-trace average of the same command (profiles/), for comparison:
                          # the HIP-event bracket also counts dispatch latency while other streams' kernels hold the CUs
-                         "rocprof_avg_launch_us_committed": rocprof_us},
+                         "rocprof_avg_launch_us_committed": rocprof_us,
+                         "alone": None if alone_us is None else {"avg_launch_us": round(alone_us, 2),
+                                                                   "achieved": round(alg_bytes / alone_us / 1e3, 1),
+                                                                   "frac": round(alg_bytes / alone_us / 1e3 / HBM_PEAK_GBS, 4)}},
         }
         if stages:
             line["stages"] = stages  # every GPU stage timed (extra pass outside the timed region; chained LK launches off)
