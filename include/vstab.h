@@ -199,6 +199,12 @@ VSTAB_API vstab_status vstab_rotation_filter_add(vstab_rotation_filter *f, const
 VSTAB_API vstab_status vstab_rotation_filter_filter(const vstab_rotation_filter *f, double R_out[9]);
 VSTAB_API void vstab_rotation_filter_destroy(vstab_rotation_filter *f);
 
+/* The `debug` overlay of the filter surface (render.ts:678): a filled (2*half+1)^2 square of colour bgr (0x00RRGGBB;
+ * the low byte alone for a 1-channel plane) at each of n centres (x, y int pairs in DEVICE memory), clipped. */
+VSTAB_API vstab_status vstab_draw_markers(void *dst, size_t pitch, int width, int height, int channels,
+                                          const int *centres_xy_device, int n, int half, unsigned int bgr,
+                                          void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * The pipeline object: drop-in for FrameSourceWarp behind the FrameSource pull interface
  * (FrameSource.hpp:9-24, FrameSourceWarp.hpp:83-91).
@@ -273,6 +279,8 @@ typedef struct vstab_config {
     int out_height;      /* out_h; 0 = input height */
     double out_cx;       /* out_fx "focal point"; negative = out_width / 2 (render.ts:682) */
     double out_cy;       /* out_fy; negative = out_height / 2 */
+    int debug;           /* debug (render.ts:678): mark the features tracked into each emitted frame (green 7x7 squares;
+                            luma 235 in NV12 output) at the positions the warp sends them to.  Works in both lens modes. */
 } vstab_config;
 
 typedef struct vstab_handle vstab_handle;

@@ -63,6 +63,7 @@ struct DewobbleOptions {
     double out_fx = -1, out_fy = -1;   // "focal point" = principal point; negative = out_w/2, out_h/2
     Stab stab = sg;
     int stab_r = 30;
+    bool debug = false;
 };
 
 // opencv/FrameSourceWarp.hpp:40-96.  `out` is caller-provided device storage for the frame returned
@@ -88,7 +89,7 @@ class FrameSourceWarp : public FrameSource {
         cfg.out_width = o.out_w, cfg.out_height = o.out_h, cfg.out_cx = o.out_fx, cfg.out_cy = o.out_fy;
         cfg.tracking = o.stab != DewobbleOptions::none;
         cfg.smoother = o.stab == DewobbleOptions::fixed ? VSTAB_SMOOTHER_FIXED : o.stab == DewobbleOptions::sg ? VSTAB_SMOOTHER_SG : VSTAB_SMOOTHER_NONE;
-        cfg.smooth_radius = o.stab == DewobbleOptions::sg ? o.stab_r : 0, cfg.stream = hip_stream;
+        cfg.smooth_radius = o.stab == DewobbleOptions::sg ? o.stab_r : 0, cfg.stream = hip_stream, cfg.debug = o.debug;
         init(cfg);
     }
     ~FrameSourceWarp() override { vstab_destroy(m_handle); }

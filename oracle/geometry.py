@@ -251,6 +251,40 @@ class KalmanRotationFilter:
         return rodrigues(out)
 
 
+def project_to_output(points, K_in, K_out, R_warp, in_fish=True, out_fish=False):
+    """Where the warp with rotation R_warp (the matrix handed to the map) sends input pixels: the inverse of the map --
+    input pixel -> ray (input projection) -> R_warp^T -> output projection.  Returns integer pixel centres (rounded half
+    to even) and a validity mask (ray in front of the output camera).  For the `debug` overlay."""
+    pts = np.asarray(points, np.float64).reshape(-1, 2)
+    a, b = (pts[:, 0] - K_in[0, 2]) / K_in[0, 0], (pts[:, 1] - K_in[1, 2]) / K_in[1, 1]
+    if in_fish:
+        th = np.hypot(a, b)
+        sc = np.where(th > 0, np.sin(th) / np.where(th > 0, th, 1), 1.0)
+        ray = np.stack([a * sc, b * sc, np.cos(th)], -1)
+    else:
+        ray = np.stack([a, b, np.ones_like(a)], -1)
+    o = ray @ np.asarray(R_warp)                    # rows: R^T ray
+    ok = o[:, 2] > 0
+    with np.errstate(all="ignore"):
+        u, v = o[:, 0] / o[:, 2], o[:, 1] / o[:, 2]
+        if out_fish:
+            r = np.hypot(o[:, 0], o[:, 1])
+            sc = np.where(r > 0, np.arctan2(r, o[:, 2]) / np.where(r > 0, r, 1), 1.0)
+            u, v = o[:, 0] * sc, o[:, 1] * sc
+    c = np.stack([np.rint(K_out[0, 2] + u * K_out[0, 0]), np.rint(K_out[1, 2] + v * K_out[1, 1])], -1)
+    return c[ok].astype(np.int64), ok
+
+
+def draw_markers(img, centres, half, colour):
+    """Filled (2*half+1)^2 squares, clipped.  img: (h, w, 3) BGR or (h, w) plane (modified in place)."""
+    h, w = img.shape[:2]
+    for x, y in centres:
+        x0, x1, y0, y1 = max(x - half, 0), min(x + half + 1, w), max(y - half, 0), min(y + half + 1, h)
+        if x0 < x1 and y0 < y1:
+            img[y0:y1, x0:x1] = colour
+    return img
+
+
 class WarpStateMachine:
     """consume_frame / pull_frame control flow, FrameSourceWarp.cpp:397-476, with the pixel and
     estimation steps injected so the same state machine can be driven by oracle or by recorded

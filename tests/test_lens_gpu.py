@@ -260,3 +260,30 @@ def test_pipeline_rejects_bad_lens(vs, cuda, clip):
             vs.Stabilizer(dev_frames, total=3, **cfg)
     with pytest.raises(vs.VstabError):
         vs.Stabilizer(dev_frames, total=3, smoother=9)
+
+
+def test_debug_overlay_marks_tracked_features(vs, cuda, clip):
+    """The filter surface's `debug` option (render.ts:678): green 7x7 squares where the warp sends the features tracked
+    into each emitted frame -- product vs oracle (inverse of the map on the oracle's own tracked points)."""
+    K, frames, rots = clip
+    r = 1
+    cfg = dict(lens_mode=1, in_projection=1, out_projection=0, in_dfov=150.0, out_dfov=110.0, out_width=480, out_height=270,
+               smooth_radius=r, seed=3)
+    plain_stab, plain = run(vs, cuda, frames[:5], **cfg)
+    dbg_stab, dbg = run(vs, cuda, frames[:5], debug=1, **cfg)
+    Kout = oracle.lens_camera(oracle.PROJ_RECT, 110.0, 480, 270)
+    h = H
+    corners = oracle.good_features(np.ascontiguousarray(frames[0][:h]))
+    nxt, st = oracle.pyr_lk(frames[0][:h], frames[1][:h], corners)
+    tracked = nxt[st > 0]
+    R = dbg_stab.warp_rotation(0)
+    assert np.allclose(R, plain_stab.warp_rotation(0), atol=0)
+    centres, ok = oracle.project_to_output(tracked, K, Kout, R, in_fish=True, out_fish=False)
+    exp = oracle.draw_markers(plain[0].copy(), centres, 3, (0, 255, 0))
+    assert np.array_equal(dbg[0], exp)
+    assert (dbg[0] != plain[0]).any(axis=-1).sum() > 20 * 49            # the markers are really there
+    # NV12 pull: markers in the luma plane only
+    _, dn = run(vs, cuda, frames[:5], nv12=True, debug=1, **cfg)
+    _, pn = run(vs, cuda, frames[:5], nv12=True, **cfg)
+    ey = oracle.draw_markers(pn[0][0].copy(), centres, 3, 235)
+    assert np.array_equal(dn[0][0], ey) and np.array_equal(dn[0][1], pn[0][1])

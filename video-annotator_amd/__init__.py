@@ -55,7 +55,7 @@ class Config(_c.Structure):  # vstab_config
     _fields_ = [("preset", _i), ("scale", _d), ("crop_borders", _i), ("zoom", _d), ("smooth_radius", _i),
                 ("interpolation", _i), ("smoother", _i), ("tracking", _i), ("seed", _u64), ("stream", _vp),
                 ("lens_mode", _i), ("in_projection", _i), ("out_projection", _i), ("in_dfov", _d), ("out_dfov", _d),
-                ("out_width", _i), ("out_height", _i), ("out_cx", _d), ("out_cy", _d)]
+                ("out_width", _i), ("out_height", _i), ("out_cx", _d), ("out_cy", _d), ("debug", _i)]
 
 
 class FrameLog(_c.Structure):  # vstab_frame_log
@@ -94,6 +94,7 @@ SIGNATURES = {
     "vstab_warp_nv12_bgr": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _vp, _sz, _i, _i, _vp]),
     "vstab_create_map_ex": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _vp]),
     "vstab_warp_nv12_ex": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
+    "vstab_draw_markers": (_i, [_vp, _sz, _i, _i, _i, _vp, _i, _i, _c.c_uint, _vp]),
     "vstab_pyr_down": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp]),
     "vstab_min_eig": (_i, [_vp, _sz, _i, _i, _vp, _vp]),
     "vstab_good_features": (_i, [_vp, _sz, _i, _i, _i, _d, _d, _fp, _ip, _vp]),

@@ -549,6 +549,7 @@ struct vstab_handle {
         const uint8_t *y = nullptr, *uv = nullptr;
         size_t pitch_y = 0, pitch_uv = 0;
         bool borrowed = false;
+        std::vector<float> feats;  // vstab_config.debug: the features tracked into this frame (input pixels)
         bool have_delta = false;  // upstream supplied this frame's rotation since the previous frame (vstab_frame.delta_rotation)
         Mat3 delta;
         bool queued = false, last = false;
@@ -664,6 +665,8 @@ struct vstab_handle {
     bool spec_is_key = false;    // that launch is a pre-launched key frame (fresh corners from the speculative detection)
     std::vector<float> pre_corners;
     DevBuf host_out;                // staging buffer of vstab_pull_frame_host
+    PinnedBuf marker_pts;           // vstab_config.debug: rotating sets of marker centres, read by the kernel in place
+    unsigned marker_set = 0;
     hipStream_t dstream = nullptr;  // speculative corner detection (137 us of kernels every 21st frame) beside everything else
     bool chain_lk = true;        // VSTAB_CHAIN_LK=0 disables chained launches
     long chained_adopted = 0, chained_discarded = 0, key_prelaunched = 0;
@@ -1020,6 +1023,7 @@ static void finish_estimate(vstab_handle *H) {
     H->measured = R * H->measured;  // :441 left-multiplied accumulation
     if (H->sg) H->sg->add(H->measured);
     H->queue.emplace_back(T.slot, H->measured);
+    if (H->cfg.debug) H->slots[T.slot].feats = T.cp;
     std::memcpy(lg.R_frame, R.m, sizeof(R.m));
     std::memcpy(lg.R_accum, H->measured.m, sizeof(R.m));
     H->log.push_back(lg);
@@ -1047,7 +1051,7 @@ void vstab_config_default(vstab_config *cfg) {
     cfg->scale = 1, cfg->crop_borders = 0, cfg->zoom = 1, cfg->smooth_radius = 30;  // FrameSourceWarp.hpp:86-89
     cfg->interpolation = 1, cfg->smoother = VSTAB_SMOOTHER_SG, cfg->tracking = 1, cfg->seed = 1, cfg->stream = nullptr;
     cfg->lens_mode = 0, cfg->in_projection = VSTAB_PROJ_FISH, cfg->out_projection = VSTAB_PROJ_RECT;
-    cfg->in_dfov = 0, cfg->out_dfov = 0, cfg->out_width = 0, cfg->out_height = 0, cfg->out_cx = -1, cfg->out_cy = -1;
+    cfg->in_dfov = 0, cfg->out_dfov = 0, cfg->out_width = 0, cfg->out_height = 0, cfg->out_cx = -1, cfg->out_cy = -1, cfg->debug = 0;
 }
 
 vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vstab_handle **out) {
@@ -1195,6 +1199,39 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         GpuStage gs(H, vstab_handle::ST_WARP);
         st = vstab_warp_nv12_ex(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, p, H->map_mode, out_format, dst,
                                 pitch_dst, dst_uv, pitch_dst_uv, H->ow, H->oh, H->stream);
+    }
+    if (st == VSTAB_OK && H->cfg.debug && !S.feats.empty()) {
+        // where the warp sends each tracked feature: input pixel -> ray -> R^T -> output projection (the inverse of the map)
+        constexpr int SETS = 16, CAP = 256;
+        VSTAB_TRY(H->marker_pts.ensure(sizeof(int) * 2 * CAP * SETS));
+        int *host = H->marker_pts.as<int>() + 2 * CAP * (H->marker_set % SETS);
+        int *dev = static_cast<int *>(H->marker_pts.dev()) + 2 * CAP * (H->marker_set % SETS);
+        H->marker_set++;
+        const bool out_fish = H->map_mode == VSTAB_MAP_FISH_TO_FISH || H->map_mode == VSTAB_MAP_RECT_TO_FISH;
+        int n = 0;
+        for (size_t i = 0; i + 1 < S.feats.size() && n < CAP; i += 2) {
+            const double a = (S.feats[i] - H->Kin(0, 2)) / H->Kin(0, 0), b = (S.feats[i + 1] - H->Kin(1, 2)) / H->Kin(1, 1);
+            double rx = a, ry = b, rz = 1;
+            if (H->in_fish) {
+                const double th = std::hypot(a, b), sc = th > 0 ? std::sin(th) / th : 1.0;
+                rx = a * sc, ry = b * sc, rz = std::cos(th);
+            }
+            const double ox = warp_R(0, 0) * rx + warp_R(1, 0) * ry + warp_R(2, 0) * rz, oy = warp_R(0, 1) * rx + warp_R(1, 1) * ry + warp_R(2, 1) * rz,
+                         oz = warp_R(0, 2) * rx + warp_R(1, 2) * ry + warp_R(2, 2) * rz;
+            if (!(oz > 0)) continue;
+            double u = ox / oz, v = oy / oz;
+            if (out_fish) {
+                const double r = std::hypot(ox, oy), th = std::atan2(r, oz), sc = r > 0 ? th / r : 1.0;
+                u = ox * sc, v = oy * sc;
+            }
+            host[2 * n] = (int)std::nearbyint(H->Kout(0, 2) + u * H->Kout(0, 0)), host[2 * n + 1] = (int)std::nearbyint(H->Kout(1, 2) + v * H->Kout(1, 1));
+            n++;
+        }
+        if (out_format == VSTAB_OUT_NV12)
+            st = vstab_draw_markers(dst, pitch_dst, H->ow, H->oh, 1, dev, n, 3, 235u, H->stream);
+        else
+            st = vstab_draw_markers(dst, pitch_dst, H->ow, H->oh, 3, dev, n, 3, 0x0000FF00u, H->stream);
+        S.feats.clear();
     }
     S.queued = false, S.freed_at = ++H->free_counter;
     if (!S.borrowed) {

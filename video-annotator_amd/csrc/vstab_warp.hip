@@ -540,6 +540,21 @@ __global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
     }
 }
 
+// k_draw_markers -- the debug overlay of the lens surface (libdewobble's `debug` option, render.ts:678): a filled
+// (2 * half + 1)^2 square at every tracked feature, clipped to the image.  One workgroup per feature.
+__global__ void __launch_bounds__(64) k_draw_markers(uint8_t *__restrict__ dst, size_t pitch, int w, int h, int channels,
+                                                     const int2 *__restrict__ centres, int half, uint32_t bgr) {
+    const int2 c = centres[blockIdx.x];
+    const int side = 2 * half + 1;
+    for (int e = threadIdx.x; e < side * side; e += 64) {
+        const int x = c.x - half + e % side, y = c.y - half + e / side;
+        if (x < 0 || y < 0 || x >= w || y >= h) continue;
+        uint8_t *o = dst + (size_t)y * pitch + (size_t)x * channels;
+        o[0] = bgr & 255;
+        if (channels == 3) o[1] = (bgr >> 8) & 255, o[2] = (bgr >> 16) & 255;
+    }
+}
+
 static MapParams to_params(const float p[17]) {
     MapParams m;
     m.icx = p[0], m.icy = p[1], m.ifx = p[2], m.ify = p[3];
@@ -752,6 +767,18 @@ vstab_status vstab_warp_nv12_ex(const void *y, size_t pitch_y, const void *uv, s
         }
 #undef VSTAB_LAUNCH
     }
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+vstab_status vstab_draw_markers(void *dst, size_t pitch, int width, int height, int channels, const int *centres_xy, int n, int half,
+                                unsigned int bgr, void *stream) {
+    if (!dst || width <= 0 || height <= 0 || (channels != 1 && channels != 3) || pitch < (size_t)width * channels || n < 0 || half < 0 ||
+        half > 16 || (n > 0 && !centres_xy))
+        return fail(VSTAB_ERR_INVALID, "vstab_draw_markers: bad argument");
+    if (n == 0) return VSTAB_OK;
+    hipLaunchKernelGGL(k_draw_markers, dim3(n), dim3(64), 0, static_cast<hipStream_t>(stream), (uint8_t *)dst, pitch, width, height, channels,
+                       reinterpret_cast<const int2 *>(centres_xy), half, bgr);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }
