@@ -199,6 +199,18 @@ VSTAB_API vstab_status vstab_rotation_filter_add(vstab_rotation_filter *f, const
 VSTAB_API vstab_status vstab_rotation_filter_filter(const vstab_rotation_filter *f, double R_out[9]);
 VSTAB_API void vstab_rotation_filter_destroy(vstab_rotation_filter *f);
 
+/* A map that does not change between frames (tracking off: undistort only, the CLI's stab=none re-projections) need
+ * not be evaluated per frame as the reference does (FrameSourceWarp.cpp:283-304): vstab_quantised_map writes, once,
+ * what cv::remap makes of every map entry (32 * map rounded to int; vstab_quantised_map_bytes() bytes, 16-byte aligned
+ * device memory), and vstab_warp_nv12_mapped warps with it -- same integers, same pixels as vstab_warp_nv12_ex. */
+VSTAB_API size_t vstab_quantised_map_bytes(int dst_width, int dst_height);
+VSTAB_API vstab_status vstab_quantised_map(void *qmap, int dst_width, int dst_height, const float params[17],
+                                           int map_mode, void *stream);
+VSTAB_API vstab_status vstab_warp_nv12_mapped(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv,
+                                              int src_width, int src_height, const void *qmap, int out_format,
+                                              void *dst, size_t pitch_dst, void *dst_uv, size_t pitch_dst_uv,
+                                              int dst_width, int dst_height, void *stream);
+
 /* The `debug` overlay of the filter surface (render.ts:678): a filled (2*half+1)^2 square of colour bgr (0x00RRGGBB;
  * the low byte alone for a 1-channel plane) at each of n centres (x, y int pairs in DEVICE memory), clipped. */
 VSTAB_API vstab_status vstab_draw_markers(void *dst, size_t pitch, int width, int height, int channels,

@@ -287,3 +287,32 @@ def test_debug_overlay_marks_tracked_features(vs, cuda, clip):
     _, pn = run(vs, cuda, frames[:5], nv12=True, **cfg)
     ey = oracle.draw_markers(pn[0][0].copy(), centres, 3, 235)
     assert np.array_equal(dn[0][0], ey) and np.array_equal(dn[0][1], pn[0][1])
+
+
+def test_quantised_map_warp_equals_direct_warp(vs, cuda):
+    """vstab_quantised_map + vstab_warp_nv12_mapped (the map written once for a run of frames with equal parameters)
+    give the bytes of vstab_warp_nv12_ex for every mode, both formats, both tile shapes and odd sizes."""
+    for (w, h, dw, dh) in [(640, 360, 583, 331), (1920, 1080, 1759, 998), (3840, 2160, 3524, 1999), (320, 180, 67, 35)]:
+        f = synth.nv12(w + dh, w, h)
+        fd = dev(f, cuda)
+        for ip, ifov, op, ofov in LENSES[:2] if w > 2000 else LENSES:
+            Kin, Kout = oracle.lens_camera(ip, ifov, w, h), oracle.lens_camera(op, ofov, dw, dh)
+            mode = oracle.map_mode(ip, op)
+            for rv in [ROTS[0], ROTS[2]]:
+                p = oracle.map_params(Kin, Kout, oracle.rodrigues(rv))
+                q = vs.quantised_map(p, dw, dh, mode)
+                a = vs.warp_nv12(fd, p, dw, dh, mode, vs.OUT_BGR8)
+                b = vs.warp_nv12_mapped(fd, q, dw, dh, vs.OUT_BGR8)
+                assert bool((a == b).all()), (w, mode, rv)
+                ay, ac = vs.warp_nv12(fd, p, dw, dh, mode, vs.OUT_NV12)
+                by, bc = vs.warp_nv12_mapped(fd, q, dw, dh, vs.OUT_NV12)
+                assert bool((ay == by).all()) and bool((ac == bc).all()), (w, mode, rv)
+    # the reference kernel's map too (NaN on the optical axis included)
+    K = oracle.get_preset_camera(4, 640, 360)
+    Ko, (cw, ch) = oracle.get_output_camera(K, 640, 360)
+    Ko = Ko.copy(); Ko[0, 2], Ko[1, 2] = round(Ko[0, 2]), round(Ko[1, 2])
+    p = oracle.map_params(K, Ko, np.eye(3))
+    fd = dev(synth.nv12(5, 640, 360), cuda)
+    a = vs.warp_nv12(fd, p, cw, ch, vs.MAP_CREATEMAP_CL)
+    b = vs.warp_nv12_mapped(fd, vs.quantised_map(p, cw, ch, vs.MAP_CREATEMAP_CL), cw, ch)
+    assert bool((a == b).all()) and int(a[int(Ko[1, 2]), int(Ko[0, 2])].sum()) == 0

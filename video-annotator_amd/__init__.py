@@ -94,6 +94,9 @@ SIGNATURES = {
     "vstab_warp_nv12_bgr": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _vp, _sz, _i, _i, _vp]),
     "vstab_create_map_ex": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _vp]),
     "vstab_warp_nv12_ex": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
+    "vstab_quantised_map_bytes": (_sz, [_i, _i]),
+    "vstab_quantised_map": (_i, [_vp, _i, _i, _fp, _i, _vp]),
+    "vstab_warp_nv12_mapped": (_i, [_vp, _sz, _vp, _sz, _i, _i, _vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
     "vstab_draw_markers": (_i, [_vp, _sz, _i, _i, _i, _vp, _i, _i, _c.c_uint, _vp]),
     "vstab_pyr_down": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp]),
     "vstab_min_eig": (_i, [_vp, _sz, _i, _i, _vp, _vp]),
@@ -313,6 +316,32 @@ def warp_nv12(nv12, params, dw, dh, mode=MAP_CREATEMAP_CL, out_format=OUT_BGR8, 
     yo, co = out
     _check(_L.vstab_warp_nv12_ex(yp, pitch, uvp, pitch, w, h, _fptr(p), int(mode), int(out_format), yo.data_ptr(), yo.stride(0),
                                  co.data_ptr(), co.stride(0), dw, dh, _stream()), "vstab_warp_nv12_ex")
+    return yo, co
+
+
+def quantised_map(params, dw, dh, mode=MAP_CREATEMAP_CL, device="cuda"):
+    """The per-pixel quantised map for a run of frames with the same warp parameters -> opaque device tensor."""
+    import torch
+    p = np.ascontiguousarray(params, np.float32)
+    q = torch.empty(_L.vstab_quantised_map_bytes(dw, dh), dtype=torch.uint8, device=device)
+    _check(_L.vstab_quantised_map(q.data_ptr(), dw, dh, _fptr(p), int(mode), _stream()), "vstab_quantised_map")
+    return q
+
+
+def warp_nv12_mapped(nv12, qmap, dw, dh, out_format=OUT_BGR8, out=None):
+    import torch
+    yp, uvp, pitch, w, h = _planes(nv12)
+    if out_format == OUT_BGR8:
+        if out is None:
+            out = torch.empty((dh, dw, 3), dtype=torch.uint8, device=nv12.device)
+        _check(_L.vstab_warp_nv12_mapped(yp, pitch, uvp, pitch, w, h, qmap.data_ptr(), OUT_BGR8, out.data_ptr(), out.stride(0), None, 0,
+                                         dw, dh, _stream()), "vstab_warp_nv12_mapped")
+        return out
+    if out is None:
+        out = nv12_out_planes(dw, dh, nv12.device)
+    yo, co = out
+    _check(_L.vstab_warp_nv12_mapped(yp, pitch, uvp, pitch, w, h, qmap.data_ptr(), int(out_format), yo.data_ptr(), yo.stride(0),
+                                     co.data_ptr(), co.stride(0), dw, dh, _stream()), "vstab_warp_nv12_mapped")
     return yo, co
 
 

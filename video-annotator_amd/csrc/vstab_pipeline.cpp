@@ -665,6 +665,13 @@ struct vstab_handle {
     bool spec_is_key = false;    // that launch is a pre-launched key frame (fresh corners from the speculative detection)
     std::vector<float> pre_corners;
     DevBuf host_out;                // staging buffer of vstab_pull_frame_host
+    // Quantised-map cache: when two consecutive frames are warped with the same 17 parameters (tracking off, or any
+    // run of identical rotations) the map is written once (vstab_quantised_map) and the following warps read it
+    // instead of evaluating it -- the reference recomputes an identical map per frame (FrameSourceWarp.cpp:283-304).
+    DevBuf qmap;
+    float qmap_params[17] = {0}, last_params[17] = {0};
+    bool qmap_valid = false, have_last_params = false, map_cache = true;  // VSTAB_MAP_CACHE=0 disables
+    long warps_from_cache = 0;
     PinnedBuf marker_pts;           // vstab_config.debug: rotating sets of marker centres, read by the kernel in place
     unsigned marker_set = 0;
     hipStream_t dstream = nullptr;  // speculative corner detection (137 us of kernels every 21st frame) beside everything else
@@ -1067,6 +1074,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (const char *e = getenv("VSTAB_SPECULATE")) H->speculate = atoi(e) != 0;
     if (const char *e = getenv("VSTAB_THREADED_ESTIMATE")) H->threaded_estimate = atoi(e) != 0;
     if (const char *e = getenv("VSTAB_CHAIN_LK")) H->chain_lk = atoi(e) != 0;
+    if (const char *e = getenv("VSTAB_MAP_CACHE")) H->map_cache = atoi(e) != 0;
     H->stream = static_cast<hipStream_t>(cfg->stream);  // NULL = the default stream, as for the stateless operators
     {
         // the tracking chain is the per-frame critical path; the warp only has to finish before the
@@ -1189,7 +1197,21 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
     float p[17];
     map_params(H->Kin, H->Kout, warp_R, p);
     vstab_handle::Slot &S = H->slots[slot];
-
+    bool cached = false;
+    if (H->map_cache) {
+        if (H->qmap_valid && std::memcmp(p, H->qmap_params, sizeof(p)) == 0) {
+            cached = true;
+        } else if (H->have_last_params && std::memcmp(p, H->last_params, sizeof(p)) == 0) {
+            // second frame in a row with these parameters: write the map down now (same stream, ahead of the warp)
+            VSTAB_TRY(H->qmap.ensure(vstab_quantised_map_bytes(H->ow, H->oh)));
+            VSTAB_TRY(vstab_quantised_map(H->qmap.p, H->ow, H->oh, p, H->map_mode, H->stream));
+            std::memcpy(H->qmap_params, p, sizeof(p));
+            H->qmap_valid = cached = true;
+        }
+        std::memcpy(H->last_params, p, sizeof(p));
+        H->have_last_params = true;
+        H->warps_from_cache += cached;
+    }
     HT t_warp(HostTimers::WARP);
     VSTAB_TRY(vstab_handle::wait_if_pending(H->stream, S.ingested));  // the slot was filled on the prefetch stream (long ago, as a rule)
     vstab_status st;
@@ -1197,8 +1219,12 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         // the profiling events bracket the launch call and nothing else, so the interval is the kernel
         // (plus its dispatch), not host work between two API calls
         GpuStage gs(H, vstab_handle::ST_WARP);
-        st = vstab_warp_nv12_ex(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, p, H->map_mode, out_format, dst,
-                                pitch_dst, dst_uv, pitch_dst_uv, H->ow, H->oh, H->stream);
+        if (cached)
+            st = vstab_warp_nv12_mapped(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, H->qmap.p, out_format, dst, pitch_dst, dst_uv, pitch_dst_uv,
+                                        H->ow, H->oh, H->stream);
+        else
+            st = vstab_warp_nv12_ex(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, p, H->map_mode, out_format, dst,
+                                    pitch_dst, dst_uv, pitch_dst_uv, H->ow, H->oh, H->stream);
     }
     if (st == VSTAB_OK && H->cfg.debug && !S.feats.empty()) {
         // where the warp sends each tracked feature: input pixel -> ray -> R^T -> output projection (the inverse of the map)
@@ -1288,7 +1314,8 @@ void vstab_destroy(vstab_handle *h) {
     h->fold_pending();
     h->tracker.report_clock();
     if (getenv("VSTAB_DEBUG_SPEC"))
-        std::fprintf(stderr, "frames used in place %ld, copied into the ring %ld\n", h->frames_borrowed, h->frames_copied);
+        std::fprintf(stderr, "frames used in place %ld, copied into the ring %ld; warps from the cached map %ld\n", h->frames_borrowed, h->frames_copied,
+                     h->warps_from_cache);
     if (getenv("VSTAB_DEBUG_SPEC"))
         std::fprintf(stderr, "chained LK launches: adopted %ld, discarded %ld of %ld frames; key frames pre-launched %ld of %ld\n", h->chained_adopted,
                      h->chained_discarded, h->frame_index, h->key_prelaunched, h->prof.key_frames);

@@ -309,6 +309,8 @@ struct TiledArgs {
     int dst_vec_ok;
     int debug_mode;       // 0 = product; >0 = timing-only ablations (VSTAB_DEBUG_MODE, outputs wrong)
     int tiles_x, tiles_y;
+    const int2 *qmap;   // CACHED kernels: the quantised map (32 * map rounded to int, NaN -> INT_MIN in x) of every output pixel
+    int qpitch;         // its row pitch in pixels (a multiple of 4)
 };
 
 __device__ __forceinline__ uint32_t gather_pixel(const WarpArgs &a, int sx, int sy) {
@@ -333,7 +335,10 @@ __device__ __forceinline__ uint32_t load_u32_bytes(const uint8_t *p, int valid) 
     return v;
 }
 
-template <int RPT, int TY, int MODE = MAP_CREATEMAP_CL, int FMT = 0>
+// CACHED: phase 1 loads the quantised map written by k_quantised_map instead of evaluating it -- for runs of frames
+// warped with the same parameters (tracking off: the undistort-only configuration, the CLI's stab=none re-projections),
+// where the reference recomputes an identical map every frame.  Same integers, so the same pixels.
+template <int RPT, int TY, int MODE = MAP_CREATEMAP_CL, int FMT = 0, bool CACHED = false>
 __global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
     constexpr int NT = 16 * TY;  // threads per workgroup: 16 columns of 4 pixels x TY thread rows
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -376,8 +381,28 @@ __global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
             const int y = ybase + TY * j;
             const float vy = div_with_rcp((float)y - a.p.ocy, a.p.ofy, rfy);
             const RowTerm rt = {a.p.r[1] * vy, a.p.r[4] * vy, a.p.r[7] * vy};
+            int2 qv[4];
+            if constexpr (CACHED) {
+                // pixels past the right / bottom edge of the output have no map entry: clamp (they are never stored)
+                const uint4 *qp = reinterpret_cast<const uint4 *>(ta.qmap + (size_t)min(y, a.dh - 1) * ta.qpitch + min(x0, ta.qpitch - 4));
+                const uint4 q01 = qp[0], q23 = qp[1];  // x0 is a multiple of 4 and the pitch pads the row to one
+                qv[0] = make_int2((int)q01.x, (int)q01.y), qv[1] = make_int2((int)q01.z, (int)q01.w);
+                qv[2] = make_int2((int)q23.x, (int)q23.y), qv[3] = make_int2((int)q23.z, (int)q23.w);
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
+                if constexpr (CACHED) {
+                    const int qx = qv[i].x, qy = qv[i].y;
+                    const int X = qx >> 5, Y = qy >> 5;
+                    sx[j][i] = qx, sy[j][i] = qy;
+                    const bool inside = (uint32_t)X < sw1 && (uint32_t)Y < sh1;
+                    in_bits |= (inside ? 1u : 0u) << (j * 4 + i);
+                    int Xc, Yc;
+                    asm("v_med3_i32 %0, %1, -1, %2" : "=v"(Xc) : "v"(X), "s"(a.sw));
+                    asm("v_med3_i32 %0, %1, -1, %2" : "=v"(Yc) : "v"(Y), "s"(a.sh));
+                    mnx = min(mnx, Xc), mxx = max(mxx, Xc), mny = min(mny, Yc), mxy = max(mxy, Yc);
+                    continue;
+                }
                 float ax, ay;
                 map_pixel_ex<MODE>(ta.p32, a.p, ct[i], rt, vxs[i], vy, ax, ay);
                 // v_cvt_i32_f32 saturates (+-inf and out-of-range -> INT_MAX / INT_MIN, which land far
@@ -540,6 +565,31 @@ __global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
     }
 }
 
+// k_quantised_map -- the map of every output pixel as cv::remap quantises it (32 * map rounded half to even; a NaN
+// entry gets x = INT_MIN), written once for a run of frames that share their warp parameters (see CACHED above).
+// Exactly the phase-1 arithmetic of k_warp_tiled.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_quantised_map(int2 *__restrict__ qmap, int qpitch, int dw, int dh, MapParams p, MapParams32 p32) {
+    const int x0 = (blockIdx.x * 16 + (threadIdx.x & 15)) * 4, y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x0 >= qpitch || y >= dh) return;
+    const float rfx = rcp_refined(p.ofx), rfy = rcp_refined(p.ofy);
+    const float vy = div_with_rcp((float)y - p.ocy, p.ofy, rfy);
+    const RowTerm rt = {p.r[1] * vy, p.r[4] * vy, p.r[7] * vy};
+    int q[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float vx = div_with_rcp((float)(x0 + i) - p.ocx, p.ofx, rfx);
+        const ColTerm ct = {p.r[0] * vx, p.r[3] * vx, p.r[6] * vx};
+        float ax, ay;
+        map_pixel_ex<MODE>(p32, p, ct, rt, vx, vy, ax, ay);
+        const bool ok = !__builtin_isunordered(ax, ay);
+        q[2 * i] = ok ? (int)__builtin_rintf(ax) : INT_MIN, q[2 * i + 1] = (int)__builtin_rintf(ay);
+    }
+    uint4 *o = reinterpret_cast<uint4 *>(qmap + (size_t)y * qpitch + x0);
+    o[0] = make_uint4((uint32_t)q[0], (uint32_t)q[1], (uint32_t)q[2], (uint32_t)q[3]);
+    o[1] = make_uint4((uint32_t)q[4], (uint32_t)q[5], (uint32_t)q[6], (uint32_t)q[7]);
+}
+
 // k_draw_markers -- the debug overlay of the lens surface (libdewobble's `debug` option, render.ts:678): a filled
 // (2 * half + 1)^2 square at every tracked feature, clipped to the image.  One workgroup per feature.
 __global__ void __launch_bounds__(64) k_draw_markers(uint8_t *__restrict__ dst, size_t pitch, int w, int h, int channels,
@@ -693,9 +743,11 @@ vstab_status vstab_remap_bilinear(const void *src, size_t pitch_src, int sw, int
     return VSTAB_OK;
 }
 
-vstab_status vstab_warp_nv12_ex(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh,
-                                const float params[17], int map_mode, int out_format, void *dst, size_t pitch_dst,
-                                void *dst_uv, size_t pitch_dst_uv, int dw, int dh, void *stream) {
+}  // extern "C"
+
+static vstab_status warp_impl(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh,
+                              const float params[17], int map_mode, int out_format, void *dst, size_t pitch_dst,
+                              void *dst_uv, size_t pitch_dst_uv, int dw, int dh, void *stream, const void *qmap, int qpitch) {
     if (!y || !uv || !dst || !params) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: null pointer");
     if (sw <= 0 || sh <= 0 || (sw & 1) || (sh & 1) || sw > 32767 || sh > 32767)
         return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: source must be even-sized and <= 32767");
@@ -717,7 +769,7 @@ vstab_status vstab_warp_nv12_ex(const void *y, size_t pitch_y, const void *uv, s
     const int vec_ok = aligned(dst, 4) && pitch_dst % 4 == 0 && (!nv12_out || (aligned(dst_uv, 4) && pitch_dst_uv % 4 == 0));
     static const int variant = getenv("VSTAB_WARP_VARIANT") ? atoi(getenv("VSTAB_WARP_VARIANT")) : 2;
     const bool small_pitch = pitch_y < (1u << 24) && pitch_uv < (1u << 24) && (uint64_t)pitch_y * sh < (1ull << 32);
-    const bool plain = map_mode == VSTAB_MAP_CREATEMAP_CL && !nv12_out;
+    const bool plain = map_mode == VSTAB_MAP_CREATEMAP_CL && !nv12_out && !qmap;
     if (!plain && !small_pitch) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: source pitch too large for this mode");
     if (plain && (variant == 1 || !small_pitch)) {  // v1 direct-gather kernel (kept as the in-kernel fallback's twin, for A/B runs)
         dim3 grid(div_up(dw, WARP_TILE_W), div_up(dh, WARP_TILE_H));
@@ -737,7 +789,8 @@ vstab_status vstab_warp_nv12_ex(const void *y, size_t pitch_y, const void *uv, s
         // slots of the chip a few rounds of tiles; 64 x 16 with 24 KB for small outputs (1080p: 896 tiles of 64 x 32
         // would leave CUs idle; measured 16.6 us against 18.1).  The knobs exist for the reference mode only.
         const long tiles32 = (long)div_up(dw, WARP_TILE_W) * div_up(dh, 32);
-        const int rpt = !plain ? 2 : rpt_env ? rpt_env : (tiles32 < 1536 ? 1 : 2), tyr = plain ? tyr_env : 16;
+        const int rpt = qmap ? (tiles32 < 1536 ? 1 : 2) : !plain ? 2 : rpt_env ? rpt_env : (tiles32 < 1536 ? 1 : 2), tyr = plain ? tyr_env : 16;
+        ta.qmap = static_cast<const int2 *>(qmap), ta.qpitch = qpitch;
         const int lds_kb = lds_env ? lds_env : (rpt == 1 && tyr == 16 ? 24 : 40);
         const size_t lds_bytes = (size_t)lds_kb * 1024;
         // the staging loop keeps at most 5 trips x 8 pixels per thread in flight (STAGE_MAX in k_warp_tiled)
@@ -746,7 +799,12 @@ vstab_status vstab_warp_nv12_ex(const void *y, size_t pitch_y, const void *uv, s
         dim3 grid(8 * div_up((unsigned)(ta.tiles_x * ta.tiles_y), 8));
         hipStream_t st = static_cast<hipStream_t>(stream);
 #define VSTAB_LAUNCH(R, T, M, F) hipLaunchKernelGGL((k_warp_tiled<R, T, M, F>), grid, dim3(16 * T), lds_bytes, st, ta)
-        if (plain) {
+        if (qmap) {  // phase 1 reads the quantised map: the map mode no longer matters
+            if (rpt == 1 && !nv12_out) hipLaunchKernelGGL((k_warp_tiled<1, 16, MAP_CREATEMAP_CL, 0, true>), grid, dim3(256), lds_bytes, st, ta);
+            else if (rpt == 1) hipLaunchKernelGGL((k_warp_tiled<1, 16, MAP_CREATEMAP_CL, 1, true>), grid, dim3(256), lds_bytes, st, ta);
+            else if (!nv12_out) hipLaunchKernelGGL((k_warp_tiled<2, 16, MAP_CREATEMAP_CL, 0, true>), grid, dim3(256), lds_bytes, st, ta);
+            else hipLaunchKernelGGL((k_warp_tiled<2, 16, MAP_CREATEMAP_CL, 1, true>), grid, dim3(256), lds_bytes, st, ta);
+        } else if (plain) {
             if (tyr == 8 && rpt == 2) VSTAB_LAUNCH(2, 8, MAP_CREATEMAP_CL, 0);
             else if (tyr == 8 && rpt == 4) VSTAB_LAUNCH(4, 8, MAP_CREATEMAP_CL, 0);
             else if (tyr == 4 && rpt == 4) VSTAB_LAUNCH(4, 4, MAP_CREATEMAP_CL, 0);
@@ -781,6 +839,49 @@ vstab_status vstab_draw_markers(void *dst, size_t pitch, int width, int height, 
                        reinterpret_cast<const int2 *>(centres_xy), half, bgr);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
+}
+
+extern "C" {
+
+vstab_status vstab_warp_nv12_ex(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh,
+                                const float params[17], int map_mode, int out_format, void *dst, size_t pitch_dst,
+                                void *dst_uv, size_t pitch_dst_uv, int dw, int dh, void *stream) {
+    return warp_impl(y, pitch_y, uv, pitch_uv, sw, sh, params, map_mode, out_format, dst, pitch_dst, dst_uv, pitch_dst_uv, dw, dh, stream, nullptr, 0);
+}
+
+size_t vstab_quantised_map_bytes(int dst_width, int dst_height) {
+    return dst_width > 0 && dst_height > 0 ? (size_t)((dst_width + 3) & ~3) * dst_height * 8 : 0;
+}
+
+vstab_status vstab_quantised_map(void *qmap, int dw, int dh, const float params[17], int map_mode, void *stream) {
+    if (!qmap || !params || dw <= 0 || dh <= 0 || dw > 32767 || dh > 32767) return fail(VSTAB_ERR_INVALID, "vstab_quantised_map: bad argument");
+    if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_RECT_TO_FISH) return fail(VSTAB_ERR_INVALID, "vstab_quantised_map: unknown map mode");
+    if (!aligned(qmap, 16)) return fail(VSTAB_ERR_INVALID, "vstab_quantised_map: the buffer must be 16-byte aligned");
+    const int qpitch = (dw + 3) & ~3;
+    const MapParams p = to_params(params);
+    const MapParams32 p32 = {params[0] * 32.0f, params[1] * 32.0f, params[2] * 32.0f, params[3] * 32.0f, params[10], params[13], params[16]};
+    dim3 grid(div_up(qpitch / 4, 16), div_up(dh, 16));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define VSTAB_LAUNCH(M) hipLaunchKernelGGL(k_quantised_map<M>, grid, dim3(256), 0, st, static_cast<int2 *>(qmap), qpitch, dw, dh, p, p32)
+    switch (map_mode) {
+        case VSTAB_MAP_CREATEMAP_CL: VSTAB_LAUNCH(MAP_CREATEMAP_CL); break;
+        case VSTAB_MAP_FISH_TO_RECT: VSTAB_LAUNCH(MAP_FISH_TO_RECT); break;
+        case VSTAB_MAP_FISH_TO_FISH: VSTAB_LAUNCH(MAP_FISH_TO_FISH); break;
+        case VSTAB_MAP_RECT_TO_RECT: VSTAB_LAUNCH(MAP_RECT_TO_RECT); break;
+        default: VSTAB_LAUNCH(MAP_RECT_TO_FISH); break;
+    }
+#undef VSTAB_LAUNCH
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+vstab_status vstab_warp_nv12_mapped(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh, const void *qmap,
+                                    int out_format, void *dst, size_t pitch_dst, void *dst_uv, size_t pitch_dst_uv, int dw, int dh,
+                                    void *stream) {
+    if (!qmap || !aligned(qmap, 16)) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_mapped: the quantised map must be a 16-byte aligned device buffer");
+    static const float unused[17] = {0};
+    return warp_impl(y, pitch_y, uv, pitch_uv, sw, sh, unused, VSTAB_MAP_CREATEMAP_CL, out_format, dst, pitch_dst, dst_uv, pitch_dst_uv, dw, dh, stream,
+                     qmap, (dw + 3) & ~3);
 }
 
 vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh,
