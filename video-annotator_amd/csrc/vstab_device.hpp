@@ -139,6 +139,72 @@ __device__ __forceinline__ void map_pixel32(const MapParams32 &p, const ColTerm 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same arithmetic on two pixels at once (ext_vector_type(2) -> v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, which issue
+// two fp32 operations in 4.8 cycles where two v_fma_f32 take 8; tools/probe_rate.hip).  Every component goes through exactly
+// the operation sequence of the scalar functions above, so the results are bit-identical to them.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
+__device__ __forceinline__ f32x2 rcp_refined2(f32x2 d) {
+    const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const f32x2 e = fma2(-d, r, splat2(1.0f));
+    return fma2(e, r, r);
+}
+__device__ __forceinline__ f32x2 div_with_rcp2(f32x2 n, f32x2 d, f32x2 r) {
+    f32x2 q = n * r;
+    f32x2 e = fma2(-d, q, n);
+    q = fma2(e, r, q);
+    e = fma2(-d, q, n);
+    return fma2(e, r, q);
+}
+__device__ __forceinline__ f32x2 sqrt_rn2(f32x2 x) {
+    const f32x2 y = {__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)};
+    f32x2 g = x * y, h = splat2(0.5f) * y;
+    const f32x2 e = fma2(-h, g, splat2(0.5f));
+    h = fma2(h, e, h);
+    g = fma2(g, e, g);
+    const f32x2 d = fma2(-g, g, x);
+    return fma2(d, h, g);
+}
+// map_pixel32 (FISH_TO_RECT = false) / map_pixel_ex<MAP_FISH_TO_RECT> (true) for two pixels of one column: a = column terms,
+// b = row terms of the two rows
+template <bool FISH_TO_RECT>
+__device__ __forceinline__ void map_pixel32_x2(float icx32, float icy32, float ifx32, float ify32, float r02, float r12, float r22,
+                                               float a0, float a1, float a2, f32x2 b0, f32x2 b1, f32x2 b2, f32x2 &ax, f32x2 &ay) {
+    const f32x2 wx = (splat2(a0) + b0) + splat2(r02);
+    const f32x2 wy = (splat2(a1) + b1) + splat2(r12);
+    const f32x2 wz = (splat2(a2) + b2) + splat2(r22);
+    const f32x2 rz = rcp_refined2(wz);
+    const f32x2 px = div_with_rcp2(wx, wz, rz), py = div_with_rcp2(wy, wz, rz);
+    const f32x2 q = px * px + py * py;
+    const f32x2 rad = sqrt_rn2(q);
+    const f32x2 rr = rcp_refined2(rad);
+    const i32x2 inv = rad > splat2(1.0f);
+    const f32x2 t = inv ? div_with_rcp2(splat2(1.0f), rad, rr) : rad;
+    const f32x2 s = t * t;
+    f32x2 g = splat2(0.0028423243202269077f);
+    g = fma2(g, s, splat2(-0.016053270548582077f));
+    g = fma2(g, s, splat2(0.04269874095916748f));
+    g = fma2(g, s, splat2(-0.07508683204650879f));
+    g = fma2(g, s, splat2(0.1064559817314148f));
+    g = fma2(g, s, splat2(-0.14205896854400635f));
+    g = fma2(g, s, splat2(0.19993145763874054f));
+    g = fma2(g, s, splat2(-0.33333125710487366f));
+    f32x2 at = fma2(t * s, g, t);
+    at = inv ? (splat2(1.57079637050628662109375f) - at) + splat2(-4.37113900018624283e-8f) : at;
+    f32x2 k = div_with_rcp2(at, rad, rr);
+    if constexpr (FISH_TO_RECT) k = (q == splat2(0.0f)) ? splat2(1.0f) : k;
+    ax = splat2(icx32) + (px * k) * splat2(ifx32);
+    ay = splat2(icy32) + (py * k) * splat2(ify32);
+    if constexpr (FISH_TO_RECT) {
+        const i32x2 ok = wz > splat2(0.0f);
+        ax = ok ? ax : splat2(__builtin_nanf("")), ay = ok ? ay : splat2(__builtin_nanf(""));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Generalised map (the libdewobble option surface in_p / out_p in {fish, rect},
 // render.ts:611-617,669-683,711-717).  libdewobble is not part of the reference tree, so the arithmetic
 // is defined by this project (the test suite holds a plain-C statement of it): mode

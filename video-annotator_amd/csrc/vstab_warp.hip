@@ -8,6 +8,7 @@
 
 #include "vstab_device.hpp"
 #include "vstab_internal.hpp"
+#include "vstab_warp_args.hpp"
 
 namespace vstab {
 
@@ -220,26 +221,6 @@ __global__ void __launch_bounds__(256) k_remap_bilinear(const uint8_t *__restric
 constexpr int WARP_ROWS_PER_THREAD = 4;
 constexpr int WARP_TILE_W = 64, WARP_TILE_H = 16 * WARP_ROWS_PER_THREAD;
 
-struct WarpArgs {
-    const uint8_t *y;
-    const uint8_t *uv;
-    uint8_t *dst;     // BGR8, or the luma plane in NV12 output mode
-    uint8_t *dst_uv;  // NV12 output mode: interleaved chroma plane, ceil(dh/2) rows of 2*ceil(dw/2) bytes
-    size_t pitch_y, pitch_uv, pitch_dst, pitch_dst_uv;
-    int sw, sh, dw, dh;
-    MapParams p;
-};
-
-__device__ __forceinline__ void fetch_tap(const WarpArgs &a, int X, int Y, int &b, int &g, int &r) {
-    if ((unsigned)X < (unsigned)a.sw && (unsigned)Y < (unsigned)a.sh) {
-        const int yv = a.y[(size_t)Y * a.pitch_y + X];
-        const uint16_t c = *reinterpret_cast<const uint16_t *>(a.uv + (size_t)(Y >> 1) * a.pitch_uv + (X & ~1));
-        yuv_to_bgr(yv, chroma_term(c & 255, c >> 8), b, g, r);
-    } else {
-        b = g = r = 0;
-    }
-}
-
 __device__ __forceinline__ uint32_t warp_pixel(const WarpArgs &a, const ColTerm &ct, const RowTerm &rt) {
     float mx, my;
     map_pixel(a.p, ct, rt, mx, my);
@@ -286,288 +267,9 @@ __global__ void __launch_bounds__(256) k_warp_nv12_bgr(WarpArgs a, int vec_ok) {
     }
 }
 
-// =============================================================================================
-// k_warp_tiled (v2) -- the fused hot kernel with an LDS-staged, pre-converted source tile.
-//
-// Per 64 x (16*RPT) output tile (256 threads, 4 columns x RPT rows per thread):
-//   phase 1  every thread evaluates the map for its pixels (hand-scheduled IEEE arithmetic,
-//            map_pixel32) and keeps the quantised coordinates sx, sy in registers; the bounding
-//            box of all taps of "inside" pixels is reduced wave-wide and merged through LDS.
-//   phase 2  the workgroup stages the bounding box of the NV12 source into LDS as BGRx dwords:
-//            coalesced dword loads of two luma rows + one chroma row per 4x2 block, the cvtColor
-//            arithmetic applied ONCE per source pixel (not once per tap), ds_write_b128.
-//   phase 3  four ds_read per pixel, exact fixed-point blend, 12-byte store per thread and row.
-// Pixels whose 2x2 footprint crosses the source border (per-tap zeroing, rare) and tiles whose
-// bounding box exceeds the LDS budget (degenerate rotations) take the direct-gather path, which
-// computes the same integers.  HBM traffic = the NV12 frame once + the BGR frame once.
-// =============================================================================================
-struct TiledArgs {
-    WarpArgs w;
-    MapParams32 p32;
-    int lds_capacity_px;  // dwords available for the staged tile
-    int src_vec_ok;       // planes and pitches 4-B aligned -> dword loads
-    int dst_vec_ok;
-    int debug_mode;       // 0 = product; >0 = timing-only ablations (VSTAB_DEBUG_MODE, outputs wrong)
-    int tiles_x, tiles_y;
-    const int2 *qmap;   // CACHED kernels: the quantised map (32 * map rounded to int, NaN -> INT_MIN in x) of every output pixel
-    int qpitch;         // its row pitch in pixels (a multiple of 4)
-};
-
-__device__ __forceinline__ uint32_t gather_pixel(const WarpArgs &a, int sx, int sy) {
-    const int X = sx >> 5, Y = sy >> 5;
-    const uint32_t fx = sx & 31, fy = sy & 31;
-    const int w00 = (32 - fx) * (32 - fy), w01 = fx * (32 - fy), w10 = (32 - fx) * fy, w11 = fx * fy;
-    int b0, g0, r0, b1, g1, r1, b2, g2, r2, b3, g3, r3;
-    fetch_tap(a, X, Y, b0, g0, r0);
-    fetch_tap(a, X + 1, Y, b1, g1, r1);
-    fetch_tap(a, X, Y + 1, b2, g2, r2);
-    fetch_tap(a, X + 1, Y + 1, b3, g3, r3);
-    const uint32_t B = (uint32_t)(b0 * w00 + b1 * w01 + b2 * w10 + b3 * w11 + 512) >> 10;
-    const uint32_t G = (uint32_t)(g0 * w00 + g1 * w01 + g2 * w10 + g3 * w11 + 512) >> 10;
-    const uint32_t R = (uint32_t)(r0 * w00 + r1 * w01 + r2 * w10 + r3 * w11 + 512) >> 10;
-    return B | (G << 8) | (R << 16);
-}
-
-__device__ __forceinline__ uint32_t load_u32_bytes(const uint8_t *p, int valid) {
-    uint32_t v = 0;
-    for (int i = 0; i < 4; i++)
-        if (i < valid) v |= (uint32_t)p[i] << (8 * i);
-    return v;
-}
-
-// CACHED: phase 1 loads the quantised map written by k_quantised_map instead of evaluating it -- for runs of frames
-// warped with the same parameters (tracking off: the undistort-only configuration, the CLI's stab=none re-projections),
-// where the reference recomputes an identical map every frame.  Same integers, so the same pixels.
-template <int RPT, int TY, int MODE = MAP_CREATEMAP_CL, int FMT = 0, bool CACHED = false>
-__global__ void __launch_bounds__(16 * TY) k_warp_tiled(TiledArgs ta) {
-    constexpr int NT = 16 * TY;  // threads per workgroup: 16 columns of 4 pixels x TY thread rows
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    int *bbox = reinterpret_cast<int *>(smem);  // minX, minY, maxX, maxY (16 B; keeps the tile 16-B aligned)
-    uint32_t *tile = smem + 4;
-    const WarpArgs &a = ta.w;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8),
-    // so give every XCD one contiguous band of tiles in raster order.  Horizontally adjacent tiles
-    // then share an L2: the 128-B lines their source rows and output rows straddle are fetched /
-    // written back once instead of once per XCD.  Placement only affects speed, never results.
-    const int ntiles = ta.tiles_x * ta.tiles_y;
-    const int per_xcd = (ntiles + 7) >> 3;
-    const int tile_id = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
-    if (tile_id >= ntiles) return;  // uniform for the workgroup (before any barrier)
-    const int tile_y = tile_id / ta.tiles_x, tile_x = tile_id - tile_y * ta.tiles_x;
-    const int x0 = tile_x * WARP_TILE_W + tx * 4;
-    const int ybase = tile_y * (TY * RPT) + ty;
-    if (tid == 0) bbox[0] = bbox[1] = INT_MAX, bbox[2] = bbox[3] = INT_MIN;
-    __syncthreads();
-
-    // ---------------- phase 1: map + quantise + classify -------------------------------------
-    int sx[RPT][4], sy[RPT][4];
-    uint32_t in_bits = 0, live_bits = 0;  // bit (j*4+i): all four taps inside the source / pixel exists in the output
-    int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
-    {
-        // column / row terms with ONE refined reciprocal per axis (createMap.cl:16-17 divisions)
-        const float rfx = rcp_refined(a.p.ofx), rfy = rcp_refined(a.p.ofy);
-        ColTerm ct[4];
-        float vxs[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float vx = div_with_rcp((float)(x0 + i) - a.p.ocx, a.p.ofx, rfx);
-            ct[i] = {a.p.r[0] * vx, a.p.r[3] * vx, a.p.r[6] * vx};
-            vxs[i] = vx;
-        }
-        const uint32_t sw1 = (uint32_t)(a.sw - 1), sh1 = (uint32_t)(a.sh - 1);
-#pragma unroll
-        for (int j = 0; j < RPT; j++) {
-            const int y = ybase + TY * j;
-            const float vy = div_with_rcp((float)y - a.p.ocy, a.p.ofy, rfy);
-            const RowTerm rt = {a.p.r[1] * vy, a.p.r[4] * vy, a.p.r[7] * vy};
-            int2 qv[4];
-            if constexpr (CACHED) {
-                // pixels past the right / bottom edge of the output have no map entry: clamp (they are never stored)
-                const uint4 *qp = reinterpret_cast<const uint4 *>(ta.qmap + (size_t)min(y, a.dh - 1) * ta.qpitch + min(x0, ta.qpitch - 4));
-                const uint4 q01 = qp[0], q23 = qp[1];  // x0 is a multiple of 4 and the pitch pads the row to one
-                qv[0] = make_int2((int)q01.x, (int)q01.y), qv[1] = make_int2((int)q01.z, (int)q01.w);
-                qv[2] = make_int2((int)q23.x, (int)q23.y), qv[3] = make_int2((int)q23.z, (int)q23.w);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if constexpr (CACHED) {
-                    const int qx = qv[i].x, qy = qv[i].y;
-                    const int X = qx >> 5, Y = qy >> 5;
-                    sx[j][i] = qx, sy[j][i] = qy;
-                    const bool inside = (uint32_t)X < sw1 && (uint32_t)Y < sh1;
-                    in_bits |= (inside ? 1u : 0u) << (j * 4 + i);
-                    int Xc, Yc;
-                    asm("v_med3_i32 %0, %1, -1, %2" : "=v"(Xc) : "v"(X), "s"(a.sw));
-                    asm("v_med3_i32 %0, %1, -1, %2" : "=v"(Yc) : "v"(Y), "s"(a.sh));
-                    mnx = min(mnx, Xc), mxx = max(mxx, Xc), mny = min(mny, Yc), mxy = max(mxy, Yc);
-                    continue;
-                }
-                float ax, ay;
-                map_pixel_ex<MODE>(ta.p32, a.p, ct[i], rt, vxs[i], vy, ax, ay);
-                // v_cvt_i32_f32 saturates (+-inf and out-of-range -> INT_MAX / INT_MIN, which land far
-                // outside any source <= 32767 wide after >> 5); only NaN (-> 0) needs an explicit test,
-                // and one ordered compare covers both coordinates.  Equivalent to cv::remap's cvRound
-                // -> INT_MIN -> "outside" (see quantise()).
-                // A NaN pixel gets sx = INT_MIN, i.e. a column far to the left of any source: every later test
-                // then classifies it as outside without looking at the flag again.
-                const bool ok = !__builtin_isunordered(ax, ay);
-                const int qx = ok ? (int)__builtin_rintf(ax) : INT_MIN, qy = (int)__builtin_rintf(ay);
-                const int X = qx >> 5, Y = qy >> 5;
-                sx[j][i] = qx, sy[j][i] = qy;
-                const bool inside = (uint32_t)X < sw1 && (uint32_t)Y < sh1;
-                in_bits |= (inside ? 1u : 0u) << (j * 4 + i);
-                // bounding box over ALL pixels with the coordinates clamped to one step outside the source: a
-                // superset of the inside pixels' box (pixels outside pull it to the nearest edge only), without
-                // a select per bound
-                int Xc, Yc;
-                asm("v_med3_i32 %0, %1, -1, %2" : "=v"(Xc) : "v"(X), "s"(a.sw));
-                asm("v_med3_i32 %0, %1, -1, %2" : "=v"(Yc) : "v"(Y), "s"(a.sh));
-                mnx = min(mnx, Xc), mxx = max(mxx, Xc), mny = min(mny, Yc), mxy = max(mxy, Yc);
-            }
-        }
-    }
-    {
-        // pixels of the tile that hang over the right / bottom edge of the output are neither sampled nor
-        // stored (they still took part in the bounding box, which only makes it slightly conservative)
-        uint32_t cols = 0, live = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) cols |= (x0 + i < a.dw ? 1u : 0u) << i;
-#pragma unroll
-        for (int j = 0; j < RPT; j++) live |= (ybase + TY * j < a.dh ? cols : 0u) << (4 * j);
-        in_bits &= live, live_bits = live;
-    }
-    // bounding box: DPP reduction inside each 16-lane row (4 steps), then one LDS atomic per row.
-    // (same-address LDS atomics from all 64 lanes serialise badly; shuffles cost 6 steps + bpermutes)
-#define VSTAB_ROW_STEP(n)                                                                       \
-    mnx = min(mnx, __builtin_amdgcn_update_dpp(INT_MAX, mnx, 0x110 + n, 0xf, 0xf, false));       \
-    mny = min(mny, __builtin_amdgcn_update_dpp(INT_MAX, mny, 0x110 + n, 0xf, 0xf, false));       \
-    mxx = max(mxx, __builtin_amdgcn_update_dpp(INT_MIN, mxx, 0x110 + n, 0xf, 0xf, false));       \
-    mxy = max(mxy, __builtin_amdgcn_update_dpp(INT_MIN, mxy, 0x110 + n, 0xf, 0xf, false));
-    VSTAB_ROW_STEP(1) VSTAB_ROW_STEP(2) VSTAB_ROW_STEP(4) VSTAB_ROW_STEP(8)
-#undef VSTAB_ROW_STEP
-    if (tx == 15) {  // lane 15 of each row holds the row's bounds
-        atomicMin(&bbox[0], mnx), atomicMin(&bbox[1], mny), atomicMax(&bbox[2], mxx), atomicMax(&bbox[3], mxy);
-    }
-    __syncthreads();
-
-    // ---------------- phase 2: stage the source bounding box as BGRx --------------------------
-    // back inside the range of top-left taps of inside pixels: [0, sw - 2] x [0, sh - 2]
-    const int bmnx = max(bbox[0], 0), bmny = max(bbox[1], 0), bmxx = min(bbox[2], a.sw - 2), bmxy = min(bbox[3], a.sh - 2);
-    const int bx0 = bmnx & ~3, by0 = bmny & ~1;
-    const int wb = (bmxx + 2 - bx0 + 3) & ~3, hb = (bmxy + 2 - by0 + 1) & ~1;  // taps reach max+1
-    const bool have = bmnx <= bmxx && bmny <= bmxy;
-    const bool use_lds = have && wb * hb <= ta.lds_capacity_px;
-    const int dbg = ta.debug_mode;
-    if (use_lds && dbg != 1 && dbg != 3) {
-        const int ux_n = wb >> 2, units = ux_n * (hb >> 1);
-        const uint32_t magic = (1u << 18) / (uint32_t)ux_n + 1u;  // u / ux_n == (u * magic) >> 18 for u < 2048
-        const uint32_t pitch_y = (uint32_t)a.pitch_y, pitch_uv = (uint32_t)a.pitch_uv;  // < 2^24 (host check)
-        // All loads of this thread's units are issued before the first conversion waits for one: the box holds at
-        // most lds_capacity_px / 8 units, i.e. STAGE_MAX trips per thread, so staging costs one exposed memory
-        // latency instead of one per trip (measured: phase 2 was 22 % of the kernel for 14 % of its instructions).
-        constexpr int STAGE_MAX = 5;  // 5 * NT * 8 >= 10236 pixels (40 KB of LDS); the launcher checks the budget
-        uint32_t y0w[STAGE_MAX], y1w[STAGE_MAX], uvw[STAGE_MAX];
-#pragma unroll
-        for (int it = 0; it < STAGE_MAX; it++) {
-            const int u = tid + it * NT;
-            y0w[it] = y1w[it] = uvw[it] = 0;
-            if (u < units) {
-                const uint32_t uy = ((uint32_t)u * magic) >> 18, ux = (uint32_t)u - __umul24(uy, (uint32_t)ux_n);
-                const uint32_t gx = (uint32_t)bx0 + 4u * ux, gy = (uint32_t)by0 + 2u * uy;
-                const uint32_t oy = __umul24(gy, pitch_y) + gx, ouv = __umul24(gy >> 1, pitch_uv) + gx;  // frame < 4 GiB
-                if (ta.src_vec_ok && (int)gx + 4 <= a.sw) {
-                    y0w[it] = *reinterpret_cast<const uint32_t *>(a.y + oy);
-                    y1w[it] = *reinterpret_cast<const uint32_t *>(a.y + oy + pitch_y);
-                    uvw[it] = *reinterpret_cast<const uint32_t *>(a.uv + ouv);
-                } else {
-                    const int valid = min(4, a.sw - (int)gx);
-                    y0w[it] = load_u32_bytes(a.y + oy, valid), y1w[it] = load_u32_bytes(a.y + oy + pitch_y, valid);
-                    uvw[it] = load_u32_bytes(a.uv + ouv, valid);
-                }
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < STAGE_MAX; it++) {
-            const int u = tid + it * NT;
-            if (u < units) {
-                const uint32_t uy = ((uint32_t)u * magic) >> 18, ux = (uint32_t)u - __umul24(uy, (uint32_t)ux_n);
-                const ChromaTerm c0 = chroma_term_folded(uvw[it] & 255, (uvw[it] >> 8) & 255);
-                const ChromaTerm c1 = chroma_term_folded((uvw[it] >> 16) & 255, uvw[it] >> 24);
-                uint4 r0, r1;
-                r0.x = pack_bgrx(y0w[it] & 255, c0), r0.y = pack_bgrx((y0w[it] >> 8) & 255, c0);
-                r0.z = pack_bgrx((y0w[it] >> 16) & 255, c1), r0.w = pack_bgrx(y0w[it] >> 24, c1);
-                r1.x = pack_bgrx(y1w[it] & 255, c0), r1.y = pack_bgrx((y1w[it] >> 8) & 255, c0);
-                r1.z = pack_bgrx((y1w[it] >> 16) & 255, c1), r1.w = pack_bgrx(y1w[it] >> 24, c1);
-                uint32_t *d = tile + __umul24(2u * uy, (uint32_t)wb) + 4u * ux;
-                *reinterpret_cast<uint4 *>(d) = r0;
-                *reinterpret_cast<uint4 *>(d + wb) = r1;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---------------- phase 3: sample, blend, store ---------------------------------------------
-    if (x0 >= a.dw) return;
-    const int lds_origin = by0 * wb + bx0;
-#pragma unroll
-    for (int j = 0; j < RPT; j++) {
-        const int y = ybase + TY * j;
-        if (y >= a.dh) break;
-        uint32_t px[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t bit = 1u << (j * 4 + i);
-            uint32_t v = 0;
-            if (dbg == 1 || dbg == 2) {
-                v = (uint32_t)(sx[j][i] ^ sy[j][i]) ^ tile[tid];
-            } else if ((in_bits & bit) && use_lds) {
-                const uint32_t *t = tile + (__mul24(sy[j][i] >> 5, wb) + (sx[j][i] >> 5) - lds_origin);
-                v = blend_bgrx(t[0], t[1], t[wb], t[wb + 1], sx[j][i] & 31, sy[j][i] & 31);
-            } else if (live_bits & bit) {
-                // rare: the 2x2 footprint crosses the source border (per-tap zeroing) or the tile's box did not fit
-                const int X = sx[j][i] >> 5, Y = sy[j][i] >> 5;
-                if (X < a.sw && X + 1 >= 0 && Y < a.sh && Y + 1 >= 0) v = gather_pixel(a, sx[j][i], sy[j][i]);
-            }
-            px[i] = v;
-        }
-        if constexpr (FMT == 0) {
-            uint8_t *o = a.dst + ((size_t)(uint32_t)y * a.pitch_dst + (uint32_t)x0 * 3u);
-            if (ta.dst_vec_ok && x0 + 4 <= a.dw) {
-                uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
-                o32[0] = px[0] | (px[1] << 24);
-                o32[1] = (px[1] >> 8) | (px[2] << 16);
-                o32[2] = (px[2] >> 16) | (px[3] << 8);
-            } else {
-                for (int i = 0; i < 4 && x0 + i < a.dw; i++) {
-                    o[3 * i] = px[i] & 255, o[3 * i + 1] = (px[i] >> 8) & 255, o[3 * i + 2] = (px[i] >> 16) & 255;
-                }
-            }
-        } else {
-            // NV12 output: luma for every pixel, chroma from the even-row / even-column pixels
-            const uint32_t yw = bgr_to_y(px[0]) | (bgr_to_y(px[1]) << 8) | (bgr_to_y(px[2]) << 16) | (bgr_to_y(px[3]) << 24);
-            uint8_t *o = a.dst + ((size_t)(uint32_t)y * a.pitch_dst + (uint32_t)x0);
-            if (ta.dst_vec_ok && x0 + 4 <= a.dw) {
-                *reinterpret_cast<uint32_t *>(o) = yw;
-            } else {
-                for (int i = 0; i < 4 && x0 + i < a.dw; i++) o[i] = (yw >> (8 * i)) & 255;
-            }
-            if (!(y & 1)) {
-                const uint32_t cw = bgr_to_uv(px[0]) | (bgr_to_uv(px[2]) << 16);
-                uint8_t *c = a.dst_uv + ((size_t)(uint32_t)(y >> 1) * a.pitch_dst_uv + (uint32_t)x0);
-                if (ta.dst_vec_ok && x0 + 2 < a.dw) {
-                    *reinterpret_cast<uint32_t *>(c) = cw;
-                } else {
-                    for (int i = 0; i < 4 && x0 + (i & ~1) < a.dw; i++) c[i] = (cw >> (8 * i)) & 255;
-                }
-            }
-        }
-    }
-}
-
 // k_quantised_map -- the map of every output pixel as cv::remap quantises it (32 * map rounded half to even; a NaN
 // entry gets x = INT_MIN), written once for a run of frames that share their warp parameters (see CACHED above).
-// Exactly the phase-1 arithmetic of k_warp_tiled.
+// The map arithmetic of k_warp_fused; its cvRound is the plain formulation (rint, NaN -> INT_MIN).
 template <int MODE>
 __global__ void __launch_bounds__(256) k_quantised_map(int2 *__restrict__ qmap, int qpitch, int dw, int dh, MapParams p, MapParams32 p32) {
     const int x0 = (blockIdx.x * 16 + (threadIdx.x & 15)) * 4, y = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -767,63 +469,20 @@ static vstab_status warp_impl(const void *y, size_t pitch_y, const void *uv, siz
     a.sw = sw, a.sh = sh, a.dw = dw, a.dh = dh;
     a.p = to_params(params);
     const int vec_ok = aligned(dst, 4) && pitch_dst % 4 == 0 && (!nv12_out || (aligned(dst_uv, 4) && pitch_dst_uv % 4 == 0));
-    static const int variant = getenv("VSTAB_WARP_VARIANT") ? atoi(getenv("VSTAB_WARP_VARIANT")) : 2;
     const bool small_pitch = pitch_y < (1u << 24) && pitch_uv < (1u << 24) && (uint64_t)pitch_y * sh < (1ull << 32);
     const bool plain = map_mode == VSTAB_MAP_CREATEMAP_CL && !nv12_out && !qmap;
     if (!plain && !small_pitch) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: source pitch too large for this mode");
-    if (plain && (variant == 1 || !small_pitch)) {  // v1 direct-gather kernel (kept as the in-kernel fallback's twin, for A/B runs)
+    bool direct = !small_pitch;
+#ifdef VSTAB_DEV
+    static const int variant = getenv("VSTAB_WARP_VARIANT") ? atoi(getenv("VSTAB_WARP_VARIANT")) : 2;
+    direct = direct || (plain && variant == 1);
+#endif
+    if (direct) {  // frames of 4 GiB and more: the direct-gather kernel with 64-bit addressing
         dim3 grid(div_up(dw, WARP_TILE_W), div_up(dh, WARP_TILE_H));
         hipLaunchKernelGGL(k_warp_nv12_bgr, grid, dim3(16, 16), 0, static_cast<hipStream_t>(stream), a, vec_ok);
     } else {
-        TiledArgs ta;
-        ta.w = a;
-        ta.p32 = {params[0] * 32.0f, params[1] * 32.0f, params[2] * 32.0f, params[3] * 32.0f, params[10], params[13], params[16]};
-        ta.src_vec_ok = aligned(y, 4) && aligned(uv, 4) && pitch_y % 4 == 0 && pitch_uv % 4 == 0;
-        ta.dst_vec_ok = vec_ok;
-        static const int dbg = getenv("VSTAB_DEBUG_MODE") ? atoi(getenv("VSTAB_DEBUG_MODE")) : 0;
-        ta.debug_mode = dbg;
-        static const int rpt_env = getenv("VSTAB_RPT") ? atoi(getenv("VSTAB_RPT")) : 0;
-        static const int tyr_env = getenv("VSTAB_TY") ? atoi(getenv("VSTAB_TY")) : 16;
-        static const int lds_env = getenv("VSTAB_LDS_KB") ? atoi(getenv("VSTAB_LDS_KB")) : 0;
-        // Tile shape: 64 x 32 output pixels and 40 KB of LDS (4 workgroups per CU) when that gives the 1024 workgroup
-        // slots of the chip a few rounds of tiles; 64 x 16 with 24 KB for small outputs (1080p: 896 tiles of 64 x 32
-        // would leave CUs idle; measured 16.6 us against 18.1).  The knobs exist for the reference mode only.
-        const long tiles32 = (long)div_up(dw, WARP_TILE_W) * div_up(dh, 32);
-        const int rpt = qmap ? (tiles32 < 1536 ? 1 : 2) : !plain ? 2 : rpt_env ? rpt_env : (tiles32 < 1536 ? 1 : 2), tyr = plain ? tyr_env : 16;
-        ta.qmap = static_cast<const int2 *>(qmap), ta.qpitch = qpitch;
-        const int lds_kb = lds_env ? lds_env : (rpt == 1 && tyr == 16 ? 24 : 40);
-        const size_t lds_bytes = (size_t)lds_kb * 1024;
-        // the staging loop keeps at most 5 trips x 8 pixels per thread in flight (STAGE_MAX in k_warp_tiled)
-        ta.lds_capacity_px = std::min((int)(lds_bytes / 4) - 4, 5 * 8 * 16 * tyr);
-        ta.tiles_x = (int)div_up(dw, WARP_TILE_W), ta.tiles_y = (int)div_up(dh, tyr * rpt);
-        dim3 grid(8 * div_up((unsigned)(ta.tiles_x * ta.tiles_y), 8));
-        hipStream_t st = static_cast<hipStream_t>(stream);
-#define VSTAB_LAUNCH(R, T, M, F) hipLaunchKernelGGL((k_warp_tiled<R, T, M, F>), grid, dim3(16 * T), lds_bytes, st, ta)
-        if (qmap) {  // phase 1 reads the quantised map: the map mode no longer matters
-            if (rpt == 1 && !nv12_out) hipLaunchKernelGGL((k_warp_tiled<1, 16, MAP_CREATEMAP_CL, 0, true>), grid, dim3(256), lds_bytes, st, ta);
-            else if (rpt == 1) hipLaunchKernelGGL((k_warp_tiled<1, 16, MAP_CREATEMAP_CL, 1, true>), grid, dim3(256), lds_bytes, st, ta);
-            else if (!nv12_out) hipLaunchKernelGGL((k_warp_tiled<2, 16, MAP_CREATEMAP_CL, 0, true>), grid, dim3(256), lds_bytes, st, ta);
-            else hipLaunchKernelGGL((k_warp_tiled<2, 16, MAP_CREATEMAP_CL, 1, true>), grid, dim3(256), lds_bytes, st, ta);
-        } else if (plain) {
-            if (tyr == 8 && rpt == 2) VSTAB_LAUNCH(2, 8, MAP_CREATEMAP_CL, 0);
-            else if (tyr == 8 && rpt == 4) VSTAB_LAUNCH(4, 8, MAP_CREATEMAP_CL, 0);
-            else if (tyr == 4 && rpt == 4) VSTAB_LAUNCH(4, 4, MAP_CREATEMAP_CL, 0);
-            else if (tyr == 16 && rpt == 1) VSTAB_LAUNCH(1, 16, MAP_CREATEMAP_CL, 0);
-            else VSTAB_LAUNCH(2, 16, MAP_CREATEMAP_CL, 0);
-        } else {
-            switch (map_mode * 2 + (nv12_out ? 1 : 0)) {
-                case 1: VSTAB_LAUNCH(2, 16, MAP_CREATEMAP_CL, 1); break;
-                case 2: VSTAB_LAUNCH(2, 16, MAP_FISH_TO_RECT, 0); break;
-                case 3: VSTAB_LAUNCH(2, 16, MAP_FISH_TO_RECT, 1); break;
-                case 4: VSTAB_LAUNCH(2, 16, MAP_FISH_TO_FISH, 0); break;
-                case 5: VSTAB_LAUNCH(2, 16, MAP_FISH_TO_FISH, 1); break;
-                case 6: VSTAB_LAUNCH(2, 16, MAP_RECT_TO_RECT, 0); break;
-                case 7: VSTAB_LAUNCH(2, 16, MAP_RECT_TO_RECT, 1); break;
-                case 8: VSTAB_LAUNCH(2, 16, MAP_RECT_TO_FISH, 0); break;
-                default: VSTAB_LAUNCH(2, 16, MAP_RECT_TO_FISH, 1); break;
-            }
-        }
-#undef VSTAB_LAUNCH
+        const bool src_vec_ok = aligned(y, 8) && aligned(uv, 8) && pitch_y % 8 == 0 && pitch_uv % 8 == 0;  // 8-byte staging loads
+        return launch_warp_fused(a, params, map_mode, nv12_out, src_vec_ok, vec_ok, qmap, qpitch, static_cast<hipStream_t>(stream));
     }
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
