@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvstab.so")
+LIB_PATH = os.environ.get("VSTAB_LIB_PATH") or os.path.join(_HERE, "lib", "libvstab.so")  # override: A/B runs of two builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -92,12 +92,42 @@ __device__ __forceinline__ void probe_tile(const FusedArgs &ta, int tile_x, int 
         const int2 q = ta.qmap[(size_t)(y0 + py) * ta.qpitch + (x0 + px)];
         qx = q.x, qy = q.y;
     } else {
-        const float vx = div_with_rcp((float)(x0 + px) - a.p.ocx, a.p.ofx, rfx);
-        const float vy = div_with_rcp((float)(y0 + py) - a.p.ocy, a.p.ofy, rfy);
-        const ColTerm ct = {a.p.r[0] * vx, a.p.r[3] * vx, a.p.r[6] * vx};
-        const RowTerm rt = {a.p.r[1] * vy, a.p.r[4] * vy, a.p.r[7] * vy};
         float ax, ay;
-        map_pixel_ex<MODE>(ta.p32, a.p, ct, rt, vx, vy, ax, ay);
+        if constexpr (MODE == MAP_CREATEMAP_CL || MODE == MAP_FISH_TO_RECT) {
+            // The box needs the map to a fraction of a pixel only (it has a pixel of margin and never decides a result),
+            // so the probe uses the approximate reciprocal / rsqrt instructions and fused operations: a third of the
+            // dependent chain of the exact evaluation, on the one wave the other three are waiting for.
+            const float vx = ((float)(x0 + px) - a.p.ocx) * rfx, vy = ((float)(y0 + py) - a.p.ocy) * rfy;
+            const float wx = __builtin_fmaf(a.p.r[0], vx, __builtin_fmaf(a.p.r[1], vy, a.p.r[2]));
+            const float wy = __builtin_fmaf(a.p.r[3], vx, __builtin_fmaf(a.p.r[4], vy, a.p.r[5]));
+            const float wz = __builtin_fmaf(a.p.r[6], vx, __builtin_fmaf(a.p.r[7], vy, a.p.r[8]));
+            const float rz = __builtin_amdgcn_rcpf(wz), ux = wx * rz, uy = wy * rz;
+            const float q = __builtin_fmaf(ux, ux, uy * uy), rs = __builtin_amdgcn_rsqf(q), rad = q * rs;
+            const bool inv = rad > 1.0f;
+            const float t = inv ? rs : rad, s2 = t * t;
+            float g = 0.0028423243202269077f;
+            g = __builtin_fmaf(g, s2, -0.016053270548582077f);
+            g = __builtin_fmaf(g, s2, 0.04269874095916748f);
+            g = __builtin_fmaf(g, s2, -0.07508683204650879f);
+            g = __builtin_fmaf(g, s2, 0.1064559817314148f);
+            g = __builtin_fmaf(g, s2, -0.14205896854400635f);
+            g = __builtin_fmaf(g, s2, 0.19993145763874054f);
+            g = __builtin_fmaf(g, s2, -0.33333125710487366f);
+            float at = __builtin_fmaf(t * s2, g, t);
+            at = inv ? 1.57079637050628662109375f - at : at;
+            const float k = at * rs;  // atan(rad) / rad; NaN on the axis (q == 0) only widens the box
+            ax = __builtin_fmaf(ux * k, ta.p32.ifx32, ta.p32.icx32), ay = __builtin_fmaf(uy * k, ta.p32.ify32, ta.p32.icy32);
+            if (MODE == MAP_FISH_TO_RECT && !(wz > 0.0f)) ax = ay = __builtin_nanf("");
+        } else {
+            const float vx = div_with_rcp((float)(x0 + px) - a.p.ocx, a.p.ofx, rfx);
+            const float vy = div_with_rcp((float)(y0 + py) - a.p.ocy, a.p.ofy, rfy);
+            const ColTerm ct = {a.p.r[0] * vx, a.p.r[3] * vx, a.p.r[6] * vx};
+            const RowTerm rt = {a.p.r[1] * vy, a.p.r[4] * vy, a.p.r[7] * vy};
+            map_pixel_ex<MODE>(ta.p32, a.p, ct, rt, vx, vy, ax, ay);
+        }
+#ifdef VSTAB_DEV
+        if (ta.ablate & 1) ax = (float)(x0 + px) * (32.0f * (float)a.sw / (float)a.dw), ay = (float)(y0 + py) * (32.0f * (float)a.sh / (float)a.dh);
+#endif
         qx = __float_as_int(ax + QMAGIC) - QMAGIC_BITS, qy = __float_as_int(ay + QMAGIC) - QMAGIC_BITS;
     }
     // clamp to one step outside the source: pixels that map outside pull the box to the nearest edge only
@@ -155,7 +185,11 @@ __global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
         tile_x = idx - (tile_y - base) * ta.tiles_x;
     }
     // ---- probe (wave 0 only; the other waves wait at the barrier without taking issue slots) --------------------
-    if (wave == 0) probe_tile<R, MODE, CACHED>(ta, tile_x, tile_y, lane, rfx, rfy, smem);
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);  // three waves wait for this one
+        probe_tile<R, MODE, CACHED>(ta, tile_x, tile_y, lane, rfx, rfy, smem);
+        __builtin_amdgcn_s_setprio(0);
+    }
     __syncthreads();
     const int bx0 = __builtin_amdgcn_readfirstlane((int)smem[0]), by0 = __builtin_amdgcn_readfirstlane((int)smem[1]);
     const int wb = __builtin_amdgcn_readfirstlane((int)smem[2]), hb = __builtin_amdgcn_readfirstlane((int)smem[3]);
@@ -359,7 +393,7 @@ __global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * p0, (int)out[j]);
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * p0 + 4, (int)out[j]);
                 const uint32_t d = __builtin_amdgcn_perm(hi, lo, sel);
-                if (lane < nfull) *reinterpret_cast<uint32_t *>(o + (uint32_t)(4 * lane)) = d;
+                if (lane < nfull) __builtin_nontemporal_store(d, reinterpret_cast<uint32_t *>(o + (uint32_t)(4 * lane)));
                 else if (lane == nfull && rem) {
                     for (int i = 0; i < rem; i++) o[4 * lane + i] = (d >> (8 * i)) & 255;
                 }
