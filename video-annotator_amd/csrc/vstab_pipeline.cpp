@@ -60,7 +60,7 @@ struct PinnedBuf {  // host memory the device can read and write directly (mappe
         if (bytes <= n) return VSTAB_OK;
         if (p) (void)hipHostFree(p);
         p = nullptr, n = 0;
-        if (hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return fail(VSTAB_ERR_NOMEM, "hipHostMalloc failed");
+        if (hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) return fail(VSTAB_ERR_NOMEM, "hipHostMalloc failed");
         n = bytes;
         return VSTAB_OK;
     }
@@ -78,6 +78,7 @@ constexpr int PREFETCH_DEPTH = 8;
 
 class Tracker {
   public:
+    static constexpr int REC_BUFS = 3;  // record / point buffers in rotation: in flight, chained behind it, being read by the host
     vstab_status init(int w, int h) {
         w_ = w, h_ = h, levels_ = lk_levels(w, h);
         int lw = w, lh = h;
@@ -89,6 +90,13 @@ class Tracker {
         lvl_w_[0] = w, lvl_h_[0] = h;
         VSTAB_TRY(small_.ensure(256));
         VSTAB_TRY(hsmall_.ensure(256));
+        // record and point buffers for the pipeline's 200 features (FrameSourceWarp.cpp:230), so that nothing is
+        // reallocated while a launch that uses them is queued
+        for (int b = 0; b < REC_BUFS; b++) {
+            VSTAB_TRY(hrec_[b].ensure(256 * 16));
+            VSTAB_TRY(drec_[b].ensure(256 * 16));
+            VSTAB_TRY(hpts_[b].ensure(256 * sizeof(float2)));
+        }
         return VSTAB_OK;
     }
 
@@ -275,6 +283,8 @@ class Tracker {
         spec_state_.store(0, std::memory_order_release), spec_tag_ = -1;
     }
     ~Tracker() {
+        for (hipEvent_t e : {spec_ev_, ev_a_, ev_b_})
+            if (e) (void)hipEventDestroy(e);
         if (spec_thread_started_) {
             {
                 std::lock_guard<std::mutex> lk(spec_m_);
@@ -315,7 +325,6 @@ class Tracker {
         uint32_t seq = 0;
         bool chained = false, timed = false;
     };
-    static constexpr int REC_BUFS = 3;
 
     vstab_status track_launch(const LkPyramid &I, const LkPyramid &J, const std::vector<float> &prev_xy, hipStream_t st,
                               bool timed, Launch &L) {
@@ -326,12 +335,12 @@ class Tracker {
         L.buf = (int)(launches_++ % REC_BUFS), L.seq = ++seq_;
         VSTAB_TRY(hrec_[L.buf].ensure((size_t)n * 16));
         VSTAB_TRY(drec_[L.buf].ensure((size_t)n * 16));
-        VSTAB_TRY(hpts_.ensure((size_t)n * sizeof(float2)));
-        if (!hrec_[L.buf].dev() || !hpts_.dev()) return fail(VSTAB_ERR_DEVICE, "hipHostGetDevicePointer failed");
-        std::memcpy(hpts_.p, prev_xy.data(), sizeof(float) * prev_xy.size());
+        VSTAB_TRY(hpts_[L.buf].ensure((size_t)n * sizeof(float2)));  // one per record buffer: a launch still queued keeps its points
+        if (!hrec_[L.buf].dev() || !hpts_[L.buf].dev()) return fail(VSTAB_ERR_DEVICE, "hipHostGetDevicePointer failed");
+        std::memcpy(hpts_[L.buf].p, prev_xy.data(), sizeof(float) * prev_xy.size());
         if (timed && !ev_a_) (void)hipEventCreate(&ev_a_), (void)hipEventCreate(&ev_b_);
         if (timed) (void)hipEventRecord(ev_a_, st);
-        VSTAB_TRY(launch_lk(I, J, static_cast<const float2 *>(hpts_.dev()), n, nullptr, nullptr, hrec_[L.buf].dev(), L.seq, st, nullptr,
+        VSTAB_TRY(launch_lk(I, J, static_cast<const float2 *>(hpts_[L.buf].dev()), n, nullptr, nullptr, hrec_[L.buf].dev(), L.seq, st, nullptr,
                             drec_[L.buf].p, clock_slot()));
         if (timed) (void)hipEventRecord(ev_b_, st);
         return VSTAB_OK;
@@ -360,15 +369,20 @@ class Tracker {
         const volatile uint32_t *rec = hrec_[L.buf].as<uint32_t>();
         const auto t0 = std::chrono::steady_clock::now();
         unsigned long spins = 0;
+        // a record = two 8-byte granules {x, seq} {y, seq << 2 | status}, each valid once its own tag matches (make_record)
+        const uint32_t tag1 = L.seq << 2;
+        auto ready = [&](int i) {
+            return __atomic_load_n(&rec[4 * i + 1], __ATOMIC_ACQUIRE) == L.seq && (__atomic_load_n(&rec[4 * i + 3], __ATOMIC_ACQUIRE) & ~3u) == tag1;
+        };
         for (int i = 0; i < n; i++) {
-            while (__atomic_load_n(&rec[4 * i + 3], __ATOMIC_ACQUIRE) != L.seq) {
+            while (!ready(i)) {
                 __builtin_ia32_pause();
                 if ((++spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
                     VSTAB_HIP_TRY(hipStreamSynchronize(st));  // surfaces a launch / execution error if there is one
-                    if (__atomic_load_n(&rec[4 * i + 3], __ATOMIC_ACQUIRE) != L.seq) return fail(VSTAB_ERR_DEVICE, "LK kernel did not complete");
+                    if (!ready(i)) return fail(VSTAB_ERR_DEVICE, "LK kernel did not complete");
                 }
             }
-            const uint32_t x = rec[4 * i], y = rec[4 * i + 1], s = rec[4 * i + 2];
+            const uint32_t x = rec[4 * i], y = rec[4 * i + 2], s = rec[4 * i + 3] & 3u;
             if (s == 2u) continue;  // lost in an earlier frame of the chain: not part of this frame's point list
             float fx, fy;
             std::memcpy(&fx, &x, 4), std::memcpy(&fy, &y, 4);
@@ -448,7 +462,7 @@ class Tracker {
     static constexpr int CLK_N = 4096;
     DevBuf clk_;
     int clk_used_ = 0;
-    PinnedBuf hsmall_, hkeys_, hpts_, hrec_[REC_BUFS];
+    PinnedBuf hsmall_, hkeys_, hpts_[REC_BUFS], hrec_[REC_BUFS];
     DevBuf drec_[REC_BUFS];
     unsigned int cap_ = 0;
     hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
@@ -485,7 +499,10 @@ class EstimateWorker {
         cv_.notify_one();
     }
     int join(Mat3 &R) {  // blocks until the posted job is done
-        while (state_.load(std::memory_order_acquire) != DONE) __builtin_ia32_pause();
+        for (long spins = 0; state_.load(std::memory_order_acquire) != DONE; spins++) {
+            if (spins < 200000) __builtin_ia32_pause();
+            else std::this_thread::yield();
+        }
         state_.store(IDLE, std::memory_order_relaxed);
         R = R_;
         return inliers_;
@@ -507,7 +524,8 @@ class EstimateWorker {
             }
             if (st == QUIT) return;
             inliers_ = estimate_rotation(prev_, cur_, n_, *Kin_, *Kout_, *rng_, R_, in_fish_);
-            state_.store(DONE, std::memory_order_release);
+            int posted = POSTED;  // a destructor that stored QUIT meanwhile must not be answered with DONE
+            if (!state_.compare_exchange_strong(posted, DONE, std::memory_order_acq_rel)) return;
         }
     }
     std::thread th_;
@@ -531,6 +549,19 @@ using namespace vstab;
 // the pipeline handle
 // ---------------------------------------------------------------------------------------------
 struct vstab_handle {
+    // every way out of vstab_create after the streams and events exist, and vstab_destroy, ends here
+    ~vstab_handle() {
+        for (hipStream_t s : {tstream, pstream, dstream})
+            if (s) (void)hipStreamSynchronize(s);
+        for (auto &pe : pending) (void)hipEventDestroy(pe.a), (void)hipEventDestroy(pe.b);
+        for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
+        for (auto &s : slots)
+            if (s.ingested) (void)hipEventDestroy(s.ingested);
+        for (hipEvent_t e : warp_events)
+            if (e) (void)hipEventDestroy(e);
+        for (hipStream_t s : {dstream, pstream, tstream})
+            if (s) (void)hipStreamDestroy(s);
+    }
     vstab_config cfg;
     vstab_source src;
     hipStream_t stream = nullptr;   // caller-visible stream: the warp runs here, dst is complete when it drains
@@ -1324,16 +1355,7 @@ void vstab_destroy(vstab_handle *h) {
         (void)h->worker.join(r);
     }
     h->fold_pending();  // drains the streams
-    for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
-    for (auto &s : h->slots) {
-        if (s.ingested) (void)hipEventDestroy(s.ingested);
-    }
-    for (auto e : h->warp_events)
-        if (e) (void)hipEventDestroy(e);
-    if (h->dstream) (void)hipStreamDestroy(h->dstream);
-    if (h->pstream) (void)hipStreamDestroy(h->pstream);
-    if (h->tstream) (void)hipStreamDestroy(h->tstream);
-    delete h;
+    delete h;           // ~vstab_handle releases the events and the internal streams
 }
 
 int vstab_frame_log_count(const vstab_handle *h) { return h ? (int)(h->log_base + (long)h->log.size()) : 0; }

@@ -278,6 +278,19 @@ struct LkStage {
     }
 };
 
+// A result record for the polling host thread (Tracker::track_wait) and for the chained launch of the next frame: two
+// naturally aligned 8-byte granules {x, seq} and {y, seq << 2 | status}, each validated by its own tag, written by one
+// 16-byte store to fine-grained host memory.  Nothing in HIP or PCIe promises that a 16-byte store arrives as one
+// indivisible write, so the reader checks the tag of each half: a torn record cannot pair a new tag with stale data
+// (aligned 8-byte granules written by one store are the hand-off unit of /opt/skills/guides/MI355X_MICROARCH.md,
+// "handoff-1to1").  No fence and no wait: a system-scope release would write back the XCD's whole L2 200 times per
+// frame under the warp kernel that merges partial output lines there (warp beside the tracker 72 us against 52), and
+// four ordered stores with a wait for their acknowledgement cost the tracker chain a third of the pipeline's rate.
+__device__ __forceinline__ uint4 make_record(float x, float y, unsigned int status, unsigned int seq) {
+    return make_uint4(__float_as_uint(x), seq, __float_as_uint(y), (seq << 2) | status);
+}
+__device__ __forceinline__ unsigned int record_status(const uint4 &r) { return r.w & 3u; }
+
 __global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid J, const float2 *__restrict__ prev_pts,
                                                          int n, float2 *__restrict__ next_pts, uint8_t *__restrict__ status,
                                                          uint4 *__restrict__ host_rec, unsigned int seq,
@@ -297,15 +310,15 @@ __global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid 
         // tracked to, if it survived (status 1).  Slots that were lost earlier stay lost (status 2) and are
         // skipped by the host, which is exactly the status filter of FrameSourceWarp.cpp:261-268.
         const uint4 r = chain_in[f];
-        if (r.z != 1u) {  // uniform for the workgroup, before any barrier
+        if (record_status(r) != 1u) {  // uniform for the workgroup, before any barrier
             if (tid == 0) {
-                const uint4 dead = make_uint4(0u, 0u, 2u, seq);
+                const uint4 dead = make_record(0.0f, 0.0f, 2u, seq);
                 if (dev_rec) dev_rec[f] = dead;
                 if (host_rec) host_rec[f] = dead;
             }
             return;
         }
-        pp = make_float2(__uint_as_float(r.x), __uint_as_float(r.y));
+        pp = make_float2(__uint_as_float(r.x), __uint_as_float(r.z));
     } else {
         pp = prev_pts[f];
     }
@@ -486,10 +499,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid 
     }
     if (tid == 0) {
         if (host_rec) {
-            // one self-validating 16-byte record per feature in coherent (uncached) host memory: data and
-            // sequence tag leave in a single store, so no fence or counter is needed and the host simply
-            // polls the tags.  The device copy feeds a chained launch for the next frame.
-            const uint4 rec = make_uint4(__float_as_uint(np.x), __float_as_uint(np.y), (unsigned int)st, seq);
+            // one 16-byte record per feature in coherent host memory (make_record); the host polls the tags.  The device
+            // copy feeds a chained launch for the next frame.
+            const uint4 rec = make_record(np.x, np.y, (unsigned int)st, seq);
             if (dev_rec) dev_rec[f] = rec;
             host_rec[f] = rec;
             if (clk) atomicMax(&clk[1], wall_clock64());
