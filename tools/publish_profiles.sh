@@ -3,7 +3,7 @@
 # copies the judged summaries of gpurun_out/prof_<tag>/ (written by tools/prof_bench.sh) into profiles/
 set -e
 TAG=${1:?tag}
-PFX=${2:-r01}
+PFX=${2:-r02}
 SRC=gpurun_out/prof_$TAG
 cp $SRC/summary.txt profiles/${PFX}_bench_pipeline_rocprof_summary.txt
 cp $SRC/traffic.json profiles/traffic_4k.json
@@ -13,9 +13,9 @@ python3 - "$PFX" <<'PY'
 import csv, json, sys
 pfx = sys.argv[1]
 rows = list(csv.DictReader(open(f"profiles/{pfx}_bench_pipeline_kernel_stats.csv")))
-w = [r for r in rows if "k_warp_tiled" in r["Name"]][0]
+w = [r for r in rows if "k_warp_fused" in r["Name"]][0]
 t = json.load(open("profiles/traffic_4k.json"))
 t["rocprof_avg_launch_us"] = round(float(w["AverageNs"]) / 1e3, 2)
 json.dump(t, open("profiles/traffic_4k.json", "w"), indent=1)
-print("k_warp_tiled rocprof avg us:", t["rocprof_avg_launch_us"])
+print("k_warp_fused rocprof avg us:", t["rocprof_avg_launch_us"])
 PY

@@ -339,6 +339,11 @@ vstab_status vstab_pack_nv12(const void *y, size_t pitch_y, const void *uv, size
         dim3 grid(std::min<unsigned>(div_up((unsigned)((long)vecs * rows), 256), 1024));
         hipLaunchKernelGGL(k_pack_nv12<uint4>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y,
                            (const uint8_t *)uv, pitch_uv, vecs, height, (uint8_t *)dst, (size_t)width);
+    } else if (aligned(y, 8) && aligned(uv, 8) && aligned(dst, 8) && pitch_y % 8 == 0 && pitch_uv % 8 == 0 && width % 8 == 0) {
+        const int vecs = width / 8;
+        dim3 grid(std::min<unsigned>(div_up((unsigned)((long)vecs * rows), 256), 1024));
+        hipLaunchKernelGGL(k_pack_nv12<uint2>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y,
+                           (const uint8_t *)uv, pitch_uv, vecs, height, (uint8_t *)dst, (size_t)width);
     } else if (aligned(y, 4) && aligned(uv, 4) && aligned(dst, 4) && pitch_y % 4 == 0 && pitch_uv % 4 == 0 && width % 4 == 0) {
         const int vecs = width / 4;
         dim3 grid(std::min<unsigned>(div_up((unsigned)((long)vecs * rows), 256), 1024));
