@@ -3,6 +3,7 @@
 File:line citations are into /root/reference/opencv/.
 """
 import math
+import sys
 
 import numpy as np
 
@@ -249,6 +250,165 @@ class KalmanRotationFilter:
             self.x[a], self.P[a] = x, P
             out[a] = x[0, 0]
         return rodrigues(out)
+
+
+# ---------------------------------------------------------------------------------------------
+# guess_camera_rotation, FrameSourceWarp.cpp:316-375, restated independently of the product (numpy, fp64).
+#
+# What the reference does: undistort the current points into output-camera pixels (:322-330) and the
+# previous points into normalised coordinates (:333-338), give every previous point a random depth
+# s = rand() / RAND_MAX -> object point (x s, y s, s) (:345-350), solvePnPRansac(100 iterations, 8 px, 0.99)
+# (:354-366), Rodrigues of the result (:373); a solver exception becomes (identity, 0 inliers) (:367-371).
+#
+# What is restated here rather than taken from OpenCV 4.5 (not in the image):
+#   * rand() is un-seeded libc; this project seeds PCG32 (O'Neill) instead -- one stream per clip, one
+#     uniform draw per point, then the RANSAC draws.
+#   * cv::solvePnPRansac = RANSACPointSetRegistrator (calib3d/ptsetreg.cpp): subsets of 5 distinct points,
+#     model from the minimal solver, inliers by squared reprojection error (float) <= threshold^2, best
+#     model = most inliers (> max(best, 4)), iteration bound updated by RANSACUpdateNumIters; then a refit
+#     on the inliers (SOLVEPNP_ITERATIVE: Levenberg-Marquardt on the reprojection error).
+#   * DEVIATION: OpenCV's minimal solver for 5 points is EPnP; here (and in the product) the minimal solver
+#     is the same Levenberg-Marquardt iteration started from the identity pose (10 steps), which is what
+#     the data supports (inter-frame rotations of a few degrees).  tests/test_motion_cpu.py measures how far
+#     that carries (inter-frame rotations up to 8 degrees, 50 % outliers).
+# ---------------------------------------------------------------------------------------------
+class Pcg32:
+    """PCG32 XSH-RR (pcg-random.org minimal C implementation), seed/sequence initialisation included."""
+    M64 = (1 << 64) - 1
+
+    def __init__(self, seed=42, seq=54):
+        self.state, self.inc = 0, ((seq << 1) | 1) & self.M64
+        self.next()
+        self.state = (self.state + seed) & self.M64
+        self.next()
+
+    def next(self):
+        old = self.state
+        self.state = (old * 6364136223846793005 + self.inc) & self.M64
+        xorshifted = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+        rot = old >> 59
+        return ((xorshifted >> rot) | (xorshifted << ((-rot) & 31))) & 0xFFFFFFFF
+
+    def uniform(self):  # [0, 1], like rand() * 1. / RAND_MAX
+        return self.next() * (1.0 / 4294967295.0)
+
+    def below(self, n):
+        return (self.next() * n) >> 32
+
+
+def _pnp_project(R, t, X, f, cx, cy):
+    Y = X @ R.T + t
+    return np.stack([f * Y[:, 0] / Y[:, 2] + cx, f * Y[:, 1] / Y[:, 2] + cy], axis=1)
+
+
+def _pnp_cost(R, t, X, u, f, cx, cy):
+    with np.errstate(all="ignore"):
+        e = _pnp_project(R, t, X, f, cx, cy) - u
+        return float(np.sum(e * e))
+
+
+def _solve_pnp_lm(X, u, f, cx, cy, R, t, max_iter):
+    """Levenberg-Marquardt on the reprojection error over a left rotation increment w and a translation
+    increment: u = f Yx / Yz + cx, v = f Yy / Yz + cy, Y = R X + t, dY/dw = -[R X]x, dY/dt = I.
+    Damping: (J^T J + lambda diag(J^T J)) d = -J^T r, lambda x 0.1 on success, x 10 on failure (at most 8
+    tries per step); stops when a step gains less than 1e-9 of the cost."""
+    lam = 1e-3
+    cost = _pnp_cost(R, t, X, u, f, cx, cy)
+    if not math.isfinite(cost):
+        return None
+    for _ in range(max_iter):
+        RX = X @ R.T
+        Y = RX + t
+        iz = 1.0 / Y[:, 2]
+        fz, xz, yz = f * iz, Y[:, 0] * iz, Y[:, 1] * iz
+        eu, ev = fz * Y[:, 0] + cx - u[:, 0], fz * Y[:, 1] + cy - u[:, 1]
+        x, y, z = RX[:, 0], RX[:, 1], RX[:, 2]
+        zero = np.zeros_like(x)
+        Ju = np.stack([-fz * xz * y, fz * (z + xz * x), -fz * y, fz, zero, -fz * xz], axis=1)
+        Jv = np.stack([-fz * (z + yz * y), fz * yz * x, fz * x, zero, fz, -fz * yz], axis=1)
+        H = Ju.T @ Ju + Jv.T @ Jv
+        g = Ju.T @ eu + Jv.T @ ev
+        improved = False
+        for _try in range(8):
+            A = H + lam * np.diag(np.diag(H) + 1e-12)
+            try:
+                d = np.linalg.solve(A, -g)
+            except np.linalg.LinAlgError:
+                lam *= 10
+                continue
+            Rc, tc = rodrigues(d[:3]) @ R, t + d[3:]
+            c2 = _pnp_cost(Rc, tc, X, u, f, cx, cy)
+            if math.isfinite(c2) and c2 < cost:
+                rel = (cost - c2) / max(cost, 1e-300)
+                R, t, cost, lam, improved = Rc, tc, c2, max(lam * 0.1, 1e-12), True
+                if rel < 1e-9 or cost < 1e-20:
+                    return R, t
+                break
+            lam *= 10
+        if not improved:
+            break
+    return R, t
+
+
+def _ransac_update_iters(p, ep, model_points, max_iters):
+    """cv::RANSACUpdateNumIters (calib3d/ptsetreg.cpp)."""
+    p, ep = min(max(p, 0.0), 1.0), min(max(ep, 0.0), 1.0)
+    num, denom = max(1.0 - p, sys.float_info.min), 1.0 - (1.0 - ep) ** model_points
+    if denom < sys.float_info.min:
+        return 0
+    num, denom = math.log(num), math.log(denom)
+    return max_iters if denom >= 0 or -num >= max_iters * (-denom) else int(np.rint(num / denom))
+
+
+def estimate_rotation(prev_pts, cur_pts, K_in, K_out, rng, in_fish=True):
+    """-> (R, number of RANSAC inliers).  prev_pts / cur_pts: (n, 2) float32 input-image pixels;
+    rng: Pcg32 (the clip's stream; it is advanced)."""
+    prev_pts = np.asarray(prev_pts, np.float32).reshape(-1, 2)
+    cur_pts = np.asarray(cur_pts, np.float32).reshape(-1, 2)
+    n = len(prev_pts)
+    if n < 5:
+        return np.eye(3), 0
+    if in_fish:
+        und_cur = fisheye_undistort_points(cur_pts, K_in, None, K_out)
+        und_prev = fisheye_undistort_points(prev_pts, K_in)
+    else:  # pinhole input lens (the libdewobble in_p=rect surface): no tan(theta) / theta factor
+        nc = (cur_pts.astype(np.float64) - [K_in[0, 2], K_in[1, 2]]) / [K_in[0, 0], K_in[1, 1]]
+        npv = (prev_pts.astype(np.float64) - [K_in[0, 2], K_in[1, 2]]) / [K_in[0, 0], K_in[1, 1]]
+        und_cur = np.stack([K_out[0, 0] * nc[:, 0] + K_out[0, 2], K_out[1, 1] * nc[:, 1] + K_out[1, 2]], axis=1)
+        und_prev = npv
+    img = und_cur.astype(np.float32).astype(np.float64)          # Point2f
+    pn = und_prev.astype(np.float32).astype(np.float64)          # Point2f
+    s = np.array([rng.uniform() for _ in range(n)])              # :345
+    obj = np.stack([pn[:, 0] * s, pn[:, 1] * s, s], axis=1)      # :346-350
+    f, cx, cy = float(K_out[0, 0]), float(K_out[0, 2]), float(K_out[1, 2])
+    model_points, thresh2, confidence = 5, np.float32(64.0), 0.99
+    niters, best_count, best, best_mask = 100, 0, None, None
+    it = 0
+    while it < niters:
+        it += 1
+        idx = []
+        while len(idx) < model_points:
+            c = rng.below(n)
+            if c not in idx:
+                idx.append(c)
+        m = _solve_pnp_lm(obj[idx], img[idx], f, cx, cy, np.eye(3), np.zeros(3), 10)
+        if m is None:
+            continue
+        with np.errstate(all="ignore"):
+            e = _pnp_project(m[0], m[1], obj, f, cx, cy) - img
+            err = (e[:, 0] * e[:, 0] + e[:, 1] * e[:, 1]).astype(np.float32)
+            mask = err <= thresh2                                 # NaN compares false
+        good = int(mask.sum())
+        if good > max(best_count, model_points - 1):
+            best_count, best, best_mask = good, m, mask
+            niters = _ransac_update_iters(confidence, (n - good) / n, model_points, niters)
+    if best_count <= 0:
+        return np.eye(3), 0
+    inl = np.nonzero(best_mask)[0]
+    ref = _solve_pnp_lm(obj[inl], img[inl], f, cx, cy, best[0], best[1], 20)
+    if ref is not None:
+        best = ref
+    return rodrigues(rodrigues_inv(best[0])), best_count
 
 
 def project_to_output(points, K_in, K_out, R_warp, in_fish=True, out_fish=False):

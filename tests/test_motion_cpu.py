@@ -46,6 +46,46 @@ def test_rotation_estimate_with_outliers_and_noise(vs):
     assert oracle.rotation_angle(R @ Rt.T) < 1.5e-3
 
 
+def test_rotation_estimate_equals_independent_restatement(vs):
+    """The product's guess_camera_rotation (FrameSourceWarp.cpp:316-375: undistortion, seeded random depths, 5-point
+    RANSAC at 8 px / 0.99 / 100 iterations, refit, Rodrigues) against oracle/geometry.py's numpy restatement on the same
+    PCG32 stream: same inlier count, R to 1e-9 -- from small shakes to 12 degrees between frames, up to 50 % outliers --
+    and both recover the true rotation."""
+    rng = np.random.default_rng(5)
+    for (w, h) in [(1920, 1080), (3840, 2160)]:
+        K = oracle.get_preset_camera(4, w, h)
+        Ko, _ = oracle.get_output_camera(K, w, h)
+        for deg in (0.2, 3.0, 5.0, 8.0, 12.0):
+            for outliers in (0.0, 0.3, 0.5):
+                ax = rng.normal(size=3)
+                Rt = oracle.rodrigues(ax / np.linalg.norm(ax) * np.deg2rad(deg))
+                p, c = _pairs(K, w, h, Rt, 200, rng, outlier_frac=outliers, noise=0.2)
+                seed = int(rng.integers(1, 1000))
+                Rp, ip = vs.estimate_rotation(p, c, K, Ko, seed=seed)
+                Ro, io = oracle.estimate_rotation(p, c, K, Ko, oracle.Pcg32(seed))
+                assert ip == io and np.abs(Rp - Ro).max() < 1e-9, (deg, outliers, ip, io)
+                assert ip >= 0.9 * (1 - outliers) * 200
+                assert np.degrees(oracle.rotation_angle(Rp @ Rt.T)) < 0.1, (deg, outliers)
+
+
+def test_bad_estimate_reaches_the_inlier_gate(vs):
+    """FrameSourceWarp.cpp:432-438 through a BAD estimate rather than too few points: 200 tracked pairs of which 85 %
+    are wrong leave fewer than 40 inliers, in the product and in the oracle alike."""
+    rng = np.random.default_rng(9)
+    K = oracle.get_preset_camera(4, 1920, 1080)
+    Ko, _ = oracle.get_output_camera(K, 1920, 1080)
+    p, c = _pairs(K, 1920, 1080, oracle.rodrigues((0.05, -0.02, 0.03)), 200, rng, outlier_frac=0.85, noise=0.3)
+    Rp, ip = vs.estimate_rotation(p, c, K, Ko, seed=21)
+    Ro, io = oracle.estimate_rotation(p, c, K, Ko, oracle.Pcg32(21))
+    assert ip == io and ip < 40 and np.abs(Rp - Ro).max() < 1e-9
+
+
+def test_pcg32_stream_matches_the_product(vs):
+    """The seeded stream itself: identical estimates for identical seeds, different draws for different seeds."""
+    g = oracle.Pcg32(42, 54)
+    assert [g.next() for _ in range(3)] == [0xa15c02b7, 0x7b47f409, 0xba1d3330]   # pcg32-demo, seed 42 / sequence 54
+
+
 def test_rotation_estimate_degenerate_inputs(vs):
     K = oracle.get_preset_camera(4, 1920, 1080)
     Ko, _ = oracle.get_output_camera(K, 1920, 1080)

@@ -42,10 +42,10 @@ def test_pipeline_matches_oracle_state_machine(vs, cuda, clip):
     Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
     assert stab.out_size == (cw, ch) and np.allclose(stab.K_out, Ko, atol=1e-11)
 
-    # oracle state machine: oracle corner detector + oracle LK, rotation estimates injected from the
-    # product's log (the estimator is randomised in the reference, F6; it is tested by ground truth)
-    it = iter(log)
+    # oracle state machine: oracle corner detector, oracle LK and the oracle's own restatement of guess_camera_rotation
+    # (oracle/geometry.py: same seeded PCG32 stream as vstab_config.seed, nothing taken from the product's log)
     counts = []
+    rng = oracle.Pcg32(11)
 
     def track(prev, cur, corners):
         nxt, st = oracle.pyr_lk(prev, cur, corners)
@@ -53,8 +53,7 @@ def test_pipeline_matches_oracle_state_machine(vs, cuda, clip):
         return corners[st > 0], nxt[st > 0]
 
     def estimate(pp, cp):
-        lg = next(it)
-        return lg["R"], 100  # R already includes the product's own < 40 fallback decision
+        return oracle.estimate_rotation(pp, cp, K, Ko, rng)
 
     warp_rots = []
     sm = oracle.WarpStateMachine(frames, R_SMOOTH, lambda g: oracle.good_features(np.ascontiguousarray(g)), track, estimate,
@@ -69,9 +68,13 @@ def test_pipeline_matches_oracle_state_machine(vs, cuda, clip):
     # key-frame decisions, corner counts and tracked counts are identical (bit-exact detector + tracker)
     assert [l["key"] for l in log] == [l["key"] for l in sm.log]
     assert [(l["n_corners"], l["n_tracked"]) for l in log] == counts
-    # smoothing: rotation handed to the warp agrees with the numpy SG filter / inverses to fp64 rounding
+    # rotation estimates: the product's RANSAC + refit against the oracle's independent restatement, frame by frame
+    assert [l["inliers"] for l in log] == [l["inliers"] for l in sm.log]
+    for a, b in zip(log, sm.log):
+        assert np.allclose(a["R"], b["R"], atol=1e-9)
+    # smoothing: rotation handed to the warp agrees with the numpy SG filter / inverses
     for i in range(N - 1):
-        assert np.allclose(stab.warp_rotation(i), warp_rots[i], atol=1e-11), i
+        assert np.allclose(stab.warp_rotation(i), warp_rots[i], atol=1e-9), i
     # pixels: bit-exact against the oracle warp of the same frame with the product's own rotation
     for i in [0, 1, R_SMOOTH, N - 2]:
         p = oracle.map_params(K, Ko, stab.warp_rotation(i))
@@ -448,7 +451,7 @@ def _check_against_oracle_state_machine(vs, cuda, frames, K, w, h, r, seed):
     n = len(frames)
     assert len(outs) == max(n - 1, 0) and len(log) == max(n - 1, 0)
     Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
-    it = iter(log)
+    rng = oracle.Pcg32(seed)  # the clip's stream of vstab_config.seed
     counts, warp_rots = [], []
 
     def track(prev, cur, corners):
@@ -460,7 +463,7 @@ def _check_against_oracle_state_machine(vs, cuda, frames, K, w, h, r, seed):
         return corners[st > 0], nxt[st > 0]
 
     sm = oracle.WarpStateMachine(frames, r, lambda g: oracle.good_features(np.ascontiguousarray(g)), track,
-                                 lambda pp, cp: (next(it)["R"], 100), lambda f, R: (warp_rots.append(R), f)[1])
+                                 lambda pp, cp: oracle.estimate_rotation(pp, cp, K, Ko, rng), lambda f, R: (warp_rots.append(R), f)[1])
     exp = []
     while True:
         o = sm.pull_frame()
@@ -469,8 +472,10 @@ def _check_against_oracle_state_machine(vs, cuda, frames, K, w, h, r, seed):
         exp.append(o)
     assert [l["key"] for l in log] == [l["key"] for l in sm.log]
     assert [(l["n_corners"], l["n_tracked"]) for l in log] == counts
+    assert [l["inliers"] for l in log] == [l["inliers"] for l in sm.log]   # the oracle's own RANSAC, same seeded stream
+    assert all(np.allclose(a["R"], b["R"], atol=1e-9) for a, b in zip(log, sm.log))
     for i in range(len(outs)):
-        assert np.allclose(stab.warp_rotation(i), warp_rots[i], atol=1e-10), i
+        assert np.allclose(stab.warp_rotation(i), warp_rots[i], atol=1e-9), i
         p = oracle.map_params(K, Ko, stab.warp_rotation(i))
         assert np.array_equal(outs[i], oracle.warp_nv12(exp[i], p, cw, ch)), i
     return log
