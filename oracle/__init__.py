@@ -278,6 +278,11 @@ def scharr(img):
     return d
 
 
+def set_lk_accumulation(float_raster_order):
+    """False (normative): exact int64 LK sums.  True: fp32 raster-order accumulation, for measuring the gap."""
+    lib().vo_set_lk_accumulation(1 if float_raster_order else 0)
+
+
 def pyr_lk(prev, nxt, pts):
     """find_point_pairs_with_optical_flow's calcOpticalFlowPyrLK, FrameSourceWarp.cpp:252."""
     a, ap = _u8(prev)

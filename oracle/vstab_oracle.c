@@ -627,6 +627,12 @@ VO_API int vo_pyramid_levels(int w, int h) {
 
 static inline int vo_cvfloor(float v) { return (int)floorf(v); }
 
+/* Accumulation of the LK sums.  0 (normative for this project): exact int64 sums converted once.  1: fp32 accumulation in
+ * raster order, the literal reading of OpenCV's scalar loop -- only used to MEASURE what the documented
+ * deviation is worth (tests/test_oracle_cpu.py); OpenCV's SIMD builds use yet another, lane-wise order. */
+static int vo_lk_float_acc = 0;
+VO_API void vo_set_lk_accumulation(int mode) { vo_lk_float_acc = mode != 0; }
+
 static void vo_lk_point(const vo_level *I, const vo_level *J, int level, int max_level,
                         const float *prev_pt, float *next_pt, uint8_t *status) {
     const float half = (VO_LK_WIN - 1) * 0.5f;
@@ -653,6 +659,7 @@ static void vo_lk_point(const vo_level *I, const vo_level *J, int level, int max
     int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
     int16_t Iw[VO_LK_WIN * VO_LK_WIN], Ixw[VO_LK_WIN * VO_LK_WIN], Iyw[VO_LK_WIN * VO_LK_WIN];
     int64_t sA11 = 0, sA12 = 0, sA22 = 0;
+    float fA11 = 0, fA12 = 0, fA22 = 0;
     for (int y = 0; y < VO_LK_WIN; y++)
         for (int x = 0; x < VO_LK_WIN; x++) {
             int X = ipx + x, Y = ipy + y;
@@ -671,8 +678,10 @@ static void vo_lk_point(const vo_level *I, const vo_level *J, int level, int max
             sA11 += (int64_t)ixval * ixval;
             sA12 += (int64_t)ixval * iyval;
             sA22 += (int64_t)iyval * iyval;
+            fA11 += (float)(ixval * ixval), fA12 += (float)(ixval * iyval), fA22 += (float)(iyval * iyval);
         }
     float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+    if (vo_lk_float_acc) A11 = fA11 * FLT_SCALE, A12 = fA12 * FLT_SCALE, A22 = fA22 * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     float minEig = ((A22 + A11) - sqrtf((A11 - A22) * (A11 - A22) + (4.f * A12) * A12)) /
                    (float)(2 * VO_LK_WIN * VO_LK_WIN);
@@ -696,6 +705,7 @@ static void vo_lk_point(const vo_level *I, const vo_level *J, int level, int max
         iw10 = (int)lrintf((1.f - a) * b * (1 << W_BITS));
         iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         int64_t sb1 = 0, sb2 = 0;
+        float fb1 = 0, fb2 = 0;
         for (int y = 0; y < VO_LK_WIN; y++)
             for (int x = 0; x < VO_LK_WIN; x++) {
                 int X = inx + x, Y = iny + y;
@@ -705,8 +715,10 @@ static void vo_lk_point(const vo_level *I, const vo_level *J, int level, int max
                            Iw[y * VO_LK_WIN + x];
                 sb1 += (int64_t)diff * Ixw[y * VO_LK_WIN + x];
                 sb2 += (int64_t)diff * Iyw[y * VO_LK_WIN + x];
+                fb1 += (float)(diff * Ixw[y * VO_LK_WIN + x]), fb2 += (float)(diff * Iyw[y * VO_LK_WIN + x]);
             }
         float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+        if (vo_lk_float_acc) b1 = fb1 * FLT_SCALE, b2 = fb2 * FLT_SCALE;
         float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
         npx += dx, npy += dy;
         next_pt[0] = npx + half, next_pt[1] = npy + half;

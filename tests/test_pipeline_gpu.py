@@ -554,6 +554,58 @@ def test_pipeline_at_4k_baseline_config(vs, cuda):
     assert np.array_equal(y.cpu().numpy(), ey) and np.array_equal(uv.cpu().numpy().reshape(euv.shape), euv)
 
 
+def test_long_bench_shaped_run_1080p(vs, cuda):
+    """The configuration bench.py times, checked end to end: 1080p, smooth_radius 30, 160 frames through the C ring source
+    (frames used in place: `hold`), chained tracker launches and speculative corner detection on -- against the oracle's
+    state machine with the oracle's own detector, tracker and rotation estimator: key-frame list (the > 20 frames rule
+    fires seven times), corner / track / inlier counts, rotations, every tenth emitted frame bit for bit."""
+    import torch
+    import bench
+    w, h, r, n = 1920, 1080, 30, 160
+    K = oracle.get_preset_camera(4, w, h)
+    Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
+    dev_frames, _ = bench.shaky_ring(torch, cuda, w, h, K, n, seed=5)
+    stab = vs.Stabilizer(dev_frames, total=n, smooth_radius=r, seed=77)
+    outs = {}
+    i = 0
+    while True:
+        o = stab.pull()
+        if o is None:
+            break
+        if i % 10 == 0 or i == n - 2:
+            outs[i] = o.cpu().numpy()
+        i += 1
+    assert i == n - 1
+    log = stab.frame_log()
+    frames = [f.cpu().numpy() for f in dev_frames]
+    rng = oracle.Pcg32(77)
+    counts, warp_rots = [], []
+
+    def track(prev, cur, corners):
+        nxt, st = oracle.pyr_lk(prev, cur, corners)
+        counts.append((len(corners), int((st > 0).sum())))
+        return corners[st > 0], nxt[st > 0]
+
+    sm = oracle.WarpStateMachine(frames, r, lambda g: oracle.good_features(np.ascontiguousarray(g)), track,
+                                 lambda pp, cp: oracle.estimate_rotation(pp, cp, K, Ko, rng), lambda f, R: (warp_rots.append(R), f)[1])
+    exp = []
+    while True:
+        o = sm.pull_frame()
+        if o is None:
+            break
+        exp.append(o)
+    assert len(exp) == n - 1
+    keys = [k for k, l in enumerate(log) if l["key"]]
+    assert keys == [k for k, l in enumerate(sm.log) if l["key"]] and len(keys) >= 7
+    assert [(l["n_corners"], l["n_tracked"]) for l in log] == counts
+    assert [l["inliers"] for l in log] == [l["inliers"] for l in sm.log]
+    assert all(np.allclose(a["R"], b["R"], atol=1e-9) for a, b in zip(log, sm.log))
+    for k in range(n - 1):
+        assert np.allclose(stab.warp_rotation(k), warp_rots[k], atol=1e-9), k
+    for k, got in outs.items():
+        assert np.array_equal(got, oracle.warp_nv12(exp[k], oracle.map_params(K, Ko, stab.warp_rotation(k)), cw, ch)), k
+
+
 @pytest.mark.gpu
 def test_bench_launches_its_own_ranks():
     """`bench.py --gpus 2` outside torch.distributed.run starts two ranks itself (rehearsed on one GPU over gloo) and
