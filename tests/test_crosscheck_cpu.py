@@ -2,6 +2,7 @@
 neither is in the container) against INDEPENDENT implementations that are: scipy / numpy fp64 models.
 They pin the parts of the oracle that the reference tree itself cannot pin."""
 import numpy as np
+import pytest
 import scipy.linalg
 import scipy.ndimage as ndi
 import scipy.signal
@@ -119,3 +120,30 @@ def test_lk_tracks_a_known_subpixel_translation():
     assert st.mean() > 0.9
     d = (nxt - pts)[st > 0]
     assert np.abs(np.median(d[:, 0]) - dx) < 0.05 and np.abs(np.median(d[:, 1]) - dy) < 0.05
+
+
+def test_opencv_itself_when_present():
+    """if a machine with OpenCV ever appears, check the restatements against the real thing.  Neither the
+    build container nor the GPU box has cv2 (no wheel, no network), so this normally skips; it is never required."""
+    cv2 = pytest.importorskip("cv2")
+    rng = np.random.default_rng(0)
+    w, h = 320, 180
+    frame = synth.nv12(5, w, h)
+    # a2: cvtColor(COLOR_YUV2BGR_NV12), CPU path -- bit-exact expected (20-bit fixed point)
+    assert np.array_equal(oracle.cvt_nv12_bgr(frame), cv2.cvtColor(frame, cv2.COLOR_YUV2BGR_NV12))
+    # a10: remap INTER_LINEAR, BORDER_CONSTANT 0 -- bit-exact expected (1/32-px quantisation, 15-bit weights)
+    bgr = oracle.cvt_nv12_bgr(frame)
+    mx = (np.tile(np.arange(w, dtype=np.float32), (h, 1)) * 0.93 + rng.uniform(-3, 3, (h, w))).astype(np.float32)
+    my = (np.tile(np.arange(h, dtype=np.float32)[:, None], (1, w)) * 1.04 + rng.uniform(-3, 3, (h, w))).astype(np.float32)
+    assert np.array_equal(oracle.remap_bilinear(bgr, mx, my), cv2.remap(bgr, mx, my, cv2.INTER_LINEAR, borderMode=cv2.BORDER_CONSTANT, borderValue=0))
+    # a3: goodFeaturesToTrack(200, 0.01, 30) -- same corner list expected (float summation order may move ties)
+    gray = np.ascontiguousarray(frame[:h])
+    ours = oracle.good_features(gray)
+    theirs = cv2.goodFeaturesToTrack(gray, 200, 0.01, 30).reshape(-1, 2)
+    assert len(ours) == len(theirs) and np.abs(ours - theirs).max() <= 1.0
+    # a4: calcOpticalFlowPyrLK defaults -- tracks within the accumulation-order noise (test_oracle_cpu: <= 0.05 px)
+    nxt = np.roll(gray, (1, 2), axis=(0, 1))
+    o_pts, o_st = oracle.pyr_lk(gray, nxt, ours)
+    c_pts, c_st, _ = cv2.calcOpticalFlowPyrLK(gray, nxt, ours.reshape(-1, 1, 2), None)
+    both = (o_st > 0) & (c_st.reshape(-1) > 0)
+    assert (o_st > 0).sum() == (c_st > 0).sum() and np.abs(o_pts - c_pts.reshape(-1, 2))[both].max() < 0.05
