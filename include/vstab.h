@@ -147,6 +147,15 @@ VSTAB_API vstab_status vstab_warp_nv12_ex(const void *y, size_t pitch_y, const v
                                           int out_format, void *dst, size_t pitch_dst, void *dst_uv,
                                           size_t pitch_dst_uv, int dst_width, int dst_height, void *stream);
 
+/* Rolling-shutter warp (BASELINE.json config 5: "rolling-shutter per-row warp"; no counterpart in the reference, whose gyro
+ * path is a stub: gpmf.cpp:5-11): vstab_warp_nv12_ex for map modes 0 / 1 with a rotation per OUTPUT ROW.  Row y is mapped
+ * with the matrix whose nine entries are interpolated in fp32 between params[8..16] (first row) and rot_bottom (last row):
+ * t = (float)y / (float)max(dst_height - 1, 1), m_k = fmaf(t, rot_bottom[k] - params[8 + k], params[8 + k]). */
+VSTAB_API vstab_status vstab_warp_nv12_rs(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv,
+                                          int src_width, int src_height, const float params[17], const float rot_bottom[9],
+                                          int map_mode, int out_format, void *dst, size_t pitch_dst, void *dst_uv,
+                                          size_t pitch_dst_uv, int dst_width, int dst_height, void *stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Tracking front-end (device images in; small point lists on the host, as in the reference where

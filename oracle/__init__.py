@@ -62,6 +62,8 @@ def lib():
         L.vo_create_map_ex.argtypes = [f32p, f32p, c.c_int, c.c_int, f32p, c.c_int]
         L.vo_cvt_bgr_nv12.argtypes = [u8p, c.c_int, c.c_int, u8p, u8p]
         L.vo_warp_nv12_ex.argtypes = [u8p, c.c_int, c.c_int, f32p, c.c_int, c.c_int, u8p, c.c_int, c.c_int, u8p]
+        L.vo_create_map_rs.argtypes = [f32p, f32p, c.c_int, c.c_int, f32p, f32p, c.c_int]
+        L.vo_warp_nv12_rs.argtypes = [u8p, c.c_int, c.c_int, f32p, f32p, c.c_int, c.c_int, u8p, c.c_int, c.c_int, u8p]
         L.vo_min_eig.argtypes = [u8p, c.c_size_t, c.c_int, c.c_int, f32p]
         L.vo_good_features.argtypes = [u8p, c.c_size_t, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, f32p, f32p]
         L.vo_good_features.restype = c.c_int
@@ -237,6 +239,31 @@ def warp_nv12_ex(nv12, params, dw, dh, mode=0, out_format=0):
     out = np.empty(dw * dh * 3 if out_format == 0 else dw * dh + 2 * cw * ch, np.uint8)
     work = np.empty(w * h * 3 + 16 + 2 * dw * dh * 4 + dw * dh * 3, np.uint8)
     lib().vo_warp_nv12_ex(ap, w, h, pp, int(mode), int(out_format), _p(out, ctypes.c_uint8), dw, dh, _p(work, ctypes.c_uint8))
+    if out_format == 0:
+        return out.reshape(dh, dw, 3)
+    return out[: dw * dh].reshape(dh, dw), out[dw * dh:].reshape(ch, cw, 2)
+
+
+def create_map_rs(params, rot_bottom, cols, rows, mode=0):
+    """Rolling-shutter map planes (config 5): row y uses the rotation interpolated between params[8:17] and rot_bottom."""
+    p, pp = _f32(params)
+    rb, rbp = _f32(np.asarray(rot_bottom, np.float32).reshape(9))
+    mx, my = np.empty((rows, cols), np.float32), np.empty((rows, cols), np.float32)
+    lib().vo_create_map_rs(_p(mx, ctypes.c_float), _p(my, ctypes.c_float), cols, rows, pp, rbp, int(mode))
+    return mx, my
+
+
+def warp_nv12_rs(nv12, params, rot_bottom, dw, dh, mode=0, out_format=0):
+    """Rolling-shutter warp chain.  out_format 0 -> (dh, dw, 3) BGR; 1 -> (y, uv) as cvt_bgr_nv12."""
+    rows, w = nv12.shape
+    h = rows * 2 // 3
+    a, ap = _u8(nv12)
+    p, pp = _f32(params)
+    rb, rbp = _f32(np.asarray(rot_bottom, np.float32).reshape(9))
+    cw, ch = (dw + 1) // 2, (dh + 1) // 2
+    out = np.empty(dw * dh * 3 if out_format == 0 else dw * dh + 2 * cw * ch, np.uint8)
+    work = np.empty(w * h * 3 + 16 + 2 * dw * dh * 4 + dw * dh * 3, np.uint8)
+    lib().vo_warp_nv12_rs(ap, w, h, pp, rbp, int(mode), int(out_format), _p(out, ctypes.c_uint8), dw, dh, _p(work, ctypes.c_uint8))
     if out_format == 0:
         return out.reshape(dh, dw, 3)
     return out[: dw * dh].reshape(dh, dw), out[dw * dh:].reshape(ch, cw, 2)

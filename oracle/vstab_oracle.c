@@ -324,6 +324,32 @@ VO_API void vo_create_map_ex(float *mapx, float *mapy, int cols, int rows, const
 }
 
 /* ------------------------------------------------------------------------------------------
+ * BASELINE config 5 (no reference counterpart; arithmetic defined by this project): rolling-shutter warp.  Output row y
+ * is mapped with its own matrix, the nine entries interpolated in fp32 between the rotation of the first row (p[8..16])
+ * and the rotation of the last row (rot_bottom):  t = (float)y / (float)max(rows - 1, 1)  (IEEE division),
+ * d_k = rot_bottom[k] - p[8 + k],  m_k = fmaf(t, d_k, p[8 + k]);  then the map arithmetic of `mode` (0 = createMap.cl,
+ * 1 = fish -> rect) with m in place of the rotation.  No re-orthonormalisation: the two rotations are a frame apart.
+ * ------------------------------------------------------------------------------------------ */
+VO_API void vo_create_map_rs(float *mapx, float *mapy, int cols, int rows, const float *p, const float *rot_bottom, int mode) {
+    float d[9];
+    for (int k = 0; k < 9; k++) d[k] = rot_bottom[k] - p[8 + k];
+    const float den = (float)(rows > 1 ? rows - 1 : 1);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < rows; y++) {
+        float q[17];
+        memcpy(q, p, sizeof q);
+        const float t = (float)y / den;
+        for (int k = 0; k < 9; k++) q[8 + k] = fmaf(t, d[k], p[8 + k]);
+        for (int x = 0; x < cols; x++) {
+            if (mode == 0)
+                vo_map_pixel(x, y, q, mapx + (size_t)y * cols + x, mapy + (size_t)y * cols + x);
+            else
+                vo_map_pixel_ex(x, y, q, mode, mapx + (size_t)y * cols + x, mapy + (size_t)y * cols + x);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * f2: NV12 output for the encoder hand-off (render.ts:275-281).
  * The reference's C++ path stops at BGR; the conversion is DEFINED as OpenCV 4.5's
  * cvtColor(COLOR_BGR2YUV_I420) arithmetic (imgproc color_yuv, RGB8toYUV420pInvoker: BT.601
@@ -370,6 +396,24 @@ VO_API void vo_warp_nv12_ex(const uint8_t *nv12, int w, int h, const float *p, i
     uint8_t *tmp = (uint8_t *)(mapy + (size_t)dw * dh);
     vo_cvt_nv12_bgr(nv12, w, h, bgr);
     vo_create_map_ex(mapx, mapy, dw, dh, p, mode);
+    if (out_format == 0) {
+        vo_remap_bilinear(bgr, w, h, 3, mapx, mapy, dst, dw, dh);
+    } else {
+        vo_remap_bilinear(bgr, w, h, 3, mapx, mapy, tmp, dw, dh);
+        vo_cvt_bgr_nv12(tmp, dw, dh, dst, dst + (size_t)dw * dh);
+    }
+}
+
+/* the rolling-shutter warp as a reference-style chain (cvtColor, per-row map planes, remap, optional BGR -> NV12);
+ * buffers as vo_warp_nv12_ex */
+VO_API void vo_warp_nv12_rs(const uint8_t *nv12, int w, int h, const float *p, const float *rot_bottom, int mode, int out_format,
+                            uint8_t *dst, int dw, int dh, uint8_t *work) {
+    uint8_t *bgr = work;
+    float *mapx = (float *)(work + (((size_t)w * h * 3 + 15) & ~(size_t)15));
+    float *mapy = mapx + (size_t)dw * dh;
+    uint8_t *tmp = (uint8_t *)(mapy + (size_t)dw * dh);
+    vo_cvt_nv12_bgr(nv12, w, h, bgr);
+    vo_create_map_rs(mapx, mapy, dw, dh, p, rot_bottom, mode);
     if (out_format == 0) {
         vo_remap_bilinear(bgr, w, h, 3, mapx, mapy, dst, dw, dh);
     } else {

@@ -133,3 +133,30 @@ def test_warp_chain_nv12_output_is_conversion_of_bgr_output():
     y, uv = oracle.warp_nv12_ex(f, p, 101, 57, oracle.MAP_FISH_TO_RECT, 1)
     ey, euv = oracle.cvt_bgr_nv12(bgr)
     assert np.array_equal(y, ey) and np.array_equal(uv, euv)
+
+
+def test_rolling_shutter_map_definition():
+    """vo_create_map_rs (config 5, defined by this project): row 0 uses the first rotation exactly, the matrix of row y is
+    the fp32 interpolation t = y / (rows - 1), and for a small rotation difference the map lies between the two per-frame
+    maps (it is their interpolation to first order)."""
+    w, h = 640, 360
+    K = oracle.get_preset_camera(4, w, h)
+    Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
+    p = oracle.map_params(K, Ko, oracle.rodrigues((0.01, 0.02, -0.01)))
+    pb = oracle.map_params(K, Ko, oracle.rodrigues((0.02, 0.01, 0.01)))
+    mx, my = oracle.create_map_rs(p, pb[8:], cw, ch)
+    tx, ty = oracle.create_map(p, cw, ch)
+    bx, by = oracle.create_map(pb, cw, ch)
+    assert np.array_equal(mx[0], tx[0]) and np.array_equal(my[0], ty[0])
+    y = ch // 3
+    q = p.copy()
+    t = np.float32(y) / np.float32(ch - 1)
+    q[8:] = (np.float64(t) * (pb[8:] - p[8:]).astype(np.float64) + p[8:].astype(np.float64)).astype(np.float32)   # fmaf
+    rx, ry = oracle.create_map(q, cw, ch)
+    assert np.array_equal(mx[y], rx[y]) and np.array_equal(my[y], ry[y])
+    lo, hi = np.minimum(tx, bx) - 0.05, np.maximum(tx, bx) + 0.05
+    ok = ~np.isnan(mx)
+    assert ((mx >= lo) & (mx <= hi))[ok].all()
+    # identical rotations: the per-frame map, bit for bit
+    sx, sy = oracle.create_map_rs(p, p[8:], cw, ch)
+    assert np.array_equal(sx, tx, equal_nan=True) and np.array_equal(sy, ty, equal_nan=True)

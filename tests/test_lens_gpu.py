@@ -316,3 +316,41 @@ def test_quantised_map_warp_equals_direct_warp(vs, cuda):
     a = vs.warp_nv12(fd, p, cw, ch, vs.MAP_CREATEMAP_CL)
     b = vs.warp_nv12_mapped(fd, vs.quantised_map(p, cw, ch, vs.MAP_CREATEMAP_CL), cw, ch)
     assert bool((a == b).all()) and int(a[int(Ko[1, 2]), int(Ko[0, 2])].sum()) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: rolling-shutter warp (a rotation per output row).  No reference counterpart; the arithmetic is
+# defined in oracle/vstab_oracle.c (vo_create_map_rs) and reproduced bit for bit by k_warp_fused's RS instantiations.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,mode,fmt", [(640, 360, 0, 0), (640, 360, 1, 0), (640, 360, 0, 1), (1920, 1080, 0, 0), (322, 182, 1, 0)])
+def test_rolling_shutter_warp_bit_exact_vs_oracle(vs, cuda, w, h, mode, fmt):
+    K = oracle.get_preset_camera(4, w, h)
+    Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
+    frame = synth.nv12(21, w, h)
+    fd = dev(frame, cuda)
+    for top, bot in [((0.0, 0.0, 0.0), (0.0, 0.0, 0.0)), ((0.01, -0.02, 0.005), (0.03, -0.01, -0.01)), ((0.2, 0.1, -0.3), (0.25, 0.12, -0.28))]:
+        p = oracle.map_params(K, Ko, oracle.rodrigues(top))
+        rb = oracle.map_params(K, Ko, oracle.rodrigues(bot))[8:]
+        exp = oracle.warp_nv12_rs(frame, p, rb, cw, ch, mode, fmt)
+        got = vs.warp_nv12_rs(fd, p, rb, cw, ch, mode, fmt)
+        if fmt == 0:
+            assert np.array_equal(got.cpu().numpy(), exp), (top, bot, int((got.cpu().numpy() != exp).sum()))
+        else:
+            assert np.array_equal(got[0].cpu().numpy(), exp[0]) and np.array_equal(got[1].cpu().numpy().reshape(exp[1].shape), exp[1])
+    # equal rotations top and bottom = the per-frame warp
+    p = oracle.map_params(K, Ko, oracle.rodrigues((0.02, 0.01, -0.03)))
+    same = vs.warp_nv12_rs(fd, p, p[8:], cw, ch, mode, 0)
+    assert np.array_equal(same.cpu().numpy(), vs.warp_nv12(fd, p, cw, ch, mode, 0).cpu().numpy())
+
+
+def test_rolling_shutter_warp_at_4k_and_bad_modes(vs, cuda):
+    w, h = 3840, 2160
+    K = oracle.get_preset_camera(4, w, h)
+    Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
+    frame = synth.nv12(22, w, h)
+    p = oracle.map_params(K, Ko, oracle.rodrigues((0.004, -0.002, 0.001)))
+    rb = oracle.map_params(K, Ko, oracle.rodrigues((0.006, -0.001, 0.002)))[8:]   # 0.2 degrees of shake during the readout
+    got = vs.warp_nv12_rs(dev(frame, cuda), p, rb, cw, ch).cpu().numpy()
+    assert np.array_equal(got, oracle.warp_nv12_rs(frame, p, rb, cw, ch))
+    with pytest.raises(vs.VstabError):
+        vs.warp_nv12_rs(dev(frame, cuda), p, rb, cw, ch, mode=2)   # fisheye output: no per-row variant

@@ -94,6 +94,7 @@ SIGNATURES = {
     "vstab_warp_nv12_bgr": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _vp, _sz, _i, _i, _vp]),
     "vstab_create_map_ex": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _vp]),
     "vstab_warp_nv12_ex": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
+    "vstab_warp_nv12_rs": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _fp, _i, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
     "vstab_quantised_map_bytes": (_sz, [_i, _i]),
     "vstab_quantised_map": (_i, [_vp, _i, _i, _fp, _i, _vp]),
     "vstab_warp_nv12_mapped": (_i, [_vp, _sz, _vp, _sz, _i, _i, _vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
@@ -316,6 +317,26 @@ def warp_nv12(nv12, params, dw, dh, mode=MAP_CREATEMAP_CL, out_format=OUT_BGR8, 
     yo, co = out
     _check(_L.vstab_warp_nv12_ex(yp, pitch, uvp, pitch, w, h, _fptr(p), int(mode), int(out_format), yo.data_ptr(), yo.stride(0),
                                  co.data_ptr(), co.stride(0), dw, dh, _stream()), "vstab_warp_nv12_ex")
+    return yo, co
+
+
+def warp_nv12_rs(nv12, params, rot_bottom, dw, dh, mode=MAP_CREATEMAP_CL, out_format=OUT_BGR8, out=None):
+    """vstab_warp_nv12_rs: the warp with a rotation per output row (first row params[8:17], last row rot_bottom)."""
+    import torch
+    yp, uvp, pitch, w, h = _planes(nv12)
+    p = np.ascontiguousarray(params, np.float32)
+    rb = np.ascontiguousarray(rot_bottom, np.float32).reshape(9)
+    if out_format == OUT_BGR8:
+        if out is None:
+            out = torch.empty((dh, dw, 3), dtype=torch.uint8, device=nv12.device)
+        _check(_L.vstab_warp_nv12_rs(yp, pitch, uvp, pitch, w, h, _fptr(p), _fptr(rb), int(mode), OUT_BGR8, out.data_ptr(), out.stride(0), None, 0,
+                                     dw, dh, _stream()), "vstab_warp_nv12_rs")
+        return out
+    if out is None:
+        out = nv12_out_planes(dw, dh, nv12.device)
+    yo, co = out
+    _check(_L.vstab_warp_nv12_rs(yp, pitch, uvp, pitch, w, h, _fptr(p), _fptr(rb), int(mode), int(out_format), yo.data_ptr(), yo.stride(0),
+                                 co.data_ptr(), co.stride(0), dw, dh, _stream()), "vstab_warp_nv12_rs")
     return yo, co
 
 

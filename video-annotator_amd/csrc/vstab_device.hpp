@@ -169,13 +169,13 @@ __device__ __forceinline__ f32x2 sqrt_rn2(f32x2 x) {
     return fma2(d, h, g);
 }
 // map_pixel32 (FISH_TO_RECT = false) / map_pixel_ex<MAP_FISH_TO_RECT> (true) for two pixels of one column: a = column terms,
-// b = row terms of the two rows
+// b = row terms, r = third column of the rotation, each for the two rows (all three differ per row in the rolling-shutter warp)
 template <bool FISH_TO_RECT>
-__device__ __forceinline__ void map_pixel32_x2(float icx32, float icy32, float ifx32, float ify32, float r02, float r12, float r22,
-                                               float a0, float a1, float a2, f32x2 b0, f32x2 b1, f32x2 b2, f32x2 &ax, f32x2 &ay) {
-    const f32x2 wx = (splat2(a0) + b0) + splat2(r02);
-    const f32x2 wy = (splat2(a1) + b1) + splat2(r12);
-    const f32x2 wz = (splat2(a2) + b2) + splat2(r22);
+__device__ __forceinline__ void map_pixel32_x2(float icx32, float icy32, float ifx32, float ify32, f32x2 r02, f32x2 r12, f32x2 r22,
+                                               f32x2 a0, f32x2 a1, f32x2 a2, f32x2 b0, f32x2 b1, f32x2 b2, f32x2 &ax, f32x2 &ay) {
+    const f32x2 wx = (a0 + b0) + r02;
+    const f32x2 wy = (a1 + b1) + r12;
+    const f32x2 wz = (a2 + b2) + r22;
     const f32x2 rz = rcp_refined2(wz);
     const f32x2 px = div_with_rcp2(wx, wz, rz), py = div_with_rcp2(wy, wz, rz);
     const f32x2 q = px * px + py * py;
@@ -211,7 +211,9 @@ __device__ __forceinline__ void map_pixel32_x2(float icx32, float icy32, float i
 // FISH_TO_RECT performs createMap.cl's operations and differs only where createMap.cl degenerates
 // (axis ray: correction factor 1 instead of 0/0; rays behind the camera: outside instead of mirrored).
 // ---------------------------------------------------------------------------------------------
-enum MapMode { MAP_CREATEMAP_CL = 0, MAP_FISH_TO_RECT = 1, MAP_FISH_TO_FISH = 2, MAP_RECT_TO_RECT = 3, MAP_RECT_TO_FISH = 4 };
+enum MapMode { MAP_CREATEMAP_CL = 0, MAP_FISH_TO_RECT = 1, MAP_FISH_TO_FISH = 2, MAP_RECT_TO_RECT = 3, MAP_RECT_TO_FISH = 4,
+               // internal: modes 0 / 1 with a per-row rotation (rolling shutter, BASELINE config 5)
+               MAP_RS_CREATEMAP_CL = 5, MAP_RS_FISH_TO_RECT = 6 };
 template <int MODE>
 struct ModeTraits {
     static constexpr bool out_fish = MODE == MAP_FISH_TO_FISH || MODE == MAP_RECT_TO_FISH;

@@ -454,7 +454,8 @@ vstab_status vstab_remap_bilinear(const void *src, size_t pitch_src, int sw, int
 
 static vstab_status warp_impl(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh,
                               const float params[17], int map_mode, int out_format, void *dst, size_t pitch_dst,
-                              void *dst_uv, size_t pitch_dst_uv, int dw, int dh, void *stream, const void *qmap, int qpitch) {
+                              void *dst_uv, size_t pitch_dst_uv, int dw, int dh, void *stream, const void *qmap, int qpitch,
+                              const float *rot_bottom = nullptr) {
     if (!y || !uv || !dst || !params) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: null pointer");
     if (sw <= 0 || sh <= 0 || (sw & 1) || (sh & 1) || sw > 32767 || sh > 32767)
         return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: source must be even-sized and <= 32767");
@@ -475,7 +476,9 @@ static vstab_status warp_impl(const void *y, size_t pitch_y, const void *uv, siz
     a.p = to_params(params);
     const int vec_ok = aligned(dst, 4) && pitch_dst % 4 == 0 && (!nv12_out || (aligned(dst_uv, 4) && pitch_dst_uv % 4 == 0));
     const bool small_pitch = pitch_y < (1u << 24) && pitch_uv < (1u << 24) && (uint64_t)pitch_y * sh < (1ull << 32);
-    const bool plain = map_mode == VSTAB_MAP_CREATEMAP_CL && !nv12_out && !qmap;
+    if (rot_bottom && map_mode != VSTAB_MAP_CREATEMAP_CL && map_mode != VSTAB_MAP_FISH_TO_RECT)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_rs: the per-row warp exists for the fisheye -> pinhole modes (0, 1) only");
+    const bool plain = map_mode == VSTAB_MAP_CREATEMAP_CL && !nv12_out && !qmap && !rot_bottom;
     if (!plain && !small_pitch) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: source pitch too large for this mode");
     bool direct = !small_pitch;
 #ifdef VSTAB_DEV
@@ -487,7 +490,7 @@ static vstab_status warp_impl(const void *y, size_t pitch_y, const void *uv, siz
         hipLaunchKernelGGL(k_warp_nv12_bgr, grid, dim3(16, 16), 0, static_cast<hipStream_t>(stream), a, vec_ok);
     } else {
         const bool src_vec_ok = aligned(y, 8) && aligned(uv, 8) && pitch_y % 8 == 0 && pitch_uv % 8 == 0;  // 8-byte staging loads
-        return launch_warp_fused(a, params, map_mode, nv12_out, src_vec_ok, vec_ok, qmap, qpitch, static_cast<hipStream_t>(stream));
+        return launch_warp_fused(a, params, map_mode, nv12_out, src_vec_ok, vec_ok, qmap, qpitch, rot_bottom, static_cast<hipStream_t>(stream));
     }
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
@@ -511,6 +514,14 @@ vstab_status vstab_warp_nv12_ex(const void *y, size_t pitch_y, const void *uv, s
                                 const float params[17], int map_mode, int out_format, void *dst, size_t pitch_dst,
                                 void *dst_uv, size_t pitch_dst_uv, int dw, int dh, void *stream) {
     return warp_impl(y, pitch_y, uv, pitch_uv, sw, sh, params, map_mode, out_format, dst, pitch_dst, dst_uv, pitch_dst_uv, dw, dh, stream, nullptr, 0);
+}
+
+vstab_status vstab_warp_nv12_rs(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh, const float params[17],
+                                const float rot_bottom[9], int map_mode, int out_format, void *dst, size_t pitch_dst, void *dst_uv,
+                                size_t pitch_dst_uv, int dw, int dh, void *stream) {
+    if (!rot_bottom) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_rs: null pointer");
+    return warp_impl(y, pitch_y, uv, pitch_uv, sw, sh, params, map_mode, out_format, dst, pitch_dst, dst_uv, pitch_dst_uv, dw, dh, stream, nullptr, 0,
+                     rot_bottom);
 }
 
 size_t vstab_quantised_map_bytes(int dst_width, int dst_height) {

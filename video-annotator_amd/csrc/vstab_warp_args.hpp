@@ -24,6 +24,8 @@ struct FusedArgs {
     int tiles_x, tiles_y;
     const int2 *qmap;  // CACHED kernels: the quantised map (32 * map rounded to int, NaN -> INT_MIN in x) of every output pixel
     int qpitch;        // its row pitch in pixels (a multiple of 4)
+    float rs_d[9];     // rolling-shutter modes: rotation of the last output row minus rotation of the first (w.p.r), fp32
+    float rs_den;      // and (float)max(dh - 1, 1)
 #ifdef VSTAB_DEV
     unsigned long long *timing;  // development builds: 4 qwords per workgroup {memrealtime, memtime at entry and exit}
     int ablate;                  // timing-only ablations (wrong pixels): 1 linear map, 2 xor blend, 4 raw conversion, 8 no stores
@@ -65,6 +67,6 @@ __device__ __forceinline__ uint32_t load_u32_bytes(const uint8_t *p, int valid) 
 }
 
 vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int map_mode, bool nv12_out, bool src_vec_ok, bool dst_vec_ok,
-                               const void *qmap, int qpitch, hipStream_t st);
+                               const void *qmap, int qpitch, const float *rot_bottom, hipStream_t st);
 
 }  // namespace vstab

@@ -77,6 +77,8 @@ template <int R, int MODE, bool CACHED>
 __device__ __forceinline__ void probe_tile(const FusedArgs &ta, int tile_x, int tile_y, int lane, float rfx, float rfy, uint32_t *hdr) {
     constexpr int TH = 4 * R;
     constexpr int STAGE_MAX = R == 8 ? 3 : 2;
+    constexpr bool RS = MODE >= MAP_RS_CREATEMAP_CL;          // per-row rotation
+    constexpr int BASE = RS ? MODE - MAP_RS_CREATEMAP_CL : MODE;  // the projection pair
     const WarpArgs &a = ta.w;
     const int x0 = tile_x * 64, y0 = tile_y * TH;
     // ---- probe: the map on 64 perimeter pixels -> source bounding box of the tile --------------------------
@@ -93,14 +95,22 @@ __device__ __forceinline__ void probe_tile(const FusedArgs &ta, int tile_x, int 
         qx = q.x, qy = q.y;
     } else {
         float ax, ay;
-        if constexpr (MODE == MAP_CREATEMAP_CL || MODE == MAP_FISH_TO_RECT) {
+        if constexpr (BASE == MAP_CREATEMAP_CL || BASE == MAP_FISH_TO_RECT) {
             // The box needs the map to a fraction of a pixel only (it has a pixel of margin and never decides a result),
             // so the probe uses the approximate reciprocal / rsqrt instructions and fused operations: a third of the
             // dependent chain of the exact evaluation, on the one wave the other three are waiting for.
             const float vx = ((float)(x0 + px) - a.p.ocx) * rfx, vy = ((float)(y0 + py) - a.p.ocy) * rfy;
-            const float wx = __builtin_fmaf(a.p.r[0], vx, __builtin_fmaf(a.p.r[1], vy, a.p.r[2]));
-            const float wy = __builtin_fmaf(a.p.r[3], vx, __builtin_fmaf(a.p.r[4], vy, a.p.r[5]));
-            const float wz = __builtin_fmaf(a.p.r[6], vx, __builtin_fmaf(a.p.r[7], vy, a.p.r[8]));
+            float m[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) m[k] = a.p.r[k];
+            if constexpr (RS) {  // the matrix of this lane's row, to probe accuracy
+                const float t = (float)(y0 + py) * __builtin_amdgcn_rcpf(ta.rs_den);
+#pragma unroll
+                for (int k = 0; k < 9; k++) m[k] = __builtin_fmaf(t, ta.rs_d[k], a.p.r[k]);
+            }
+            const float wx = __builtin_fmaf(m[0], vx, __builtin_fmaf(m[1], vy, m[2]));
+            const float wy = __builtin_fmaf(m[3], vx, __builtin_fmaf(m[4], vy, m[5]));
+            const float wz = __builtin_fmaf(m[6], vx, __builtin_fmaf(m[7], vy, m[8]));
             const float rz = __builtin_amdgcn_rcpf(wz), ux = wx * rz, uy = wy * rz;
             const float q = __builtin_fmaf(ux, ux, uy * uy), rs = __builtin_amdgcn_rsqf(q), rad = q * rs;
             const bool inv = rad > 1.0f;
@@ -117,13 +127,13 @@ __device__ __forceinline__ void probe_tile(const FusedArgs &ta, int tile_x, int 
             at = inv ? 1.57079637050628662109375f - at : at;
             const float k = at * rs;  // atan(rad) / rad; NaN on the axis (q == 0) only widens the box
             ax = __builtin_fmaf(ux * k, ta.p32.ifx32, ta.p32.icx32), ay = __builtin_fmaf(uy * k, ta.p32.ify32, ta.p32.icy32);
-            if (MODE == MAP_FISH_TO_RECT && !(wz > 0.0f)) ax = ay = __builtin_nanf("");
+            if (BASE == MAP_FISH_TO_RECT && !(wz > 0.0f)) ax = ay = __builtin_nanf("");
         } else {
             const float vx = div_with_rcp((float)(x0 + px) - a.p.ocx, a.p.ofx, rfx);
             const float vy = div_with_rcp((float)(y0 + py) - a.p.ocy, a.p.ofy, rfy);
             const ColTerm ct = {a.p.r[0] * vx, a.p.r[3] * vx, a.p.r[6] * vx};
             const RowTerm rt = {a.p.r[1] * vy, a.p.r[4] * vy, a.p.r[7] * vy};
-            map_pixel_ex<MODE>(ta.p32, a.p, ct, rt, vx, vy, ax, ay);
+            map_pixel_ex<BASE>(ta.p32, a.p, ct, rt, vx, vy, ax, ay);
         }
 #ifdef VSTAB_DEV
         if (ta.ablate & 1) ax = (float)(x0 + px) * (32.0f * (float)a.sw / (float)a.dw), ay = (float)(y0 + py) * (32.0f * (float)a.sh / (float)a.dh);
@@ -164,6 +174,8 @@ __global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float rfx = rcp_refined(a.p.ofx), rfy = rcp_refined(a.p.ofy);
     constexpr int QB = CACHED ? 0 : QMAGIC_BITS;  // offset of the quantised-coordinate representation kept in registers
+    constexpr bool RS = MODE >= MAP_RS_CREATEMAP_CL;          // per-row rotation (BASELINE config 5)
+    constexpr int BASE = RS ? MODE - MAP_RS_CREATEMAP_CL : MODE;  // the projection pair
 
     // ---- tile of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), so every XCD
     // gets one contiguous band of tile rows in raster order: horizontally and vertically adjacent tiles then share an
@@ -249,10 +261,18 @@ __global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
         asm volatile("" : "+v"(vx) : : "memory");
         const ColTerm ct = {a.p.r[0] * vx, a.p.r[3] * vx, a.p.r[6] * vx};
         // row terms: lane l < R evaluates row l of this wave once; every lane then reads them from that lane
-        const float vy_l = div_with_rcp((float)(y0 + wave * R + (lane & (R - 1))) - a.p.ocy, a.p.ofy, rfy);
-        const float b0_l = a.p.r[1] * vy_l, b1_l = a.p.r[4] * vy_l, b2_l = a.p.r[7] * vy_l;
+        const int y_l = y0 + wave * R + (lane & (R - 1));
+        const float vy_l = div_with_rcp((float)y_l - a.p.ocy, a.p.ofy, rfy);
+        float m_l[9];  // the rotation of row y_l: the frame's, or interpolated towards the last row's (rolling shutter)
+#pragma unroll
+        for (int k = 0; k < 9; k++) m_l[k] = a.p.r[k];
+        if constexpr (RS) {
+            const float t = div_with_rcp((float)y_l, ta.rs_den, rcp_refined(ta.rs_den));
+#pragma unroll
+            for (int k = 0; k < 9; k++) m_l[k] = __builtin_fmaf(t, ta.rs_d[k], a.p.r[k]);
+        }
+        const float b0_l = m_l[1] * vy_l, b1_l = m_l[4] * vy_l, b2_l = m_l[7] * vy_l;
         const float icx32 = ta.p32.icx32, icy32 = ta.p32.icy32, ifx32 = ta.p32.ifx32, ify32 = ta.p32.ify32;
-        const float r02 = ta.p32.r02, r12 = ta.p32.r12, r22 = ta.p32.r22;
         auto bcast = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
 #ifdef VSTAB_DEV
         if (ta.ablate & 1) {
@@ -263,13 +283,22 @@ __global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
             }
         } else
 #endif
-        if constexpr (MODE == MAP_CREATEMAP_CL || MODE == MAP_FISH_TO_RECT) {
+        if constexpr (BASE == MAP_CREATEMAP_CL || BASE == MAP_FISH_TO_RECT) {
             // two rows at a time through the packed-fp32 pipe
 #pragma unroll
             for (int j = 0; j < R; j += 2) {
                 const f32x2 b0 = {bcast(b0_l, j), bcast(b0_l, j + 1)}, b1 = {bcast(b1_l, j), bcast(b1_l, j + 1)}, b2 = {bcast(b2_l, j), bcast(b2_l, j + 1)};
+                f32x2 a0 = splat2(ct.a0), a1 = splat2(ct.a1), a2 = splat2(ct.a2), r02 = splat2(a.p.r[2]), r12 = splat2(a.p.r[5]), r22 = splat2(a.p.r[8]);
+                if constexpr (RS) {  // every row has its own matrix: column products and third column per row
+                    a0 = (f32x2){bcast(m_l[0], j), bcast(m_l[0], j + 1)} * splat2(vx);
+                    a1 = (f32x2){bcast(m_l[3], j), bcast(m_l[3], j + 1)} * splat2(vx);
+                    a2 = (f32x2){bcast(m_l[6], j), bcast(m_l[6], j + 1)} * splat2(vx);
+                    r02 = (f32x2){bcast(m_l[2], j), bcast(m_l[2], j + 1)};
+                    r12 = (f32x2){bcast(m_l[5], j), bcast(m_l[5], j + 1)};
+                    r22 = (f32x2){bcast(m_l[8], j), bcast(m_l[8], j + 1)};
+                }
                 f32x2 ax, ay;
-                map_pixel32_x2<MODE == MAP_FISH_TO_RECT>(icx32, icy32, ifx32, ify32, r02, r12, r22, ct.a0, ct.a1, ct.a2, b0, b1, b2, ax, ay);
+                map_pixel32_x2<BASE == MAP_FISH_TO_RECT>(icx32, icy32, ifx32, ify32, r02, r12, r22, a0, a1, a2, b0, b1, b2, ax, ay);
                 ax += splat2(QMAGIC), ay += splat2(QMAGIC);
                 qxb[j] = __float_as_int(ax.x), qxb[j + 1] = __float_as_int(ax.y);
                 qyb[j] = __float_as_int(ay.x), qyb[j + 1] = __float_as_int(ay.y);
@@ -280,7 +309,7 @@ __global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
                 const float vy = bcast(vy_l, j);
                 const RowTerm rt = {bcast(b0_l, j), bcast(b1_l, j), bcast(b2_l, j)};
                 float ax, ay;
-                map_pixel_ex<MODE>(ta.p32, a.p, ct, rt, vx, vy, ax, ay);
+                map_pixel_ex<BASE>(ta.p32, a.p, ct, rt, vx, vy, ax, ay);
                 qxb[j] = __float_as_int(ax + QMAGIC), qyb[j] = __float_as_int(ay + QMAGIC);
             }
         }
@@ -451,12 +480,15 @@ extern "C" __attribute__((visibility("default"))) void vstab_dev_set_timing(void
 #endif
 
 vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int map_mode, bool nv12_out, bool src_vec_ok, bool dst_vec_ok,
-                               const void *qmap, int qpitch, hipStream_t st) {
+                               const void *qmap, int qpitch, const float *rot_bottom, hipStream_t st) {
     FusedArgs ta;
     ta.w = a;
     ta.p32 = {params[0] * 32.0f, params[1] * 32.0f, params[2] * 32.0f, params[3] * 32.0f, params[10], params[13], params[16]};
     ta.src_vec_ok = src_vec_ok, ta.dst_vec_ok = dst_vec_ok;
     ta.qmap = static_cast<const int2 *>(qmap), ta.qpitch = qpitch;
+    for (int k = 0; k < 9; k++) ta.rs_d[k] = rot_bottom ? rot_bottom[k] - params[8 + k] : 0.0f;  // fp32, as the oracle forms it
+    ta.rs_den = (float)(a.dh > 1 ? a.dh - 1 : 1);
+    if (rot_bottom) map_mode += MAP_RS_CREATEMAP_CL;  // modes 0 / 1 only (checked by the caller)
 #ifdef VSTAB_DEV
     ta.timing = g_dev_timing;
     static const int ablate = getenv("VSTAB_ABLATE") ? atoi(getenv("VSTAB_ABLATE")) : 0;
@@ -493,7 +525,9 @@ vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int ma
             case VSTAB_MAP_FISH_TO_RECT: VSTAB_LAUNCH_RF(MAP_FISH_TO_RECT, false); break;
             case VSTAB_MAP_FISH_TO_FISH: VSTAB_LAUNCH_RF(MAP_FISH_TO_FISH, false); break;
             case VSTAB_MAP_RECT_TO_RECT: VSTAB_LAUNCH_RF(MAP_RECT_TO_RECT, false); break;
-            default: VSTAB_LAUNCH_RF(MAP_RECT_TO_FISH, false); break;
+            case VSTAB_MAP_RECT_TO_FISH: VSTAB_LAUNCH_RF(MAP_RECT_TO_FISH, false); break;
+            case MAP_RS_CREATEMAP_CL: VSTAB_LAUNCH_RF(MAP_RS_CREATEMAP_CL, false); break;
+            default: VSTAB_LAUNCH_RF(MAP_RS_FISH_TO_RECT, false); break;
         }
     }
 #undef VSTAB_LAUNCH_RF
