@@ -14,7 +14,7 @@ def pmc(dirname):
                 acc[(r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 res = {}
-for d in ("pmc_fetch", "pmc_write", "cal_fetch", "cal_write"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "cal_fetch", "cal_write"):
     for (k, c), v in sorted(pmc(d).items()):
         lines.append(f"pmc[{d}]: {k:42s} {c:12s} mean_per_launch={v:.5g} (KB)")
         res[(d, k, c)] = v
