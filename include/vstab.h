@@ -252,7 +252,10 @@ typedef struct vstab_frame {
     int hold;          /* how many FURTHER pull callbacks these planes stay valid and unchanged for.  0 (default): only
                           until the next callback -- the library then waits for its copy of this frame to finish before
                           it calls upstream again (a decoder that recycles one output surface).  Ref-counted or pooled
-                          frames can say how deep the pool is and the wait disappears from the frame loop. */
+                          frames can say how deep the pool is and the wait disappears from the frame loop.  From
+                          smooth_radius + 14 on, the planes are not copied at all but read in place by the tracker and
+                          by the warp (which runs on vstab_config.stream): the callback at which the promise runs out
+                          first waits, on the host, for that warp to finish.  1 << 29 or more: never waited for. */
 } vstab_frame;
 
 /* Upstream FrameSource (FrameSource.hpp:14,20): return 0 and fill *out, VSTAB_EOF (-1) at end of

@@ -256,9 +256,12 @@ def test_pipeline_at_1080p_baseline_config(vs, cuda):
         assert np.array_equal(outs[i], oracle.warp_nv12(frames[i + 1], p, cw, ch)), i
 
 
-def _run_raw_device_source(vs, cuda, frames, hold, recycle, p010=False, **cfg_kw):
+def _run_raw_device_source(vs, cuda, frames, hold, recycle, p010=False, pool=0, lag=False, **cfg_kw):
     """Drive the raw C ABI with a device-frame source.  recycle: upstream owns ONE surface and overwrites it with
-    the next frame inside every pull callback (a decoder recycling its output surface)."""
+    the next frame inside every pull callback (a decoder recycling its output surface).  pool = P: upstream owns P
+    surfaces, hands them out round-robin and rewrites surface i % P (on its own stream) inside the callback of frame i
+    -- a decoder's frame pool, hold = P - 1.  lag: the caller's stream is kept busy before every pull so that the warps
+    run long after the host has moved on."""
     import ctypes
     import torch
     n = len(frames)
@@ -269,6 +272,9 @@ def _run_raw_device_source(vs, cuda, frames, hold, recycle, p010=False, **cfg_kw
     else:
         dev = [torch.from_numpy(f).to(cuda) for f in frames]
     surface = torch.empty_like(dev[0])
+    surfaces = [torch.empty_like(dev[0]) for _ in range(pool)]
+    side = torch.cuda.Stream() if pool else None
+    ballast = torch.randn(4096, 4096, device=cuda) if lag else None
     esz = 2 if p010 else 1
     state = {"i": 0, "loaded": -1}
 
@@ -282,6 +288,13 @@ def _run_raw_device_source(vs, cuda, frames, hold, recycle, p010=False, **cfg_kw
                 torch.cuda.synchronize()
                 state["loaded"] = i
             t = surface
+        elif pool:
+            t = surfaces[i % pool]
+            if state["loaded"] != i:
+                with torch.cuda.stream(side):               # upstream's own stream: nothing orders it behind the warps
+                    t.copy_(dev[i])
+                side.synchronize()
+                state["loaded"] = i
         else:
             t = dev[i]
         o = out.contents
@@ -302,11 +315,15 @@ def _run_raw_device_source(vs, cuda, frames, hold, recycle, p010=False, **cfg_kw
     outs = []
     while True:
         o = torch.empty((oh.value, ow.value, 3), dtype=torch.uint8, device=cuda)
+        if lag:
+            for _ in range(4):
+                ballast @ ballast                            # (cfg.stream is the null stream, torch's current one)
         st = vs.lib.vstab_pull_frame(h, o.data_ptr(), o.stride(0))
         if st == vs.EOF:
             break
         assert st == vs.OK, vs.lib.vstab_last_error()
-        outs.append(o.cpu().numpy())
+        outs.append(o if lag else o.cpu().numpy())
+    outs = [o.cpu().numpy() if lag else o for o in outs]
     vs.lib.vstab_destroy(h)
     return outs
 
@@ -326,6 +343,69 @@ def test_frame_lifetime_promise_hold(vs, cuda, clip):
     ref_stab, ref = run_product(vs, cuda, frames[:n], smooth_radius=3, tracking=0)
     outs = _run_raw_device_source(vs, cuda, frames[:n], 0, True, smooth_radius=3, tracking=0)
     assert len(outs) == len(ref) and all(np.array_equal(a, b) for a, b in zip(outs, ref))
+
+
+def test_finite_hold_borrowed_frames_wait_for_their_warp(vs, cuda, clip):
+    """Frames used in place under a FINITE promise (a decoder pool of 18 surfaces, hold = 17 = r + read-ahead + 6 at
+    r = 3): upstream counts pull callbacks, the warps run on the caller's stream.  With that stream kept ~20 ms behind
+    the host per pull, the pool rewrites surface i % 18 while the warp of frame i - 18 is still queued unless the
+    library waits for that warp before the callback that ends the promise."""
+    K, frames, _ = clip
+    n = 40
+    ref_stab, ref = run_product(vs, cuda, frames[:n], smooth_radius=3, seed=9)
+    for tracking in (1, 0):
+        if not tracking:
+            ref_stab, ref = run_product(vs, cuda, frames[:n], smooth_radius=3, tracking=0)
+        outs = _run_raw_device_source(vs, cuda, frames[:n], 17, False, pool=18, lag=True, smooth_radius=3, seed=9, tracking=tracking)
+        assert len(outs) == len(ref)
+        for i, (a, b) in enumerate(zip(outs, ref)):
+            assert np.array_equal(a, b), (tracking, i)
+
+
+def test_upstream_error_surfaces_after_the_frames_read_ahead(vs, cuda, clip):
+    """The reference meets an upstream error when it CONSUMES the failing frame (FrameSourceWarp.cpp:453-455): with
+    frames 0..19 good and frame 20 failing at r = 3, outputs 0..15 are emitted (output k needs frames up to k + r + 1)
+    and the pull of output 16 fails.  The read-ahead here calls upstream earlier; the error must not."""
+    import ctypes
+    import torch
+    K, frames, _ = clip
+    good = 20
+    dev_frames = [torch.from_numpy(f).to(cuda) for f in frames[:good]]
+    state = {"i": 0}
+
+    def fill(out, advance):
+        if state["i"] >= good:
+            return 7
+        f = dev_frames[state["i"]]
+        o = out.contents
+        o.y, o.uv = f.data_ptr(), f.data_ptr() + H * f.stride(0)
+        o.pitch_y = o.pitch_uv = f.stride(0)
+        o.width, o.height, o.mem, o.pts, o.hold = W, H, 0, 0, 1 << 30
+        if advance:
+            state["i"] += 1
+        return 0
+    pull = vs.PULL_FN(lambda u, o: fill(o, True))
+    peek = vs.PULL_FN(lambda u, o: fill(o, False))
+    src = vs.Source(pull, peek, None)
+    cfg = vs.default_config(smooth_radius=3, seed=9)
+    h = ctypes.c_void_p()
+    assert vs.lib.vstab_create(ctypes.byref(cfg), ctypes.byref(src), ctypes.byref(h)) == vs.OK
+    ow, oh = ctypes.c_int(), ctypes.c_int()
+    assert vs.lib.vstab_get_output_info(h, ctypes.byref(ow), ctypes.byref(oh), None, None) == vs.OK
+    ref_stab, ref = run_product(vs, cuda, frames[:good + 8], smooth_radius=3, seed=9)
+    emitted = 0
+    while True:
+        o = torch.empty((oh.value, ow.value, 3), dtype=torch.uint8, device=cuda)
+        st = vs.lib.vstab_pull_frame(h, o.data_ptr(), o.stride(0))
+        if st != vs.OK:
+            break
+        assert np.array_equal(o.cpu().numpy(), ref[emitted]), emitted
+        emitted += 1
+    assert st == vs.ERR_SOURCE and b"7" in vs.lib.vstab_last_error()
+    assert emitted == good - 3 - 1
+    o = torch.empty((oh.value, ow.value, 3), dtype=torch.uint8, device=cuda)
+    assert vs.lib.vstab_pull_frame(h, o.data_ptr(), o.stride(0)) == vs.ERR_SOURCE      # sticky
+    vs.lib.vstab_destroy(h)
 
 
 def test_cpp_adapter_example_runs(vs, cuda):

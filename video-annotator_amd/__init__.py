@@ -458,7 +458,9 @@ class Stabilizer:
     """vstab_handle wrapper.  `frames`: list of packed NV12 CUDA tensors (cycled by the C ring
     source for `total` pulls) or a Python iterable of such tensors (python callback source)."""
 
-    def __init__(self, frames, total=None, use_torch_stream=True, **cfg_kw):
+    def __init__(self, frames, total=None, use_torch_stream=True, hold=12, **cfg_kw):
+        """hold (iterable sources): vstab_frame.hold -- how many further pulls each tensor is kept alive and unchanged
+        for; from smooth_radius + 14 on the library uses the tensors in place instead of copying them."""
         import torch
         self._keep = []
         self._src = Source()
@@ -488,10 +490,10 @@ class Stabilizer:
                 yp, uvp, pitch, w, h = _planes(f)
                 o = out.contents
                 o.y, o.uv, o.pitch_y, o.pitch_uv, o.width, o.height, o.mem, o.pts = yp, uvp, pitch, pitch, w, h, 0, 0
-                o.hold = 12  # self._keep holds the last 16 tensors alive
+                o.hold = hold  # self._keep holds the last hold + 4 tensors alive
                 if advance:
                     self._keep.append(f)
-                    if len(self._keep) > 16:
+                    if len(self._keep) > hold + 4:
                         self._keep.pop(0)
                     state["next"] = None
                 return 0

@@ -595,6 +595,15 @@ struct vstab_handle {
         unsigned long serial;
         int hold;
     };
+    // A frame used in place whose vstab_frame.hold is finite: upstream counts pull callbacks, the warp that reads the
+    // planes runs on the caller's stream, so the callback at which the promise runs out first waits for that warp.
+    struct PendingBorrow {
+        unsigned long serial;
+        int hold;
+        bool warp_enqueued;
+        int warped;  // index into warp_events, -1 until an event is recorded behind the warp
+    };
+    static constexpr int HOLD_FOREVER = 1 << 29;  // promises at least this long are not tracked
     // Event operations are the expensive HIP calls here (measured on this runtime: hipEventRecord 4.4 us,
     // hipStreamWaitEvent 3.4 us, a kernel launch 2.4 us, hipEventQuery 0.08 us), so the frame loop records as
     // few as it can: one event per ingested frame (behind copy + pyramid), one event per WARP_EVENT_STRIDE
@@ -605,11 +614,24 @@ struct vstab_handle {
     int warp_event_next = 0;
     std::vector<int> uncovered;  // slots whose warp is enqueued but not yet followed by a recorded event
     vstab_status cover_warps() {  // record one event behind every warp enqueued so far
-        if (uncovered.empty()) return VSTAB_OK;
+        if (uncovered.empty() && !uncovered_borrows) return VSTAB_OK;
         const int e = warp_event_next++ % WARP_EVENT_POOL;
         VSTAB_HIP_TRY(hipEventRecord(warp_events[e], stream));
         for (int sl : uncovered) slots[sl].warped = e;
         uncovered.clear();
+        if (uncovered_borrows)
+            for (PendingBorrow &b : borrows)
+                if (b.warp_enqueued && b.warped < 0) b.warped = e;
+        uncovered_borrows = 0;
+        return VSTAB_OK;
+    }
+    // host-side wait for an event: a short query spin (0.08 us a query), then a blocking wait
+    static vstab_status host_wait(hipEvent_t ev) {
+        int spins = 0;
+        hipError_t q;
+        while ((q = hipEventQuery(ev)) == hipErrorNotReady && ++spins < 20000) __builtin_ia32_pause();
+        if (q == hipErrorNotReady) q = hipEventSynchronize(ev);
+        VSTAB_HIP_TRY(q);
         return VSTAB_OK;
     }
     // make stream `waiter` wait for `ev` unless the host can already see that it has completed
@@ -620,7 +642,19 @@ struct vstab_handle {
         VSTAB_HIP_TRY(hipStreamWaitEvent(waiter, ev, 0));
         return VSTAB_OK;
     }
+    // (the first frame of a stream is tracked from but never warped: its reads were over, host-visibly, when the
+    // second frame's LK results came back)
+    void forget_borrow(unsigned long serial) {
+        for (auto it = borrows.begin(); it != borrows.end(); ++it)
+            if (it->serial == serial) {
+                borrows.erase(it);
+                return;
+            }
+    }
     std::vector<PendingCopy> copies;  // device-frame copies upstream has not been promised to outlive yet
+    std::vector<PendingBorrow> borrows;  // frames used in place whose promise is finite (oldest first)
+    int uncovered_borrows = 0;           // of those, warps enqueued but not yet followed by a recorded event
+    int src_error = 0;                   // upstream's error code once it has failed (surfaces when the frames read ahead are used up)
     unsigned long ingest_serial = 0;
     long free_counter = 0;
     std::vector<Slot> slots;
@@ -842,14 +876,21 @@ static vstab_status prefetch_next(vstab_handle *H) {
                 continue;
             }
             const vstab_handle::Slot &S = H->slots[it->slot];
-            if (S.ingest_serial == it->serial) {  // (a re-used slot's newer copy was enqueued behind this one: also done)
-                int spins = 0;
-                hipError_t q;
-                while ((q = hipEventQuery(S.ingested)) == hipErrorNotReady && ++spins < 20000) __builtin_ia32_pause();
-                if (q == hipErrorNotReady) q = hipEventSynchronize(S.ingested);
-                VSTAB_HIP_TRY(q);
-            }
+            if (S.ingest_serial == it->serial)  // (a re-used slot's newer copy was enqueued behind this one: also done)
+                VSTAB_TRY(vstab_handle::host_wait(S.ingested));
             it = H->copies.erase(it);
+        }
+        // frames used in place: the warp reading them must be through before the callback that ends upstream's promise
+        for (auto it = H->borrows.begin(); it != H->borrows.end();) {
+            if (it->hold > 0) {
+                it->hold--, ++it;
+                continue;
+            }
+            if (!it->warp_enqueued)
+                return fail(VSTAB_ERR_INVALID, "vstab_frame.hold ran out while the frame was still waiting in the look-ahead window");
+            if (it->warped < 0) VSTAB_TRY(H->cover_warps());
+            VSTAB_TRY(vstab_handle::host_wait(H->warp_events[it->warped]));
+            it = H->borrows.erase(it);
         }
     }
     int rc;
@@ -861,7 +902,12 @@ static vstab_status prefetch_next(vstab_handle *H) {
         H->src_eof = true;
         return VSTAB_EOF;
     }
-    if (rc != 0) return fail(VSTAB_ERR_SOURCE, "upstream pull failed with " + std::to_string(rc));
+    if (rc != 0) {
+        // The reference meets this error only when it consumes the failing frame (FrameSourceWarp.cpp:453-455), after it
+        // has emitted every frame whose look-ahead window was complete; the frames read ahead here are still used.
+        H->src_eof = true, H->src_error = rc;
+        return VSTAB_EOF;
+    }
     const int slot = H->acquire_slot();
     if (slot < 0) return fail(VSTAB_ERR_NOMEM, "look-ahead ring exhausted");
     {
@@ -875,6 +921,7 @@ static vstab_status prefetch_next(vstab_handle *H) {
     // (frames promised to outlive a whole ring of pulls are not tracked: the ring slot itself is recycled sooner)
     if (f.mem == 0 && !H->slots[slot].borrowed && f.hold < (int)H->slots.size())
         H->copies.push_back({slot, H->ingest_serial, f.hold < 0 ? 0 : f.hold});
+    if (H->slots[slot].borrowed && f.hold < vstab_handle::HOLD_FOREVER) H->borrows.push_back({H->ingest_serial, f.hold, false, -1});
     H->slots[slot].queued = true;  // reserved from now on (released when its warp has been enqueued)
     const int pyr = (int)(H->prefetch_count % PYR_SETS);
     if (H->cfg.tracking) {
@@ -914,6 +961,7 @@ static vstab_status launch_tracking(vstab_handle *H) {
         if (H->last_key == -1) {
             H->last_key = H->frame_index;
             H->slots[slot].queued = false;  // the first frame is never emitted (:403-407)
+            H->forget_borrow(H->slots[slot].ingest_serial);
         } else {
             if (H->slots[slot].have_delta) H->measured = H->slots[slot].delta * H->measured;  // :441 with the sensor's rotation
             if (H->sg) H->sg->add(H->measured);
@@ -929,6 +977,7 @@ static vstab_status launch_tracking(vstab_handle *H) {
         }
         H->prof.key_frames++;
         H->slots[slot].queued = false;
+        H->forget_borrow(H->slots[slot].ingest_serial);
     } else {
         vstab_handle::Tracked &T = H->inflight;
         T = vstab_handle::Tracked();
@@ -1199,6 +1248,7 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
             continue;
         }
         if (!H->have_inflight && H->prefetched.empty() && H->src_eof) {
+            if (H->src_error) return fail(VSTAB_ERR_SOURCE, "upstream pull failed with " + std::to_string(H->src_error));
             // :456-461 pretend the camera kept its last orientation (once per call while draining)
             if (H->sg) H->sg->add(H->measured);
             break;
@@ -1295,6 +1345,13 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         S.warp_pending = true, S.warped = -1;
         H->uncovered.push_back(slot);  // the next copy into this slot waits for an event recorded behind this warp
         if ((int)H->uncovered.size() >= vstab_handle::WARP_EVENT_STRIDE) VSTAB_TRY(H->cover_warps());
+    } else if (!H->borrows.empty()) {
+        for (vstab_handle::PendingBorrow &b : H->borrows)
+            if (b.serial == S.ingest_serial) {
+                b.warp_enqueued = true;
+                if (++H->uncovered_borrows >= vstab_handle::WARP_EVENT_STRIDE) VSTAB_TRY(H->cover_warps());
+                break;
+            }
     }
     return st;
 }
