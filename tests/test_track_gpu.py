@@ -47,6 +47,52 @@ def test_good_features_bit_exact_indices(vs, cuda):
         assert len(got) > 10
 
 
+def test_fused_and_two_pass_detectors_agree_with_the_oracle(vs, cuda):
+    """The one-pass detector (k_corners_fused + k_filter_keys) and the two-pass one (k_min_eig + k_corner_candidates)
+    on ragged sizes around the 64 x 31 tile, pitched views, sizes smaller than one tile, and every corner kept
+    (max_corners large, min_distance 0 -> the full candidate list in order, i.e. the threshold and the 3x3 test)."""
+    cases = [(11, 64, 31), (12, 65, 32), (13, 63, 30), (14, 129, 63), (15, 200, 95), (16, 640, 360), (17, 9, 7), (18, 3, 3), (19, 70, 3), (20, 3, 70)]
+    for seed, w, h in cases:
+        g = synth.luma(seed, w, h) if min(w, h) > 30 else np.random.default_rng(seed).integers(0, 256, (h, w), dtype=np.uint8)
+        exp = oracle.good_features(g, 4000, 0.01, 0.0)
+        for det in (vs.DETECTOR_AUTO, vs.DETECTOR_TWO_PASS):
+            info = {}
+            got = vs.good_features(dev(g, cuda), 4000, 0.01, 0.0, detector=det, info=info)
+            assert np.array_equal(got, exp), (w, h, det, len(got), len(exp))
+            assert info["detector_used"] == (vs.DETECTOR_FUSED if det == vs.DETECTOR_AUTO else vs.DETECTOR_TWO_PASS)
+    # pitched view (row pitch != width, base not 4-byte aligned)
+    big = synth.luma(21, 400, 200)
+    view = dev(big, cuda)[3:150, 5:298]
+    exp = oracle.good_features(np.ascontiguousarray(big[3:150, 5:298]), 300, 0.01, 5.0)
+    assert np.array_equal(vs.good_features(view, 300, 0.01, 5.0, detector=vs.DETECTOR_AUTO), exp)
+    # other quality levels: the lower-bound filter inside the tile uses the same factor
+    g = synth.luma(22, 640, 360)
+    for q in (0.3, 0.001, 1e-6):
+        assert np.array_equal(vs.good_features(dev(g, cuda), 1000, q, 3.0, detector=vs.DETECTOR_AUTO), oracle.good_features(g, 1000, q, 3.0)), q
+
+
+def test_fused_detector_falls_back_when_a_tile_overflows(vs, cuda):
+    """A tile has 256 key slots.  White noise stays far below (~150 local maxima per 64 x 31 tile); a 2-px checkerboard
+    makes the eigenvalue map one plateau (every pixel a non-strict 3x3 maximum, 1984 per tile), so the two-pass
+    detector takes over -- same corners either way (ties: later raster position first)."""
+    rng = np.random.default_rng(5)
+    g = rng.integers(100, 110, (1080, 1920), dtype=np.uint8)
+    info = {}
+    got = vs.good_features(dev(g, cuda), detector=vs.DETECTOR_AUTO, info=info)
+    assert info["detector_used"] == vs.DETECTOR_FUSED
+    assert np.array_equal(got, oracle.good_features(g)) and len(got) == 200
+    h, w = 360, 640
+    g = ((np.add.outer(np.arange(h) // 2, np.arange(w) // 2) % 2) * 100 + 50).astype(np.uint8)
+    for mc, md in ((200, 30.0), (3000, 0.0)):
+        got = vs.good_features(dev(g, cuda), mc, 0.01, md, detector=vs.DETECTOR_AUTO, info=info)
+        assert info["detector_used"] == vs.DETECTOR_TWO_PASS
+        assert np.array_equal(got, oracle.good_features(g, mc, 0.01, md)) and len(got) == mc
+    # half the frame plateau, half texture: still one consistent answer
+    g[:, : w // 2] = synth.luma(3, w, h)[:, : w // 2]
+    got = vs.good_features(dev(g, cuda), 500, 0.01, 4.0, detector=vs.DETECTOR_AUTO, info=info)
+    assert np.array_equal(got, oracle.good_features(g, 500, 0.01, 4.0))
+
+
 def test_good_features_flat_image_has_no_corners(vs, cuda):
     g = np.full((60, 80), 93, np.uint8)
     assert len(vs.good_features(dev(g, cuda))) == 0 and len(oracle.good_features(g)) == 0

@@ -102,6 +102,7 @@ SIGNATURES = {
     "vstab_pyr_down": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp]),
     "vstab_min_eig": (_i, [_vp, _sz, _i, _i, _vp, _vp]),
     "vstab_good_features": (_i, [_vp, _sz, _i, _i, _i, _d, _d, _fp, _ip, _vp]),
+    "vstab_good_features_ex": (_i, [_vp, _sz, _i, _i, _i, _d, _d, _i, _fp, _ip, _ip, _vp]),
     "vstab_pyr_lk": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _fp, _u8p, _vp]),
     "vstab_estimate_rotation": (_i, [_fp, _fp, _i, _dp, _dp, _u64, _dp, _ip]),
     "vstab_sg_weights": (_i, [_i, _dp]),
@@ -385,12 +386,24 @@ def min_eig(gray):
     return out
 
 
-def good_features(gray, max_corners=200, quality=0.01, min_distance=30.0):
+DETECTOR_AUTO, DETECTOR_TWO_PASS, DETECTOR_FUSED = 0, 1, 2
+
+
+def good_features(gray, max_corners=200, quality=0.01, min_distance=30.0, detector=None, info=None):
+    """detector: None -> vstab_good_features; DETECTOR_AUTO / DETECTOR_TWO_PASS -> vstab_good_features_ex, and
+    info["detector_used"] (if a dict is given) says which kernel path produced the corners."""
     h, w = gray.shape
     xy = np.zeros((max_corners, 2), np.float32)
     n = _c.c_int()
-    _check(_L.vstab_good_features(gray.data_ptr(), gray.stride(0), w, h, max_corners, quality, min_distance, _fptr(xy),
-                                  _c.byref(n), _stream()), "vstab_good_features")
+    if detector is None:
+        _check(_L.vstab_good_features(gray.data_ptr(), gray.stride(0), w, h, max_corners, quality, min_distance, _fptr(xy),
+                                      _c.byref(n), _stream()), "vstab_good_features")
+    else:
+        used = _c.c_int()
+        _check(_L.vstab_good_features_ex(gray.data_ptr(), gray.stride(0), w, h, max_corners, quality, min_distance, detector, _fptr(xy),
+                                         _c.byref(n), _c.byref(used), _stream()), "vstab_good_features_ex")
+        if info is not None:
+            info["detector_used"] = used.value
     return xy[:n.value].copy()
 
 

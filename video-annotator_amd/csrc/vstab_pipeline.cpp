@@ -172,16 +172,31 @@ class Tracker {
                                std::vector<float> &xy, hipStream_t st, float *eig_out = nullptr) {
         xy.clear();
         float *eig = eig_out;
-        if (!eig) {
-            VSTAB_TRY(eig_.ensure(sizeof(float) * (size_t)w_ * h_));
-            eig = eig_.as<float>();
-        }
         int *max_bits = small_.as<int>();
         unsigned int *count = small_.as<unsigned int>() + 4;
         if (cap_ == 0) {
             cap_ = 1u << 18;
             VSTAB_TRY(keys_.ensure(sizeof(unsigned long long) * cap_));
         }
+        if (!eig_out && !two_pass_detector_) {
+            // one pass: eigenvalue, threshold and 3x3 maximum test fused, the eigenvalue map never stored
+            VSTAB_TRY(raw_keys_.ensure(corners_fused_scratch_bytes(w_, h_)));
+            VSTAB_TRY(launch_corners_fused(gray, pitch, w_, h_, quality, raw_keys_.p, keys_.as<unsigned long long>(), cap_, small_.as<unsigned int>(), st));
+            VSTAB_HIP_TRY(hipMemcpyAsync(hsmall_.p, count, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+            VSTAB_HIP_TRY(hipStreamSynchronize(st));
+            const unsigned int kept = hsmall_.as<unsigned int>()[0], dropped = hsmall_.as<unsigned int>()[1];
+            if (!dropped && kept <= cap_) {
+                if (kept == 0) return VSTAB_OK;
+                VSTAB_TRY(hkeys_.ensure(sizeof(unsigned long long) * kept));
+                VSTAB_HIP_TRY(hipMemcpyAsync(hkeys_.p, keys_.p, sizeof(unsigned long long) * kept, hipMemcpyDeviceToHost, st));
+                VSTAB_HIP_TRY(hipStreamSynchronize(st));
+                select_corners(hkeys_.as<unsigned long long>(), kept, max_corners, min_distance, xy);
+                return VSTAB_OK;
+            }
+            fused_overflows_++;  // a tile with more local maxima than it has slots (dense fine texture): the two-pass detector below
+        }
+        VSTAB_TRY(eig_.ensure(sizeof(float) * (size_t)w_ * h_));
+        if (!eig) eig = eig_.as<float>();
         VSTAB_TRY(launch_min_eig(gray, pitch, w_, h_, eig, max_bits, st));
         unsigned int n = 0;
         for (int attempt = 0; attempt < 2; attempt++) {
@@ -207,22 +222,22 @@ class Tracker {
     static constexpr unsigned int SPEC_CAP = 1u << 15;
     vstab_status spec_launch(const uint8_t *gray, size_t pitch, double quality, hipStream_t st, long tag) {
         spec_join();  // (a previous asynchronous selection still reading the pinned buffer: never in practice)
-        VSTAB_TRY(spec_eig_.ensure(sizeof(float) * (size_t)w_ * h_));
+        VSTAB_TRY(spec_raw_.ensure(corners_fused_scratch_bytes(w_, h_)));
         VSTAB_TRY(spec_keys_.ensure(sizeof(unsigned long long) * SPEC_CAP));
         VSTAB_TRY(spec_small_.ensure(256));
         VSTAB_TRY(spec_host_.ensure(64 + sizeof(unsigned long long) * SPEC_CAP));
         if (!spec_ev_) VSTAB_HIP_TRY(hipEventCreateWithFlags(&spec_ev_, hipEventDisableTiming));
-        int *max_bits = spec_small_.as<int>();
         unsigned int *count = spec_small_.as<unsigned int>() + 4;
-        VSTAB_TRY(launch_min_eig(gray, pitch, w_, h_, spec_eig_.as<float>(), max_bits, st));
-        VSTAB_TRY(launch_corner_candidates(spec_eig_.as<float>(), w_, h_, max_bits, quality, spec_keys_.as<unsigned long long>(), count, SPEC_CAP, st));
-        VSTAB_HIP_TRY(hipMemcpyAsync(spec_host_.p, count, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        VSTAB_TRY(launch_corners_fused(gray, pitch, w_, h_, quality, spec_raw_.p, spec_keys_.as<unsigned long long>(), SPEC_CAP, spec_small_.as<unsigned int>(), st));
+        VSTAB_HIP_TRY(hipMemcpyAsync(spec_host_.p, count, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));  // {keys kept, per-tile overflow}
         VSTAB_HIP_TRY(hipMemcpyAsync(spec_host_.as<uint8_t>() + 64, spec_keys_.p, sizeof(unsigned long long) * SPEC_CAP, hipMemcpyDeviceToHost, st));
         VSTAB_HIP_TRY(hipEventRecord(spec_ev_, st));
         spec_tag_ = tag;
         return VSTAB_OK;
     }
     long spec_tag() const { return spec_tag_; }
+    void set_two_pass_detector(bool on) { two_pass_detector_ = on; }
+    long fused_overflows() const { return fused_overflows_; }
     // Host half of the speculative detection on a helper thread: waits for the kernels' results and runs the
     // sort + minimum-distance pass, so that by the time the key frame comes its corners are simply there.
     void spec_select_async(int max_corners, double min_distance) {
@@ -251,8 +266,8 @@ class Tracker {
                     }
                     if (q == hipSuccess) {
                         const auto t1 = std::chrono::steady_clock::now();
-                        const unsigned int n = *spec_host_.as<unsigned int>();
-                        if (n <= SPEC_CAP) {
+                        const unsigned int n = spec_host_.as<unsigned int>()[0];
+                        if (n <= SPEC_CAP && spec_host_.as<unsigned int>()[1] == 0) {
                             select_corners(reinterpret_cast<unsigned long long *>(spec_host_.as<uint8_t>() + 64), n, spec_max_, spec_dist_, spec_xy_);
                             result = 2;
                         }
@@ -305,8 +320,8 @@ class Tracker {
         }
         spec_tag_ = -1;
         if (!spec_ev_ || hipEventSynchronize(spec_ev_) != hipSuccess) return false;
-        const unsigned int n = *spec_host_.as<unsigned int>();
-        if (n > SPEC_CAP) return false;
+        const unsigned int n = spec_host_.as<unsigned int>()[0];
+        if (n > SPEC_CAP || spec_host_.as<unsigned int>()[1] != 0) return false;
         select_corners(reinterpret_cast<unsigned long long *>(spec_host_.as<uint8_t>() + 64), n, max_corners, min_distance, xy);
         return true;
     }
@@ -447,7 +462,9 @@ class Tracker {
     int w_ = 0, h_ = 0, levels_ = 1;
     int lvl_w_[LK_MAX_LEVELS] = {0}, lvl_h_[LK_MAX_LEVELS] = {0};
     DevBuf pyr_[PYR_SETS][LK_MAX_LEVELS], eig_, keys_, small_;  // pyramid sets: previous, current, prefetched x2
-    DevBuf spec_eig_, spec_keys_, spec_small_;
+    DevBuf spec_raw_, spec_keys_, spec_small_, raw_keys_;
+    bool two_pass_detector_ = false;
+    long fused_overflows_ = 0;
     PinnedBuf spec_host_;
     hipEvent_t spec_ev_ = nullptr;
     long spec_tag_ = -1;
@@ -1489,17 +1506,25 @@ vstab_status vstab_min_eig(const void *gray, size_t pitch, int width, int height
     return VSTAB_OK;
 }
 
-vstab_status vstab_good_features(const void *gray, size_t pitch, int width, int height, int max_corners, double quality,
-                                 double min_distance, float *xy, int *count, void *stream) {
-    if (!gray || !xy || !count || width < 3 || height < 3 || pitch < (size_t)width || max_corners <= 0)
+vstab_status vstab_good_features_ex(const void *gray, size_t pitch, int width, int height, int max_corners, double quality,
+                                    double min_distance, int detector, float *xy, int *count, int *detector_used, void *stream) {
+    if (!gray || !xy || !count || width < 3 || height < 3 || pitch < (size_t)width || max_corners <= 0 ||
+        (detector != VSTAB_DETECTOR_AUTO && detector != VSTAB_DETECTOR_TWO_PASS))
         return fail(VSTAB_ERR_INVALID, "vstab_good_features: bad argument");
     Tracker t;
     VSTAB_TRY(t.init(width, height));
+    t.set_two_pass_detector(detector == VSTAB_DETECTOR_TWO_PASS);
     std::vector<float> out;
     VSTAB_TRY(t.good_features((const uint8_t *)gray, pitch, max_corners, quality, min_distance, out, static_cast<hipStream_t>(stream)));
     *count = (int)(out.size() / 2);
     std::memcpy(xy, out.data(), sizeof(float) * out.size());
+    if (detector_used) *detector_used = (detector == VSTAB_DETECTOR_TWO_PASS || t.fused_overflows()) ? VSTAB_DETECTOR_TWO_PASS : VSTAB_DETECTOR_FUSED;
     return VSTAB_OK;
+}
+
+vstab_status vstab_good_features(const void *gray, size_t pitch, int width, int height, int max_corners, double quality,
+                                 double min_distance, float *xy, int *count, void *stream) {
+    return vstab_good_features_ex(gray, pitch, width, height, max_corners, quality, min_distance, VSTAB_DETECTOR_AUTO, xy, count, nullptr, stream);
 }
 
 vstab_status vstab_pyr_lk(const void *prev, size_t pitch_prev, const void *next, size_t pitch_next, int width, int height,

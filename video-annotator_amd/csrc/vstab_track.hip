@@ -193,6 +193,219 @@ __global__ void __launch_bounds__(256) k_corner_candidates(const float *__restri
 }
 
 // =============================================================================================
+// k_corners_fused -- cornerMinEigenVal + the threshold / 3x3 non-maximum test of goodFeaturesToTrack in ONE pass
+// over the image: the eigenvalue map never goes to HBM.  A workgroup owns 64 x 31 output
+// pixels and evaluates the eigenvalue on the 66 x 33 pixels around them (the halo ring is recomputed, 1.11x), so the
+// 3x3 maximum test needs nothing from a neighbour.
+//   load    72 x 38 source bytes (REFLECT_101) -> LDS
+//   deriv   68 x 36 Sobel pairs: a thread owns 4 columns x 3 rows and shares the per-row terms D = I(x+1) - I(x-1),
+//           S = I(x) k0 + (I(x-1) + I(x+1)) k1 between them (5 source rows for 3 output rows); same float operation
+//           order as k_min_eig -> identical bits; floats -> LDS
+//   eig     a thread owns 3 x 3 pixels: the 5 x 5 products go to double once, the 3-row column sums are shared by
+//           the three pixels of a row (box sums of float products are exact in double in any order: <= 48
+//           significant bits), 33 instead of 81 double additions per pixel; eigenvalue in float as k_min_eig
+//   nms     eigenvalues -> LDS; 3x3 maximum with v_max3, threshold, wave-aggregated append of 64-bit keys
+// The threshold quality * max(frame) is not known until every tile is done, so a tile filters with a LOWER bound of
+// it -- quality * max(own tile, frame maximum published so far) -- and k_filter_keys applies the final threshold to
+// the survivors.  Which candidates survive the first filter depends on timing; the set that survives the second
+// does not (lower bound <= final threshold, monotone rounding), and the host sorts the keys.
+// =============================================================================================
+constexpr int CF_TW = 64, CF_TH = 31;                  // output pixels per tile
+constexpr int CF_EW = CF_TW + 2, CF_EH = CF_TH + 2;    // eigenvalue region: image (oy - 1 .., ox - 1 ..)
+constexpr int CF_DW = 68, CF_DH = 36, CF_DP = 68;      // derivative region: image (oy - 2 .., ox - 2 ..); 35 rows used
+constexpr int CF_SW = 72, CF_SH = 38;                  // source tile: image (oy - 3 .., ox - 4 ..)
+constexpr int CF_EP = 67;
+constexpr int CF_SLOTS = 256;                          // key slots per tile (a tile holds at most 1984 / 4 strict 3x3 maxima; fine noise reaches ~220)
+
+__device__ __forceinline__ float ubyte_f32(uint32_t v, int b) { return (float)((v >> (8 * b)) & 255u); }  // v_cvt_f32_ubyteN
+
+__global__ void __launch_bounds__(256) k_corners_fused(const uint8_t *__restrict__ src, size_t pitch, int w, int h, double quality,
+                                                       unsigned int *__restrict__ max_key, unsigned long long *__restrict__ slots,
+                                                       unsigned int *__restrict__ tile_counts, int vec_ok) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[CF_SH][CF_SW];
+    __shared__ __attribute__((aligned(16))) float dxs[CF_DH][CF_DP], dys[CF_DH][CF_DP];
+    __shared__ float es[CF_EH][CF_EP];
+    __shared__ int bmax;
+    __shared__ unsigned int bcount;
+    const int tid = threadIdx.x;
+    const int ox = blockIdx.x * CF_TW, oy = blockIdx.y * CF_TH;
+    // frame maximum published so far (biased bits): a lower bound of the final one.  Device-scope load: the atomics
+    // of other XCDs do not pass through this XCD's L2.
+    const unsigned int seen = __hip_atomic_load(max_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) bmax = INT_MIN, bcount = 0;
+    for (int e = tid; e < CF_SH * (CF_SW / 4); e += 256) {
+        const int ry = e / (CF_SW / 4), rd = e - ry * (CF_SW / 4);
+        reinterpret_cast<uint32_t *>(&tile[ry][0])[rd] = load4_reflect(src, (uint32_t)pitch, w, h, ox - 4 + 4 * rd, oy - 3 + ry, vec_ok != 0);
+    }
+    __syncthreads();
+    const float scale = (float)(1.0 / (4.0 * 3.0 * 255.0));
+    const float k0 = 2.0f * scale, k1 = scale;
+    if (tid < 17 * 12) {
+        const int g = tid / 17, c = tid - g * 17;
+        // derivative entry (r, q) <-> image (oy - 2 + r, ox - 2 + q) <-> tile[r + 1][q + 2]; this thread: q = 4c .. 4c+3, r = 3g .. 3g+2
+        float D[5][4], S[5][4];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const uint32_t *row = reinterpret_cast<const uint32_t *>(&tile[3 * g + j][4 * c]);
+            const uint32_t lo = row[0], hi = row[1];  // bytes 4c .. 4c+7; columns q-1 .. q+4 are bytes 1 .. 6
+            const float f[6] = {ubyte_f32(lo, 1), ubyte_f32(lo, 2), ubyte_f32(lo, 3), ubyte_f32(hi, 0), ubyte_f32(hi, 1), ubyte_f32(hi, 2)};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                D[j][i] = f[i + 2] - f[i];
+                S[j][i] = f[i + 1] * k0 + (f[i] + f[i + 2]) * k1;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int gy = oy - 2 + 3 * g + r;
+            const bool fy = gy < 0 || gy >= h;
+            float dx[4], dy[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int gx = ox - 2 + 4 * c + i;
+                dx[i] = (D[r][i] + D[r + 2][i]) * k1 + D[r + 1][i] * k0;
+                dy[i] = S[r + 2][i] - S[r][i];
+                if (gx < 0 || gx >= w) dx[i] = -dx[i];
+                if (fy) dy[i] = -dy[i];
+            }
+            *reinterpret_cast<float4 *>(&dxs[3 * g + r][4 * c]) = make_float4(dx[0], dx[1], dx[2], dx[3]);
+            *reinterpret_cast<float4 *>(&dys[3 * g + r][4 * c]) = make_float4(dy[0], dy[1], dy[2], dy[3]);
+        }
+    }
+    __syncthreads();
+    int best = INT_MIN;
+    if (tid < 22 * 11) {
+        const int by = tid / 22, bx = tid - by * 22;
+        // eigenvalue entry (ey, ex) <-> image (oy - 1 + ey, ox - 1 + ex) <-> derivative rows ey .. ey+2, columns ex .. ex+2
+        float a_[5][5], b_[5][5];
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+#pragma unroll
+            for (int i = 0; i < 5; i++) a_[j][i] = dxs[3 * by + j][3 * bx + i], b_[j][i] = dys[3 * by + j][3 * bx + i];
+        float sum[3][3][3];  // [quantity][row][column] box sums rounded to float
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            double col[3][5];
+#pragma unroll
+            for (int j = 0; j < 5; j++)
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    const float u = q == 2 ? b_[j][i] : a_[j][i], v = q == 0 ? a_[j][i] : b_[j][i];
+                    const double p = (double)(u * v);
+#pragma unroll
+                    for (int e = 0; e < 3; e++)
+                        if (j >= e && j <= e + 2) col[e][i] = j == e ? p : col[e][i] + p;
+                }
+#pragma unroll
+            for (int e = 0; e < 3; e++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) sum[q][e][i] = (float)((col[e][i] + col[e][i + 1]) + col[e][i + 2]);
+        }
+#pragma unroll
+        for (int e = 0; e < 3; e++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const float a = sum[0][e][i] * 0.5f, b = sum[1][e][i], cc = sum[2][e][i] * 0.5f;
+                const float ev = (a + cc) - sqrtf((a - cc) * (a - cc) + b * b);
+                es[3 * by + e][3 * bx + i] = ev;
+                const int gx = ox - 1 + 3 * bx + i, gy = oy - 1 + 3 * by + e;
+                if (gx >= 0 && gx < w && gy >= 0 && gy < h) best = max(best, __float_as_int(ev));
+            }
+    }
+    // tile maximum (same int-bit order as k_min_eig)
+    best = max(best, __builtin_amdgcn_update_dpp(INT_MIN, best, 0x111, 0xf, 0xf, false));
+    best = max(best, __builtin_amdgcn_update_dpp(INT_MIN, best, 0x112, 0xf, 0xf, false));
+    best = max(best, __builtin_amdgcn_update_dpp(INT_MIN, best, 0x114, 0xf, 0xf, false));
+    best = max(best, __builtin_amdgcn_update_dpp(INT_MIN, best, 0x118, 0xf, 0xf, false));
+    best = max(best, __builtin_amdgcn_update_dpp(INT_MIN, best, 0x142, 0xa, 0xf, false));
+    best = max(best, __builtin_amdgcn_update_dpp(INT_MIN, best, 0x143, 0xc, 0xf, false));
+    if ((tid & 63) == 63) atomicMax(&bmax, best);
+    __syncthreads();
+    const int tile_max = bmax;
+    // Every workgroup hitting one address costs ~11 ns apiece on this part (all XCDs meet at the memory side):
+    // only a tile that raises the maximum it saw publishes.
+    if (tid == 0 && ((unsigned int)tile_max ^ 0x80000000u) > seen) atomicMax(max_key, (unsigned int)tile_max ^ 0x80000000u);
+    // lower bound of the frame threshold; only meaningful for a non-negative maximum (float order == int order)
+    const int lb_bits = max(tile_max, (int)(seen ^ 0x80000000u));
+    const float thr_lb = lb_bits >= 0 ? (float)((double)__int_as_float(lb_bits) * quality) : -__builtin_inff();
+    // 3x3 maximum test: lane = column, a wave walks 8 rows with a rolling row-maximum
+    const int tx = tid & 63, r0 = (tid >> 6) * 8;
+    const int x = ox + tx;
+    unsigned long long *my_slots = slots + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * CF_SLOTS;
+    float rm0 = fmaxf(fmaxf(es[r0][tx], es[r0][tx + 1]), es[r0][tx + 2]);
+    float c1 = es[r0 + 1][tx + 1];
+    float rm1 = fmaxf(fmaxf(es[r0 + 1][tx], c1), es[r0 + 1][tx + 2]);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int ty = r0 + r;
+        if (ty >= CF_TH) break;  // wave-uniform (the last wave owns 7 rows)
+        const float c2 = es[ty + 2][tx + 1];
+        const float rm2 = fmaxf(fmaxf(es[ty + 2][tx], c2), es[ty + 2][tx + 2]);
+        const float m = fmaxf(fmaxf(rm0, rm1), rm2);
+        const int y = oy + ty;
+        const bool cand = x >= 1 && y >= 1 && x < w - 1 && y < h - 1 && c1 > thr_lb && c1 == m;
+        const unsigned long long ballot = __ballot(cand);
+        if (ballot) {
+            unsigned int base = 0;
+            if (tx == 0) base = atomicAdd(&bcount, (unsigned int)__popcll(ballot));  // LDS
+            base = __builtin_amdgcn_readfirstlane(base);
+            const unsigned int slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0));
+            if (cand && slot < CF_SLOTS) my_slots[slot] = ((unsigned long long)__float_as_uint(c1) << 32) | (unsigned int)(y * w + x);
+        }
+        rm0 = rm1, rm1 = rm2, c1 = c2;
+    }
+    __syncthreads();
+    if (tid == 0) tile_counts[blockIdx.y * gridDim.x + blockIdx.x] = bcount;
+}
+
+// k_filter_keys -- the final threshold quality * max(frame) over the survivors of k_corners_fused.  A workgroup
+// gathers the keys of FK_TILES tiles in LDS and appends them with ONE global atomic.
+// counts[0] = keys kept (may exceed cap_out), counts[1] = largest survivor count of a tile (> CF_SLOTS: some were dropped);
+// in both cases the caller re-runs with the two-pass detector.
+constexpr int FK_TILES = 16;
+__global__ void __launch_bounds__(256) k_filter_keys(const unsigned long long *__restrict__ slots, const unsigned int *__restrict__ tile_counts, int n_tiles,
+                                                     const unsigned int *__restrict__ max_key, double quality,
+                                                     unsigned long long *__restrict__ out, unsigned int *__restrict__ counts, unsigned int cap_out) {
+    __shared__ unsigned long long kept[FK_TILES * CF_SLOTS];
+    __shared__ unsigned int n_kept, base, worst;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) n_kept = 0, worst = 0;
+    __syncthreads();
+    const float thr = (float)((double)__int_as_float((int)(*max_key ^ 0x80000000u)) * quality);
+    for (int k = 0; k < FK_TILES / 4; k++) {
+        const int t = blockIdx.x * FK_TILES + wave * (FK_TILES / 4) + k;
+        if (t >= n_tiles) break;
+        const unsigned int n_raw = tile_counts[t];
+        if (lane == 0 && n_raw > CF_SLOTS) atomicMax(&worst, n_raw);
+        const unsigned int n = min(n_raw, (unsigned int)CF_SLOTS);
+        for (unsigned int i = lane; i < ((n + 63) & ~63u); i += 64) {
+            unsigned long long key = 0;
+            bool keep = false;
+            if (i < n) {
+                key = slots[(size_t)t * CF_SLOTS + i];
+                keep = __uint_as_float((unsigned int)(key >> 32)) > thr;
+            }
+            const unsigned long long ballot = __ballot(keep);
+            if (ballot) {
+                unsigned int b = 0;
+                if (lane == 0) b = atomicAdd(&n_kept, (unsigned int)__popcll(ballot));
+                b = __builtin_amdgcn_readfirstlane(b);
+                if (keep) kept[b + __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0))] = key;
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned int n = n_kept;
+    if (tid == 0) {
+        if (n) base = atomicAdd(&counts[0], n);
+        if (worst) atomicMax(&counts[1], worst);
+    }
+    __syncthreads();
+    for (unsigned int i = tid; i < n; i += 256)
+        if (base + i < cap_out) out[base + i] = kept[i];
+}
+
+// =============================================================================================
 // k_lk_track -- LKTrackerInvoker for all pyramid levels, one wavefront per
 // feature.  Window 21x21 = 441 pixels -> 7 per lane.  Per level: the 24x24 neighbourhood of the
 // previous image goes to LDS (REFLECT_101 padding), Scharr derivatives are computed on the fly
@@ -541,6 +754,27 @@ vstab_status launch_corner_candidates(const float *eig, int w, int h, const int 
     VSTAB_HIP_TRY(hipMemsetAsync(count, 0, sizeof(unsigned int), s));
     dim3 grid(div_up(w, 64), div_up(h, 4));
     hipLaunchKernelGGL(k_corner_candidates, grid, dim3(64, 4), 0, s, eig, w, h, max_bits, quality, keys, count, cap);
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+// Fused detector.  small: 8 dwords of device memory {biased maximum bits, -, -, -, keys kept, largest per-tile overflow,
+// -, -}; scratch: corners_fused_scratch_bytes(w, h).  On return (stream order) keys holds min(small[4], cap) keys; the
+// result is complete iff small[5] == 0 and small[4] <= cap.
+size_t corners_fused_scratch_bytes(int w, int h) {
+    const size_t tiles = (size_t)div_up(w, CF_TW) * div_up(h, CF_TH);
+    return tiles * CF_SLOTS * sizeof(unsigned long long) + tiles * sizeof(unsigned int);
+}
+
+vstab_status launch_corners_fused(const uint8_t *src, size_t pitch, int w, int h, double quality, void *scratch, unsigned long long *keys,
+                                  unsigned int cap, unsigned int *small, hipStream_t s) {
+    VSTAB_HIP_TRY(hipMemsetAsync(small, 0, 8 * sizeof(unsigned int), s));
+    const int vec_ok = reinterpret_cast<uintptr_t>(src) % 4 == 0 && pitch % 4 == 0;
+    const int tiles_x = div_up(w, CF_TW), tiles_y = div_up(h, CF_TH), tiles = tiles_x * tiles_y;
+    unsigned long long *slots = static_cast<unsigned long long *>(scratch);
+    unsigned int *tile_counts = reinterpret_cast<unsigned int *>(slots + (size_t)tiles * CF_SLOTS);
+    hipLaunchKernelGGL(k_corners_fused, dim3(tiles_x, tiles_y), dim3(256), 0, s, src, pitch, w, h, quality, small, slots, tile_counts, vec_ok);
+    hipLaunchKernelGGL(k_filter_keys, dim3(div_up(tiles, FK_TILES)), dim3(256), 0, s, slots, tile_counts, tiles, small, quality, keys, small + 4, cap);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }

@@ -32,6 +32,9 @@ vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, 
 vstab_status launch_min_eig(const uint8_t *src, size_t pitch, int w, int h, float *eig, int *max_bits, hipStream_t s);
 vstab_status launch_corner_candidates(const float *eig, int w, int h, const int *max_bits, double quality,
                                       unsigned long long *keys, unsigned int *count, unsigned int cap, hipStream_t s);
+size_t corners_fused_scratch_bytes(int w, int h);
+vstab_status launch_corners_fused(const uint8_t *src, size_t pitch, int w, int h, double quality, void *scratch, unsigned long long *keys,
+                                  unsigned int cap, unsigned int *small, hipStream_t s);
 // host_records (may be NULL): n 16-byte records {x, seq, y, seq << 2 | status} in mapped host memory, written instead
 // of next_pts / status so the host can poll for completion without a stream synchronisation
 // chain_in (may be NULL): the device records of the previous frame's launch; slot f then starts from the point that
