@@ -2,6 +2,7 @@
 // response + non-maximum suppression + compaction, pyramidal Lucas-Kanade tracker.
 // Replaces the OpenCV calls at FrameSourceWarp.cpp:230 (goodFeaturesToTrack) and :252
 // (calcOpticalFlowPyrLK).  Compiled with -ffp-contract=off: float results are bit-reproducible.
+#include <algorithm>
 #include <climits>
 
 #include "vstab_internal.hpp"
@@ -24,6 +25,18 @@ __device__ __forceinline__ uint32_t load4_reflect_row(const uint8_t *__restrict_
     return v;
 }
 
+// The same when every column is within one reflection of the row (-n < column < 2n - 1): no loops, four independent loads.
+__device__ __forceinline__ uint32_t load4_reflect_row_near(const uint8_t *__restrict__ row, int w, int gx, bool vec_ok) {
+    if (vec_ok && gx >= 0 && gx + 4 <= w) return *reinterpret_cast<const uint32_t *>(row + gx);
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = abs(gx + i);
+        v |= (uint32_t)row[min(c, 2 * w - 2 - c)] << (8 * i);
+    }
+    return v;
+}
+
 // One dword of a REFLECT_101-padded u8 image at (gx .. gx+3, gy), gx a multiple of 4.  Dwords that lie
 // inside the row are one aligned load (also on border tiles); only dwords straddling the left /
 // right image edge are assembled from bytes.
@@ -41,42 +54,76 @@ __device__ __forceinline__ uint32_t load4_reflect(const uint8_t *__restrict__ sr
 // k_pyr_down -- cv::pyrDown as used by buildOpticalFlowPyramid: 5x5 binomial
 // [1 4 6 4 1]^2, integer, (sum + 128) >> 8, REFLECT_101, dst = ((w+1)/2, (h+1)/2).
 // Register-only: one thread produces 4 adjacent outputs of one row from five 16-byte row segments
-// (aligned dword loads; the 2.5x overlap between vertically adjacent threads is served by L1/L2),
-// vertical pass first (11 columns), then the horizontal pass, one dword store.  No LDS, no barriers:
-// the kernel is a pure stream and overlaps well with the LK kernel of the previous frame.
+// (aligned dword loads; the overlap between neighbouring threads is served by L1/L2).  The 25 taps of
+// an output are accumulated with v_dot4_u32_u8 straight on the packed source dwords: the weight
+// dword of row j holds k_j * (1 4 6 4 1) at the byte positions of the taps (<= 36, a byte), two
+// dot products per output and row, so no byte is ever unpacked.  One dword store.  No LDS, no
+// barriers: the kernel is a pure stream and overlaps with the LK kernel of the previous frame.
 // =============================================================================================
-__device__ __forceinline__ uint32_t pd_byte(const uint32_t (&d)[4], int b) { return (d[b >> 2] >> ((b & 3) * 8)) & 255u; }
+__device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
 
-__global__ void __launch_bounds__(256) k_pyr_down(const uint8_t *__restrict__ src, size_t spitch, int sw, int sh,
-                                                  uint8_t *__restrict__ dst, size_t dpitch, int dw, int dh, int vec_ok) {
-    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x0 >= dw || y >= dh) return;
-    const int sx0 = 2 * x0 - 4;  // the 16 bytes [sx0, sx0+16) hold the taps of outputs x0..x0+3 at offsets 2..12
-    uint32_t v[11];  // vertical pass result for tile bytes 2..12
-#pragma unroll
-    for (int b = 0; b < 11; b++) v[b] = 0;
-    const uint32_t kk[5] = {1, 4, 6, 4, 1};
+// outputs x0 .. x0+3 of row y.  EDGE = false: the 16-byte window lies inside the row and everything is dword aligned.
+// NEAR: sw >= 16 and sh >= 4, so that every tap is within one reflection of the image.
+template <bool EDGE, bool NEAR>
+__device__ __forceinline__ void pyr_down_group(const uint8_t *__restrict__ src, uint32_t spitch, int sw, int sh, uint8_t *__restrict__ dst, size_t dpitch,
+                                               int dw, int x0, int y, bool vec_ok) {
+    const int sx0 = 2 * x0 - 4;  // the 16 bytes [sx0, sx0+16) hold the taps of outputs x0..x0+3: output c uses bytes 2c+2 .. 2c+6
+    uint32_t acc[4] = {128u, 128u, 128u, 128u};
 #pragma unroll
     for (int j = 0; j < 5; j++) {
-        const uint32_t roff = (uint32_t)reflect101(2 * y - 2 + j, sh) * (uint32_t)spitch;
+        const uint32_t k = j == 0 || j == 4 ? 1u : j == 2 ? 6u : 4u;
+        const int ry = 2 * y - 2 + j;
+        const uint8_t *row = src + (uint32_t)(NEAR ? min(abs(ry), 2 * sh - 2 - abs(ry)) : reflect101(ry, sh)) * spitch;
         uint32_t d[4];
+        if (!EDGE) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(row + sx0);
+            d[0] = p[0], d[1] = p[1], d[2] = p[2], d[3] = p[3];
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; q++)  // per-dword edge handling: only dwords straddling an image edge take the byte path
-            d[q] = load4_reflect_row(src + roff, sw, sx0 + 4 * q, vec_ok != 0);
-#pragma unroll
-        for (int b = 0; b < 11; b++) v[b] += kk[j] * pd_byte(d, b + 2);
+            for (int q = 0; q < 4; q++)  // only dwords straddling an image edge take the byte path
+                d[q] = NEAR ? load4_reflect_row_near(row, sw, sx0 + 4 * q, vec_ok) : load4_reflect_row(row, sw, sx0 + 4 * q, vec_ok);
+        }
+        // weight dwords (byte 0 = lowest address): taps 1 4 | 6 4 1 split over two dwords, or 1 4 6 4 | 1
+        const uint32_t w_hi2 = (k << 16) | (4 * k << 24);          // (0, 0, k, 4k)
+        const uint32_t w_lo3 = 6 * k | (4 * k << 8) | (k << 16);   // (6k, 4k, k, 0)
+        const uint32_t w_all = k | (4 * k << 8) | (6 * k << 16) | (4 * k << 24);  // (k, 4k, 6k, 4k)
+        acc[0] = udot4(d[1], w_lo3, udot4(d[0], w_hi2, acc[0]));
+        acc[1] = udot4(d[2], k, udot4(d[1], w_all, acc[1]));
+        acc[2] = udot4(d[2], w_lo3, udot4(d[1], w_hi2, acc[2]));
+        acc[3] = udot4(d[3], k, udot4(d[2], w_all, acc[3]));
     }
-    uint32_t r[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const uint32_t s = v[2 * c] + 4 * v[2 * c + 1] + 6 * v[2 * c + 2] + 4 * v[2 * c + 3] + v[2 * c + 4];
-        r[c] = (s + 128) >> 8;
-    }
+    // result byte c = bits 8..15 of acc[c] (sum + 128 <= 255 * 256 + 128 < 2^16)
     uint8_t *o = dst + (size_t)y * dpitch + x0;
-    if (vec_ok && x0 + 4 <= dw) {
-        *reinterpret_cast<uint32_t *>(o) = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+    if (!EDGE) {
+        const uint32_t p01 = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0501u), p23 = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0501u);
+        *reinterpret_cast<uint32_t *>(o) = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
     } else {
-        for (int c = 0; c < 4 && x0 + c < dw; c++) o[c] = (uint8_t)r[c];
+        for (int c = 0; c < 4 && x0 + c < dw; c++) o[c] = (uint8_t)(acc[c] >> 8);
+    }
+}
+
+// Groups of 4 outputs [g_lo, g_hi) of every row are interior (64 groups x 4 rows per workgroup); the remaining groups --
+// the first of a row, the last one to three, or all of them for an unaligned or tiny image -- are gathered in workgroups
+// of their own, so that no wavefront of the bulk ever runs the byte path.  Those come first in the grid: they are the
+// slow ones.
+__global__ void __launch_bounds__(256) k_pyr_down(const uint8_t *__restrict__ src, size_t spitch, int sw, int sh,
+                                                  uint8_t *__restrict__ dst, size_t dpitch, int dw, int dh, int vec_ok, int g_lo, int g_hi,
+                                                  int nbx, int nb_edge, int n_groups, int near) {
+    if ((int)blockIdx.x >= nb_edge) {
+        const int b = blockIdx.x - nb_edge, by = b / nbx, bx = b - by * nbx;
+        const int g = g_lo + bx * 64 + (threadIdx.x & 63), y = by * 4 + (threadIdx.x >> 6);
+        if (g >= g_hi || y >= dh) return;
+        pyr_down_group<false, true>(src, (uint32_t)spitch, sw, sh, dst, dpitch, dw, 4 * g, y, true);
+    } else {
+        const int n_edge = n_groups - (g_hi - g_lo);  // edge groups per row
+        const int e = blockIdx.x * 256 + threadIdx.x;
+        const int y = e / n_edge, i = e - y * n_edge;
+        if (y >= dh) return;
+        const int g = i < g_lo ? i : g_hi + (i - g_lo);
+        if (near)
+            pyr_down_group<true, true>(src, (uint32_t)spitch, sw, sh, dst, dpitch, dw, 4 * g, y, vec_ok != 0);
+        else
+            pyr_down_group<true, false>(src, (uint32_t)spitch, sw, sh, dst, dpitch, dw, 4 * g, y, vec_ok != 0);
     }
 }
 
@@ -211,8 +258,8 @@ __global__ void __launch_bounds__(256) k_corner_candidates(const float *__restri
 // does not (lower bound <= final threshold, monotone rounding), and the host sorts the keys.
 // =============================================================================================
 constexpr int CF_TW = 64, CF_TH = 31;                  // output pixels per tile
-constexpr int CF_EW = CF_TW + 2, CF_EH = CF_TH + 2;    // eigenvalue region: image (oy - 1 .., ox - 1 ..)
-constexpr int CF_DW = 68, CF_DH = 36, CF_DP = 68;      // derivative region: image (oy - 2 .., ox - 2 ..); 35 rows used
+constexpr int CF_EH = CF_TH + 2;                      // eigenvalue region: 66 x 33, image (oy - 1 .., ox - 1 ..)
+constexpr int CF_DH = 36, CF_DP = 68;                 // derivative region: 68 x 36, image (oy - 2 .., ox - 2 ..); 35 rows used
 constexpr int CF_SW = 72, CF_SH = 38;                  // source tile: image (oy - 3 .., ox - 4 ..)
 constexpr int CF_EP = 67;
 constexpr int CF_SLOTS = 256;                          // key slots per tile (a tile holds at most 1984 / 4 strict 3x3 maxima; fine noise reaches ~220)
@@ -732,8 +779,14 @@ vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, 
                              hipStream_t s) {
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
     const int vec_ok = reinterpret_cast<uintptr_t>(src) % 4 == 0 && spitch % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && dpitch % 4 == 0;
-    dim3 grid(div_up(dw, 256), div_up(dh, 4));  // 64 threads x 4 outputs wide, 4 rows per workgroup
-    hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, src, spitch, sw, sh, dst, dpitch, dw, dh, vec_ok);
+    // group g = outputs 4g .. 4g+3 reads source bytes [8g - 4, 8g + 12): interior iff g >= 1, 8g + 12 <= sw and 4g + 4 <= dw
+    const int n_groups = div_up(dw, 4);
+    const int near = sw >= 16 && sh >= 4;
+    const int g_lo = 1, g_hi = vec_ok && near ? std::max(g_lo, std::min(sw >= 12 ? (sw - 12) / 8 + 1 : 0, dw / 4)) : g_lo;
+    const int nbx = div_up(g_hi - g_lo, 64), nb_int = nbx * div_up(dh, 4);
+    const int nb_edge = div_up(dh * (n_groups - (g_hi - g_lo)), 256);
+    hipLaunchKernelGGL(k_pyr_down, dim3(nb_edge + nb_int), dim3(256), 0, s, src, spitch, sw, sh, dst, dpitch, dw, dh, vec_ok, g_lo, g_hi, nbx, nb_edge, n_groups,
+                       near);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }
