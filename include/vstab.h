@@ -179,10 +179,10 @@ VSTAB_API vstab_status vstab_good_features(const void *gray, size_t pitch, int w
                                            float *xy, int *count, void *stream);
 
 /* The same with a choice of detector.  AUTO: one fused pass (eigenvalue, threshold and 3x3 maximum test in one kernel,
- * the eigenvalue map is never stored); a frame in which some 64 x 31 tile has more than 256 local maxima above the
- * threshold (eigenvalue plateaus of a periodic pattern; white noise reaches ~150) falls back to TWO_PASS, which stores
- * the map (vstab_min_eig) and scans it.  Both give the same
- * corners.  *detector_used (may be NULL) receives VSTAB_DETECTOR_FUSED or VSTAB_DETECTOR_TWO_PASS. */
+ * the eigenvalue map is never stored); a frame with more than 2^18 corners above the threshold (an eigenvalue plateau
+ * over most of a large frame) falls back to TWO_PASS, which stores the map (vstab_min_eig), scans it and grows its key
+ * buffer as needed.  Both give the same corners.  *detector_used (may be NULL) receives VSTAB_DETECTOR_FUSED or
+ * VSTAB_DETECTOR_TWO_PASS. */
 enum { VSTAB_DETECTOR_AUTO = 0, VSTAB_DETECTOR_TWO_PASS = 1, VSTAB_DETECTOR_FUSED = 2 };
 VSTAB_API vstab_status vstab_good_features_ex(const void *gray, size_t pitch, int width, int height,
                                               int max_corners, double quality, double min_distance, int detector,

@@ -71,26 +71,38 @@ def test_fused_and_two_pass_detectors_agree_with_the_oracle(vs, cuda):
         assert np.array_equal(vs.good_features(dev(g, cuda), 1000, q, 3.0, detector=vs.DETECTOR_AUTO), oracle.good_features(g, 1000, q, 3.0)), q
 
 
-def test_fused_detector_falls_back_when_a_tile_overflows(vs, cuda):
-    """A tile has 256 key slots.  White noise stays far below (~150 local maxima per 64 x 31 tile); a 2-px checkerboard
-    makes the eigenvalue map one plateau (every pixel a non-strict 3x3 maximum, 1984 per tile), so the two-pass
-    detector takes over -- same corners either way (ties: later raster position first)."""
+def test_fused_detector_on_eigenvalue_plateaus(vs, cuda):
+    """A tile has 256 key slots.  White noise stays far below (~150 local maxima per 64 x 31 tile).  A 2-px checkerboard
+    makes the eigenvalue map one plateau (every pixel a non-strict 3x3 maximum, 1984 per tile): such tiles hand over a
+    dense map instead of keys, same corners (ties: later raster position first).  Only when more corners pass the FINAL
+    threshold than the key buffer holds (2^18) does the two-pass detector take over, which grows its buffer."""
     rng = np.random.default_rng(5)
     g = rng.integers(100, 110, (1080, 1920), dtype=np.uint8)
     info = {}
     got = vs.good_features(dev(g, cuda), detector=vs.DETECTOR_AUTO, info=info)
     assert info["detector_used"] == vs.DETECTOR_FUSED
     assert np.array_equal(got, oracle.good_features(g)) and len(got) == 200
+
+    def checker(w, h):
+        return ((np.add.outer(np.arange(h) // 2, np.arange(w) // 2) % 2) * 100 + 50).astype(np.uint8)
     h, w = 360, 640
-    g = ((np.add.outer(np.arange(h) // 2, np.arange(w) // 2) % 2) * 100 + 50).astype(np.uint8)
+    g = checker(w, h)
     for mc, md in ((200, 30.0), (3000, 0.0)):
         got = vs.good_features(dev(g, cuda), mc, 0.01, md, detector=vs.DETECTOR_AUTO, info=info)
-        assert info["detector_used"] == vs.DETECTOR_TWO_PASS
+        assert info["detector_used"] == vs.DETECTOR_FUSED
         assert np.array_equal(got, oracle.good_features(g, mc, 0.01, md)) and len(got) == mc
-    # half the frame plateau, half texture: still one consistent answer
+    # half the frame plateau, half texture; ragged size: plateau tiles cut by the right and bottom image edges
     g[:, : w // 2] = synth.luma(3, w, h)[:, : w // 2]
     got = vs.good_features(dev(g, cuda), 500, 0.01, 4.0, detector=vs.DETECTOR_AUTO, info=info)
     assert np.array_equal(got, oracle.good_features(g, 500, 0.01, 4.0))
+    g = checker(333, 181)
+    got = vs.good_features(dev(g, cuda), 2000, 0.01, 0.0, detector=vs.DETECTOR_AUTO, info=info)
+    assert info["detector_used"] == vs.DETECTOR_FUSED and np.array_equal(got, oracle.good_features(g, 2000, 0.01, 0.0))
+    # 1280 x 720 of plateau: ~9e5 corners above the threshold
+    g = checker(1280, 720)
+    got = vs.good_features(dev(g, cuda), 300, 0.01, 20.0, detector=vs.DETECTOR_AUTO, info=info)
+    assert info["detector_used"] == vs.DETECTOR_TWO_PASS
+    assert np.array_equal(got, oracle.good_features(g, 300, 0.01, 20.0)) and len(got) == 300
 
 
 def test_good_features_flat_image_has_no_corners(vs, cuda):

@@ -184,8 +184,8 @@ class Tracker {
             VSTAB_TRY(launch_corners_fused(gray, pitch, w_, h_, quality, raw_keys_.p, keys_.as<unsigned long long>(), cap_, small_.as<unsigned int>(), st));
             VSTAB_HIP_TRY(hipMemcpyAsync(hsmall_.p, count, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
             VSTAB_HIP_TRY(hipStreamSynchronize(st));
-            const unsigned int kept = hsmall_.as<unsigned int>()[0], dropped = hsmall_.as<unsigned int>()[1];
-            if (!dropped && kept <= cap_) {
+            const unsigned int kept = hsmall_.as<unsigned int>()[0];
+            if (kept <= cap_) {
                 if (kept == 0) return VSTAB_OK;
                 VSTAB_TRY(hkeys_.ensure(sizeof(unsigned long long) * kept));
                 VSTAB_HIP_TRY(hipMemcpyAsync(hkeys_.p, keys_.p, sizeof(unsigned long long) * kept, hipMemcpyDeviceToHost, st));
@@ -193,7 +193,7 @@ class Tracker {
                 select_corners(hkeys_.as<unsigned long long>(), kept, max_corners, min_distance, xy);
                 return VSTAB_OK;
             }
-            fused_overflows_++;  // a tile with more local maxima than it has slots (dense fine texture): the two-pass detector below
+            fused_overflows_++;  // more corners above the threshold than the key buffer holds: the two-pass detector below grows it
         }
         VSTAB_TRY(eig_.ensure(sizeof(float) * (size_t)w_ * h_));
         if (!eig) eig = eig_.as<float>();
@@ -229,7 +229,7 @@ class Tracker {
         if (!spec_ev_) VSTAB_HIP_TRY(hipEventCreateWithFlags(&spec_ev_, hipEventDisableTiming));
         unsigned int *count = spec_small_.as<unsigned int>() + 4;
         VSTAB_TRY(launch_corners_fused(gray, pitch, w_, h_, quality, spec_raw_.p, spec_keys_.as<unsigned long long>(), SPEC_CAP, spec_small_.as<unsigned int>(), st));
-        VSTAB_HIP_TRY(hipMemcpyAsync(spec_host_.p, count, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));  // {keys kept, per-tile overflow}
+        VSTAB_HIP_TRY(hipMemcpyAsync(spec_host_.p, count, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));  // {keys kept, tiles that spilled}
         VSTAB_HIP_TRY(hipMemcpyAsync(spec_host_.as<uint8_t>() + 64, spec_keys_.p, sizeof(unsigned long long) * SPEC_CAP, hipMemcpyDeviceToHost, st));
         VSTAB_HIP_TRY(hipEventRecord(spec_ev_, st));
         spec_tag_ = tag;
@@ -267,7 +267,7 @@ class Tracker {
                     if (q == hipSuccess) {
                         const auto t1 = std::chrono::steady_clock::now();
                         const unsigned int n = spec_host_.as<unsigned int>()[0];
-                        if (n <= SPEC_CAP && spec_host_.as<unsigned int>()[1] == 0) {
+                        if (n <= SPEC_CAP) {
                             select_corners(reinterpret_cast<unsigned long long *>(spec_host_.as<uint8_t>() + 64), n, spec_max_, spec_dist_, spec_xy_);
                             result = 2;
                         }
@@ -321,7 +321,7 @@ class Tracker {
         spec_tag_ = -1;
         if (!spec_ev_ || hipEventSynchronize(spec_ev_) != hipSuccess) return false;
         const unsigned int n = spec_host_.as<unsigned int>()[0];
-        if (n > SPEC_CAP || spec_host_.as<unsigned int>()[1] != 0) return false;
+        if (n > SPEC_CAP) return false;
         select_corners(reinterpret_cast<unsigned long long *>(spec_host_.as<uint8_t>() + 64), n, max_corners, min_distance, xy);
         return true;
     }

@@ -266,9 +266,45 @@ constexpr int CF_SLOTS = 256;                          // key slots per tile (a 
 
 __device__ __forceinline__ float ubyte_f32(uint32_t v, int b) { return (float)((v >> (8 * b)) & 255u); }  // v_cvt_f32_ubyteN
 
+// threshold + 3x3 maximum test over the eigenvalues in LDS.  DENSE = false: survivors are appended to the tile's slots
+// (*bcount counts all of them, also those past the last slot); DENSE = true: every pixel of the tile is written, the
+// eigenvalue for a survivor and -inf otherwise.
+template <bool DENSE>
+__device__ __forceinline__ void cf_nonmax(const float (&es)[CF_EH][CF_EP], int tid, int ox, int oy, int w, int h, float thr_lb,
+                                          unsigned long long *__restrict__ my_slots, unsigned int *bcount, float *__restrict__ dense) {
+    const int tx = tid & 63, r0 = (tid >> 6) * 8;
+    const int x = ox + tx;
+    float rm0 = fmaxf(fmaxf(es[r0][tx], es[r0][tx + 1]), es[r0][tx + 2]);
+    float c1 = es[r0 + 1][tx + 1];
+    float rm1 = fmaxf(fmaxf(es[r0 + 1][tx], c1), es[r0 + 1][tx + 2]);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int ty = r0 + r;
+        if (ty >= CF_TH) break;  // wave-uniform (the last wave owns 7 rows)
+        const float c2 = es[ty + 2][tx + 1];
+        const float rm2 = fmaxf(fmaxf(es[ty + 2][tx], c2), es[ty + 2][tx + 2]);
+        const float m = fmaxf(fmaxf(rm0, rm1), rm2);
+        const int y = oy + ty;
+        const bool cand = x >= 1 && y >= 1 && x < w - 1 && y < h - 1 && c1 > thr_lb && c1 == m;
+        if (DENSE) {
+            dense[ty * CF_TW + tx] = cand ? c1 : -__builtin_inff();
+        } else {
+            const unsigned long long ballot = __ballot(cand);
+            if (ballot) {
+                unsigned int base = 0;
+                if (tx == 0) base = atomicAdd(bcount, (unsigned int)__popcll(ballot));  // LDS
+                base = __builtin_amdgcn_readfirstlane(base);
+                const unsigned int slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0));
+                if (cand && slot < CF_SLOTS) my_slots[slot] = ((unsigned long long)__float_as_uint(c1) << 32) | (unsigned int)(y * w + x);
+            }
+        }
+        rm0 = rm1, rm1 = rm2, c1 = c2;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_corners_fused(const uint8_t *__restrict__ src, size_t pitch, int w, int h, double quality,
                                                        unsigned int *__restrict__ max_key, unsigned long long *__restrict__ slots,
-                                                       unsigned int *__restrict__ tile_counts, int vec_ok) {
+                                                       unsigned int *__restrict__ tile_counts, float *__restrict__ spill, int vec_ok) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[CF_SH][CF_SW];
     __shared__ __attribute__((aligned(16))) float dxs[CF_DH][CF_DP], dys[CF_DH][CF_DP];
     __shared__ float es[CF_EH][CF_EP];
@@ -376,55 +412,52 @@ __global__ void __launch_bounds__(256) k_corners_fused(const uint8_t *__restrict
     const int lb_bits = max(tile_max, (int)(seen ^ 0x80000000u));
     const float thr_lb = lb_bits >= 0 ? (float)((double)__int_as_float(lb_bits) * quality) : -__builtin_inff();
     // 3x3 maximum test: lane = column, a wave walks 8 rows with a rolling row-maximum
-    const int tx = tid & 63, r0 = (tid >> 6) * 8;
-    const int x = ox + tx;
-    unsigned long long *my_slots = slots + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * CF_SLOTS;
-    float rm0 = fmaxf(fmaxf(es[r0][tx], es[r0][tx + 1]), es[r0][tx + 2]);
-    float c1 = es[r0 + 1][tx + 1];
-    float rm1 = fmaxf(fmaxf(es[r0 + 1][tx], c1), es[r0 + 1][tx + 2]);
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int ty = r0 + r;
-        if (ty >= CF_TH) break;  // wave-uniform (the last wave owns 7 rows)
-        const float c2 = es[ty + 2][tx + 1];
-        const float rm2 = fmaxf(fmaxf(es[ty + 2][tx], c2), es[ty + 2][tx + 2]);
-        const float m = fmaxf(fmaxf(rm0, rm1), rm2);
-        const int y = oy + ty;
-        const bool cand = x >= 1 && y >= 1 && x < w - 1 && y < h - 1 && c1 > thr_lb && c1 == m;
-        const unsigned long long ballot = __ballot(cand);
-        if (ballot) {
-            unsigned int base = 0;
-            if (tx == 0) base = atomicAdd(&bcount, (unsigned int)__popcll(ballot));  // LDS
-            base = __builtin_amdgcn_readfirstlane(base);
-            const unsigned int slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0));
-            if (cand && slot < CF_SLOTS) my_slots[slot] = ((unsigned long long)__float_as_uint(c1) << 32) | (unsigned int)(y * w + x);
-        }
-        rm0 = rm1, rm1 = rm2, c1 = c2;
-    }
+    const int tile_idx = blockIdx.y * gridDim.x + blockIdx.x;
+    cf_nonmax<false>(es, tid, ox, oy, w, h, thr_lb, slots + (size_t)tile_idx * CF_SLOTS, &bcount, nullptr);
     __syncthreads();
-    if (tid == 0) tile_counts[blockIdx.y * gridDim.x + blockIdx.x] = bcount;
+    const unsigned int n = bcount;
+    if (tid == 0) tile_counts[tile_idx] = n;
+    // A tile with more survivors than slots (an eigenvalue plateau: a smooth ramp, a periodic texture) leaves them as a
+    // dense 64 x 31 map instead (-inf = not a survivor); k_filter_keys scans that with the final threshold.
+    if (n > CF_SLOTS) cf_nonmax<true>(es, tid, ox, oy, w, h, thr_lb, nullptr, nullptr, spill + (size_t)tile_idx * (CF_TW * CF_TH));
 }
 
 // k_filter_keys -- the final threshold quality * max(frame) over the survivors of k_corners_fused.  A workgroup
-// gathers the keys of FK_TILES tiles in LDS and appends them with ONE global atomic.
-// counts[0] = keys kept (may exceed cap_out), counts[1] = largest survivor count of a tile (> CF_SLOTS: some were dropped);
-// in both cases the caller re-runs with the two-pass detector.
+// gathers the keys of FK_TILES tiles in LDS and appends them with ONE global atomic; a tile that spilled (dense map) is
+// scanned row by row and appended per wavefront.  counts[0] = keys kept (may exceed cap_out: the caller then re-runs
+// with the two-pass detector, whose key buffer grows), counts[1] = number of spilled tiles (statistics).
 constexpr int FK_TILES = 16;
-__global__ void __launch_bounds__(256) k_filter_keys(const unsigned long long *__restrict__ slots, const unsigned int *__restrict__ tile_counts, int n_tiles,
+__global__ void __launch_bounds__(256) k_filter_keys(const unsigned long long *__restrict__ slots, const unsigned int *__restrict__ tile_counts,
+                                                     const float *__restrict__ spill, int n_tiles, int tiles_x, int w,
                                                      const unsigned int *__restrict__ max_key, double quality,
                                                      unsigned long long *__restrict__ out, unsigned int *__restrict__ counts, unsigned int cap_out) {
     __shared__ unsigned long long kept[FK_TILES * CF_SLOTS];
-    __shared__ unsigned int n_kept, base, worst;
+    __shared__ unsigned int n_kept, base, n_spilled;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) n_kept = 0, worst = 0;
+    if (tid == 0) n_kept = 0, n_spilled = 0;
     __syncthreads();
     const float thr = (float)((double)__int_as_float((int)(*max_key ^ 0x80000000u)) * quality);
     for (int k = 0; k < FK_TILES / 4; k++) {
         const int t = blockIdx.x * FK_TILES + wave * (FK_TILES / 4) + k;
         if (t >= n_tiles) break;
-        const unsigned int n_raw = tile_counts[t];
-        if (lane == 0 && n_raw > CF_SLOTS) atomicMax(&worst, n_raw);
-        const unsigned int n = min(n_raw, (unsigned int)CF_SLOTS);
+        const unsigned int n = tile_counts[t];
+        if (n > CF_SLOTS) {
+            if (lane == 0) atomicAdd(&n_spilled, 1u);
+            const int ty0 = t / tiles_x, ox = (t - ty0 * tiles_x) * CF_TW, oy = ty0 * CF_TH;
+            for (int r = 0; r < CF_TH; r++) {
+                const float v = spill[(size_t)t * (CF_TW * CF_TH) + r * CF_TW + lane];
+                const bool keep = v > thr;
+                const unsigned long long ballot = __ballot(keep);
+                if (ballot) {
+                    unsigned int b = 0;
+                    if (lane == 0) b = atomicAdd(&counts[0], (unsigned int)__popcll(ballot));
+                    b = __builtin_amdgcn_readfirstlane(b);
+                    const unsigned int slot = b + __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0));
+                    if (keep && slot < cap_out) out[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)((oy + r) * w + ox + lane);
+                }
+            }
+            continue;
+        }
         for (unsigned int i = lane; i < ((n + 63) & ~63u); i += 64) {
             unsigned long long key = 0;
             bool keep = false;
@@ -445,7 +478,7 @@ __global__ void __launch_bounds__(256) k_filter_keys(const unsigned long long *_
     const unsigned int n = n_kept;
     if (tid == 0) {
         if (n) base = atomicAdd(&counts[0], n);
-        if (worst) atomicMax(&counts[1], worst);
+        if (n_spilled) atomicAdd(&counts[1], n_spilled);
     }
     __syncthreads();
     for (unsigned int i = tid; i < n; i += 256)
@@ -811,12 +844,13 @@ vstab_status launch_corner_candidates(const float *eig, int w, int h, const int 
     return VSTAB_OK;
 }
 
-// Fused detector.  small: 8 dwords of device memory {biased maximum bits, -, -, -, keys kept, largest per-tile overflow,
-// -, -}; scratch: corners_fused_scratch_bytes(w, h).  On return (stream order) keys holds min(small[4], cap) keys; the
-// result is complete iff small[5] == 0 and small[4] <= cap.
+// Fused detector.  small: 8 dwords of device memory {biased maximum bits, -, -, -, keys kept, tiles that spilled, -, -};
+// scratch: corners_fused_scratch_bytes(w, h) (per tile: 256 key slots, a count, and room for a dense 64 x 31 map that
+// only a tile with more survivors than slots writes).  On return (stream order) keys holds min(small[4], cap) keys; the
+// result is complete iff small[4] <= cap.
 size_t corners_fused_scratch_bytes(int w, int h) {
     const size_t tiles = (size_t)div_up(w, CF_TW) * div_up(h, CF_TH);
-    return tiles * CF_SLOTS * sizeof(unsigned long long) + tiles * sizeof(unsigned int);
+    return tiles * (CF_SLOTS * sizeof(unsigned long long) + CF_TW * CF_TH * sizeof(float) + sizeof(unsigned int));
 }
 
 vstab_status launch_corners_fused(const uint8_t *src, size_t pitch, int w, int h, double quality, void *scratch, unsigned long long *keys,
@@ -825,9 +859,11 @@ vstab_status launch_corners_fused(const uint8_t *src, size_t pitch, int w, int h
     const int vec_ok = reinterpret_cast<uintptr_t>(src) % 4 == 0 && pitch % 4 == 0;
     const int tiles_x = div_up(w, CF_TW), tiles_y = div_up(h, CF_TH), tiles = tiles_x * tiles_y;
     unsigned long long *slots = static_cast<unsigned long long *>(scratch);
-    unsigned int *tile_counts = reinterpret_cast<unsigned int *>(slots + (size_t)tiles * CF_SLOTS);
-    hipLaunchKernelGGL(k_corners_fused, dim3(tiles_x, tiles_y), dim3(256), 0, s, src, pitch, w, h, quality, small, slots, tile_counts, vec_ok);
-    hipLaunchKernelGGL(k_filter_keys, dim3(div_up(tiles, FK_TILES)), dim3(256), 0, s, slots, tile_counts, tiles, small, quality, keys, small + 4, cap);
+    float *spill = reinterpret_cast<float *>(slots + (size_t)tiles * CF_SLOTS);
+    unsigned int *tile_counts = reinterpret_cast<unsigned int *>(spill + (size_t)tiles * CF_TW * CF_TH);
+    hipLaunchKernelGGL(k_corners_fused, dim3(tiles_x, tiles_y), dim3(256), 0, s, src, pitch, w, h, quality, small, slots, tile_counts, spill, vec_ok);
+    hipLaunchKernelGGL(k_filter_keys, dim3(div_up(tiles, FK_TILES)), dim3(256), 0, s, slots, tile_counts, spill, tiles, tiles_x, w, small, quality, keys,
+                       small + 4, cap);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }
