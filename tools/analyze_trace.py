@@ -15,10 +15,11 @@ t0 = rows[0][0]
 byk = collections.defaultdict(list)
 for s, e, k, q in rows:
     byk[k].append((s - t0, e - t0))
-# steady-state window: the last 200 warp launches
-w = byk["k_warp_tiled"]
-lo, hi = w[-220][0], w[-20][1]
-print("window %.1f us, %d warps -> period %.2f us" % ((hi - lo) / 1e3, 200, (w[-20][0] - w[-220][0]) / 200 / 1e3))
+# steady-state window: 200 warp launches in the middle of the run (the end of a run is the drain of the look-ahead queue)
+w = byk["k_warp_fused"] if "k_warp_fused" in byk else byk["k_warp_tiled"]
+mid = len(w) // 2
+lo, hi = w[mid - 100][0], w[mid + 100][1]
+print("window %.1f us, %d warps -> period %.2f us" % ((hi - lo) / 1e3, 200, (w[mid + 100][0] - w[mid - 100][0]) / 200 / 1e3))
 for k, v in byk.items():
     vv = [(s, e) for s, e in v if s >= lo and e <= hi]
     if not vv:
@@ -41,7 +42,7 @@ tot += cur_e - cur_s
 print("GPU busy (any kernel) %.1f%% of the window" % (tot / (hi - lo) * 100))
 # print a sample of the timeline
 print("sample timeline (us):")
-base = w[-120][0]
+base = w[mid][0]
 for s, e, k, q in rows:
     s -= t0; e -= t0
     if s >= base and s < base + 200000:

@@ -25,18 +25,6 @@ __device__ __forceinline__ uint32_t load4_reflect_row(const uint8_t *__restrict_
     return v;
 }
 
-// The same when every column is within one reflection of the row (-n < column < 2n - 1): no loops, four independent loads.
-__device__ __forceinline__ uint32_t load4_reflect_row_near(const uint8_t *__restrict__ row, int w, int gx, bool vec_ok) {
-    if (vec_ok && gx >= 0 && gx + 4 <= w) return *reinterpret_cast<const uint32_t *>(row + gx);
-    uint32_t v = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int c = abs(gx + i);
-        v |= (uint32_t)row[min(c, 2 * w - 2 - c)] << (8 * i);
-    }
-    return v;
-}
-
 // One dword of a REFLECT_101-padded u8 image at (gx .. gx+3, gy), gx a multiple of 4.  Dwords that lie
 // inside the row are one aligned load (also on border tiles); only dwords straddling the left /
 // right image edge are assembled from bytes.
@@ -68,29 +56,50 @@ template <bool EDGE, bool NEAR>
 __device__ __forceinline__ void pyr_down_group(const uint8_t *__restrict__ src, uint32_t spitch, int sw, int sh, uint8_t *__restrict__ dst, size_t dpitch,
                                                int dw, int x0, int y, bool vec_ok) {
     const int sx0 = 2 * x0 - 4;  // the 16 bytes [sx0, sx0+16) hold the taps of outputs x0..x0+3: output c uses bytes 2c+2 .. 2c+6
+    const uint8_t *row[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int ry = 2 * y - 2 + j;
+        row[j] = src + (uint32_t)(NEAR ? min(abs(ry), 2 * sh - 2 - abs(ry)) : reflect101(ry, sh)) * spitch;
+    }
+    uint32_t d[5][4];
+    if (!EDGE) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(row[j] + sx0);
+            d[j][0] = p[0], d[j][1] = p[1], d[j][2] = p[2], d[j][3] = p[3];
+        }
+    } else {
+        // Whether a dword lies inside the row is the same for the five rows: one branch per dword column, the five (or
+        // twenty byte) loads under it in flight together -- a branch per load would cost a memory latency per load.
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int gx = sx0 + 4 * q;
+            if (vec_ok && gx >= 0 && gx + 4 <= sw) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) d[j][q] = *reinterpret_cast<const uint32_t *>(row[j] + gx);
+            } else {
+                int col[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) col[i] = NEAR ? min(abs(gx + i), 2 * sw - 2 - abs(gx + i)) : reflect101(gx + i, sw);
+#pragma unroll
+                for (int j = 0; j < 5; j++)
+                    d[j][q] = (uint32_t)row[j][col[0]] | ((uint32_t)row[j][col[1]] << 8) | ((uint32_t)row[j][col[2]] << 16) | ((uint32_t)row[j][col[3]] << 24);
+            }
+        }
+    }
     uint32_t acc[4] = {128u, 128u, 128u, 128u};
 #pragma unroll
     for (int j = 0; j < 5; j++) {
         const uint32_t k = j == 0 || j == 4 ? 1u : j == 2 ? 6u : 4u;
-        const int ry = 2 * y - 2 + j;
-        const uint8_t *row = src + (uint32_t)(NEAR ? min(abs(ry), 2 * sh - 2 - abs(ry)) : reflect101(ry, sh)) * spitch;
-        uint32_t d[4];
-        if (!EDGE) {
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(row + sx0);
-            d[0] = p[0], d[1] = p[1], d[2] = p[2], d[3] = p[3];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++)  // only dwords straddling an image edge take the byte path
-                d[q] = NEAR ? load4_reflect_row_near(row, sw, sx0 + 4 * q, vec_ok) : load4_reflect_row(row, sw, sx0 + 4 * q, vec_ok);
-        }
         // weight dwords (byte 0 = lowest address): taps 1 4 | 6 4 1 split over two dwords, or 1 4 6 4 | 1
         const uint32_t w_hi2 = (k << 16) | (4 * k << 24);          // (0, 0, k, 4k)
         const uint32_t w_lo3 = 6 * k | (4 * k << 8) | (k << 16);   // (6k, 4k, k, 0)
         const uint32_t w_all = k | (4 * k << 8) | (6 * k << 16) | (4 * k << 24);  // (k, 4k, 6k, 4k)
-        acc[0] = udot4(d[1], w_lo3, udot4(d[0], w_hi2, acc[0]));
-        acc[1] = udot4(d[2], k, udot4(d[1], w_all, acc[1]));
-        acc[2] = udot4(d[2], w_lo3, udot4(d[1], w_hi2, acc[2]));
-        acc[3] = udot4(d[3], k, udot4(d[2], w_all, acc[3]));
+        acc[0] = udot4(d[j][1], w_lo3, udot4(d[j][0], w_hi2, acc[0]));
+        acc[1] = udot4(d[j][2], k, udot4(d[j][1], w_all, acc[1]));
+        acc[2] = udot4(d[j][2], w_lo3, udot4(d[j][1], w_hi2, acc[2]));
+        acc[3] = udot4(d[j][3], k, udot4(d[j][2], w_all, acc[3]));
     }
     // result byte c = bits 8..15 of acc[c] (sum + 128 <= 255 * 256 + 128 < 2^16)
     uint8_t *o = dst + (size_t)y * dpitch + x0;
