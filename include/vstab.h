@@ -266,6 +266,12 @@ typedef struct vstab_frame {
                           smooth_radius + 14 on, the planes are not copied at all but read in place by the tracker and
                           by the warp (which runs on vstab_config.stream): the callback at which the promise runs out
                           first waits, on the host, for that warp to finish.  1 << 29 or more: never waited for. */
+    const double *readout_rotation; /* optional (NULL = global shutter): 3x3 row-major rotation of the camera between the
+                          exposure of this frame's first and last row (rolling shutter, from the same sensor as
+                          delta_rotation; BASELINE.json config 5).  The frame is then warped with a rotation per output row:
+                          the stabilising rotation W for the first row, readout_rotation * W for the last, matrix entries
+                          interpolated in between (vstab_warp_nv12_rs; preset and fisheye -> rectilinear maps only).  Read
+                          during the callback only. */
 } vstab_frame;
 
 /* Upstream FrameSource (FrameSource.hpp:14,20): return 0 and fill *out, VSTAB_EOF (-1) at end of

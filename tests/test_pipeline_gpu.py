@@ -524,6 +524,78 @@ def test_external_rotation_source_replaces_optical_flow(vs, cuda, clip):
     assert max(oracle.rotation_angle(R) for R in warp_R) > 1e-3
 
 
+def test_rolling_shutter_readout_rotation_reaches_the_warp(vs, cuda, clip):
+    """BASELINE config 5 in the pipeline object: a sensor source that also reports the camera's rotation during the frame's
+    read-out.  The stabilising rotation W is what it would be without it (the smoother sees the per-frame deltas only); the
+    frame is warped with W for its first row and readout * W for its last (oracle.warp_nv12_rs, the definition of
+    vstab_warp_nv12_rs).  Frames without a read-out rotation take the ordinary warp.  No reference counterpart: the
+    reference's gyro path is a stub (gpmf.cpp:5-11)."""
+    import ctypes
+    import torch
+    K, frames, rots = clip
+    n, r = 12, 3
+    dev = [torch.from_numpy(f).to(cuda) for f in frames[:n]]
+    deltas = [np.eye(3)] + [rots[k] @ rots[k - 1].T for k in range(1, n)]
+    readouts = [oracle.rodrigues(np.array([0.004 * np.sin(k), -0.003 * np.cos(2 * k), 0.006 * np.sin(0.5 * k + 1)])) for k in range(n)]
+    keep_d = [np.ascontiguousarray(d, np.float64) for d in deltas]
+    keep_r = [np.ascontiguousarray(d, np.float64) for d in readouts]
+    dp = ctypes.POINTER(ctypes.c_double)
+
+    def run(with_readout):
+        state = {"i": 0}
+
+        def fill(out, advance):
+            i = state["i"]
+            if i >= n:
+                return vs.EOF
+            t = dev[i]
+            o = out.contents
+            o.y, o.uv = t.data_ptr(), t.data_ptr() + H * t.stride(0)
+            o.pitch_y = o.pitch_uv = t.stride(0)
+            o.width, o.height, o.mem, o.pts, o.hold, o.bit_depth = W, H, 0, i, 1 << 30, 8
+            o.delta_rotation = keep_d[i].ctypes.data_as(dp)
+            o.readout_rotation = keep_r[i].ctypes.data_as(dp) if with_readout(i) else None
+            if advance:
+                state["i"] += 1
+            return 0
+        pull = vs.PULL_FN(lambda u, o: fill(o, True))
+        peek = vs.PULL_FN(lambda u, o: fill(o, False))
+        src = vs.Source(pull, peek, None)
+        cfg = vs.default_config(smooth_radius=r, tracking=0)
+        h = ctypes.c_void_p()
+        assert vs.lib.vstab_create(ctypes.byref(cfg), ctypes.byref(src), ctypes.byref(h)) == vs.OK
+        outs, warp_R = [], []
+        while True:
+            o = torch.empty((ch, cw, 3), dtype=torch.uint8, device=cuda)
+            st = vs.lib.vstab_pull_frame(h, o.data_ptr(), o.stride(0))
+            if st == vs.EOF:
+                break
+            assert st == vs.OK, vs.lib.vstab_last_error()
+            outs.append(o.cpu().numpy())
+            R = np.zeros(9)
+            assert vs.lib.vstab_get_warp_rotation(h, len(outs) - 1, R.ctypes.data_as(dp)) == vs.OK
+            warp_R.append(R.reshape(3, 3))
+        vs.lib.vstab_destroy(h)
+        return outs, warp_R
+    Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
+    plain, plain_R = run(lambda i: False)
+    outs, warp_R = run(lambda i: i % 4 != 2)            # frames 2, 6, 10: global shutter
+    assert len(outs) == len(plain) == n - 1
+    differ = 0
+    for i in range(n - 1):
+        assert np.allclose(warp_R[i], plain_R[i], atol=1e-12), i   # the read-out rotation does not enter the smoother
+        k = i + 1                                                  # output i is input frame i + 1
+        p = oracle.map_params(K, Ko, warp_R[i])
+        if k % 4 != 2:
+            pb = oracle.map_params(K, Ko, readouts[k] @ warp_R[i])
+            assert np.array_equal(outs[i], oracle.warp_nv12_rs(frames[k], p, pb[8:], cw, ch)), i
+            differ += not np.array_equal(outs[i], plain[i])
+        else:
+            assert np.array_equal(outs[i], plain[i]), i
+            assert np.array_equal(outs[i], oracle.warp_nv12(frames[k], p, cw, ch)), i
+    assert differ >= 6                                             # it is not a no-op
+
+
 def _check_against_oracle_state_machine(vs, cuda, frames, K, w, h, r, seed):
     """Whole-pipeline equivalence on an arbitrary clip: decisions, counts, rotations handed to the warp, pixels."""
     stab, outs = run_product(vs, cuda, frames, smooth_radius=r, seed=seed)

@@ -14,3 +14,9 @@ for a in 0 1 2 4 8 3 7 15; do echo "VSTAB_ABLATE=$a"; VSTAB_LIB_PATH=video-annot
 bash tools/prof_warp.sh r02iso > $O/prof_warp.log 2>&1
 bash tools/prof_bench.sh r02pipe > $O/prof_bench.log 2>&1
 tail -3 $O/prof_bench.log
+bash tools/prof_detect.sh > $O/prof_detect.log 2>&1
+cp $R/gpurun_out/prof_detect/summary.txt $O/detector_summary.txt
+# keep what tools/publish_profiles.sh reads, drop the per-dispatch traces (gpurun merges at most 64 MiB back)
+find $R/gpurun_out/prof_r02pipe/trace -name "*kernel_stats.csv" -exec cp {} $O/bench_pipeline_kernel_stats_full.csv \;
+find $R/gpurun_out -name "*kernel_trace.csv" -delete
+find $R/gpurun_out -name "*counter_collection.csv" -delete

@@ -600,6 +600,8 @@ struct vstab_handle {
         std::vector<float> feats;  // vstab_config.debug: the features tracked into this frame (input pixels)
         bool have_delta = false;  // upstream supplied this frame's rotation since the previous frame (vstab_frame.delta_rotation)
         Mat3 delta;
+        bool have_readout = false;  // ... and the rotation during the frame's read-out (vstab_frame.readout_rotation): rolling-shutter warp
+        Mat3 readout;
         bool queued = false, last = false;
         long freed_at = 0;               // FIFO reuse: the slot idle the longest is taken first
         hipEvent_t ingested = nullptr;   // recorded on pstream after the copy into the slot (and its pyramid, when tracking)
@@ -934,6 +936,12 @@ static vstab_status prefetch_next(vstab_handle *H) {
     H->last_ingest_slot = slot;
     H->slots[slot].have_delta = f.delta_rotation != nullptr;
     if (f.delta_rotation) std::memcpy(H->slots[slot].delta.m, f.delta_rotation, sizeof(double) * 9);
+    H->slots[slot].have_readout = f.readout_rotation != nullptr;
+    if (f.readout_rotation) {
+        if (H->map_mode != VSTAB_MAP_CREATEMAP_CL && H->map_mode != VSTAB_MAP_FISH_TO_RECT)
+            return fail(VSTAB_ERR_INVALID, "vstab_frame.readout_rotation: the rolling-shutter warp exists for the preset and fisheye -> rectilinear maps only");
+        std::memcpy(H->slots[slot].readout.m, f.readout_rotation, sizeof(double) * 9);
+    }
     H->slots[slot].ingest_serial = ++H->ingest_serial;
     // (frames promised to outlive a whole ring of pulls are not tracked: the ring slot itself is recycled sooner)
     if (f.mem == 0 && !H->slots[slot].borrowed && f.hold < (int)H->slots.size())
@@ -1295,8 +1303,12 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
     float p[17];
     map_params(H->Kin, H->Kout, warp_R, p);
     vstab_handle::Slot &S = H->slots[slot];
+    // rolling shutter: the camera kept turning while the rows were read out; the last row is warped with the stabilising
+    // rotation of the orientation it was exposed at (measured' = readout * measured  =>  W' = readout * W)
+    float p_bottom[17];
+    if (S.have_readout) map_params(H->Kin, H->Kout, S.readout * warp_R, p_bottom);
     bool cached = false;
-    if (H->map_cache) {
+    if (H->map_cache && !S.have_readout) {
         if (H->qmap_valid && std::memcmp(p, H->qmap_params, sizeof(p)) == 0) {
             cached = true;
         } else if (H->have_last_params && std::memcmp(p, H->last_params, sizeof(p)) == 0) {
@@ -1320,6 +1332,9 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         if (cached)
             st = vstab_warp_nv12_mapped(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, H->qmap.p, out_format, dst, pitch_dst, dst_uv, pitch_dst_uv,
                                         H->ow, H->oh, H->stream);
+        else if (S.have_readout)
+            st = vstab_warp_nv12_rs(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, p, p_bottom + 8, H->map_mode, out_format, dst, pitch_dst, dst_uv,
+                                    pitch_dst_uv, H->ow, H->oh, H->stream);
         else
             st = vstab_warp_nv12_ex(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, p, H->map_mode, out_format, dst,
                                     pitch_dst, dst_uv, pitch_dst_uv, H->ow, H->oh, H->stream);
