@@ -26,6 +26,23 @@ def test_pyr_down_bit_exact(vs, cuda):
     assert np.array_equal(vs.pyr_down(dev(big, cuda)[:, :77]).cpu().numpy(), oracle.pyr_down(big[:, :77]))
 
 
+def test_pyr_down_size_sweep_and_unaligned_views(vs, cuda):
+    """The kernel splits every row into interior groups of four outputs (16-byte windows, dot products on packed dwords)
+    and edge groups (reflected taps, partial stores) that run in workgroups of their own: every width from 5 to 52 with
+    heights around the 4-row reflection limit, then views whose base or pitch is not 4-byte aligned (all-edge path)."""
+    rng = np.random.default_rng(11)
+    for h in (1, 2, 3, 4, 5, 8, 9):
+        for w in range(5, 53):
+            img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            assert np.array_equal(vs.pyr_down(dev(img, cuda)).cpu().numpy(), oracle.pyr_down(img)), (w, h)
+    big = rng.integers(0, 256, (70, 203), dtype=np.uint8)
+    d = dev(big, cuda)
+    for x0 in (0, 1, 2, 3):
+        for w in (64, 65, 66, 67, 131):
+            v = big[3:64, x0:x0 + w]
+            assert np.array_equal(vs.pyr_down(d[3:64, x0:x0 + w]).cpu().numpy(), oracle.pyr_down(np.ascontiguousarray(v))), (x0, w)
+
+
 def test_min_eig_bit_exact(vs, cuda):
     for seed, w, h in [(1, 320, 180), (2, 333, 181), (6, 64, 48)]:
         img = synth.luma(seed, w, h)
