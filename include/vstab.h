@@ -157,6 +157,20 @@ VSTAB_API vstab_status vstab_warp_nv12_rs(const void *y, size_t pitch_y, const v
                                           size_t pitch_dst_uv, int dst_width, int dst_height, void *stream);
 
 
+/* 10-bit pixel path (BASELINE.json config 5: "4K P010, fp16 blend, rolling-shutter per-row warp"; the reference is 8-bit
+ * throughout, so this operator is DEFINED here and in the oracle, vo_warp_p010).  y / uv: P010 planes, 16-bit
+ * little-endian samples with the 10 significant bits at the top, pitches in bytes, chroma interleaved U,V at half
+ * resolution.  Conversion: BT.601 limited range with the cvtColor constants at 10 bits (offsets 64 / 512).  Map: as
+ * vstab_warp_nv12_ex (all five modes); rot_bottom != NULL adds vstab_warp_nv12_rs's rotation per output row.  Blend:
+ * VSTAB_BLEND_EXACT = the integer four-product sum of the 8-bit path, (sum + 512) >> 10; VSTAB_BLEND_FP16 = four fused
+ * multiply-adds in binary16 (weights w / 1024, taps 00, 01, 10, 11), round to nearest even, clamp: within 2 levels of
+ * the exact blend.  dst: BGR, three 16-bit samples per pixel, values 0..1023 (low-aligned). */
+enum { VSTAB_BLEND_EXACT = 0, VSTAB_BLEND_FP16 = 1 };
+VSTAB_API vstab_status vstab_warp_p010(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv,
+                                       int src_width, int src_height, const float params[17], const float *rot_bottom,
+                                       int map_mode, int blend, void *dst_bgr16, size_t pitch_dst, int dst_width,
+                                       int dst_height, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Tracking front-end (device images in; small point lists on the host, as in the reference where
  * goodFeaturesToTrack / calcOpticalFlowPyrLK return std::vector<Point2f>).  These calls

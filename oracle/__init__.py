@@ -63,6 +63,9 @@ def lib():
         L.vo_cvt_bgr_nv12.argtypes = [u8p, c.c_int, c.c_int, u8p, u8p]
         L.vo_warp_nv12_ex.argtypes = [u8p, c.c_int, c.c_int, f32p, c.c_int, c.c_int, u8p, c.c_int, c.c_int, u8p]
         L.vo_create_map_rs.argtypes = [f32p, f32p, c.c_int, c.c_int, f32p, f32p, c.c_int]
+        L.vo_warp_p010.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.c_int, c.c_int, f32p, f32p, c.c_int, c.c_int, c.c_void_p, c.c_int,
+                                   c.c_int, u8p]
+        L.vo_cvt_p010_bgr10.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.c_void_p]
         L.vo_warp_nv12_rs.argtypes = [u8p, c.c_int, c.c_int, f32p, f32p, c.c_int, c.c_int, u8p, c.c_int, c.c_int, u8p]
         L.vo_min_eig.argtypes = [u8p, c.c_size_t, c.c_int, c.c_int, f32p]
         L.vo_good_features.argtypes = [u8p, c.c_size_t, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, f32p, f32p]
@@ -308,6 +311,32 @@ def scharr(img):
 def set_lk_accumulation(float_raster_order):
     """False (normative): exact int64 LK sums.  True: fp32 raster-order accumulation, for measuring the gap."""
     lib().vo_set_lk_accumulation(1 if float_raster_order else 0)
+
+
+def warp_p010(y, uv, params, dw, dh, rot_bottom=None, mode=0, blend=0):
+    """Config 5's 10-bit pixel path (DEFINED in vo_warp_p010).  y: (h, w) uint16 P010 luma, uv: (h/2, w) uint16
+    interleaved chroma; -> (dh, dw, 3) uint16 BGR, values 0..1023."""
+    ya = np.ascontiguousarray(y, np.uint16)
+    ua = np.ascontiguousarray(uv, np.uint16)
+    h, w = ya.shape
+    p, pp = _f32(params)
+    rb = None if rot_bottom is None else np.ascontiguousarray(np.asarray(rot_bottom, np.float32).reshape(9))
+    out = np.empty((dh, dw, 3), np.uint16)
+    work = np.empty(w * h * 6 + 16 + 2 * dw * dh * 4, np.uint8)
+    lib().vo_warp_p010(ya.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(ya.strides[0]), ua.ctypes.data_as(ctypes.c_void_p),
+                       ctypes.c_size_t(ua.strides[0]), w, h, pp, None if rb is None else _p(rb, ctypes.c_float), int(mode), int(blend),
+                       out.ctypes.data_as(ctypes.c_void_p), dw, dh, _p(work, ctypes.c_uint8))
+    return out
+
+
+def cvt_p010_bgr10(y, uv):
+    ya = np.ascontiguousarray(y, np.uint16)
+    ua = np.ascontiguousarray(uv, np.uint16)
+    h, w = ya.shape
+    out = np.empty((h, w, 3), np.uint16)
+    lib().vo_cvt_p010_bgr10(ya.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(ya.strides[0]), ua.ctypes.data_as(ctypes.c_void_p),
+                            ctypes.c_size_t(ua.strides[0]), w, h, out.ctypes.data_as(ctypes.c_void_p))
+    return out
 
 
 def pyr_lk(prev, nxt, pts):

@@ -423,6 +423,102 @@ VO_API void vo_warp_nv12_rs(const uint8_t *nv12, int w, int h, const float *p, c
 }
 
 /* ------------------------------------------------------------------------------------------
+ * BASELINE.json config 5: the 10-bit pixel path ("4K P010, fp16 blend, rolling-shutter per-row warp").  The reference
+ * is 8-bit throughout, so there is nothing to pin against: the arithmetic is DEFINED here ("parity unpinned") and the
+ * HIP operator vstab_warp_p010 reproduces it bit for bit.
+ *   samples   P010: 16-bit little-endian, significant bits at the top -> s >> 6 in [0, 1023]
+ *   colour    cvtColor's BT.601 constants and shift at 10 bits: offsets 64 (luma) and 512 (chroma), 64-bit sums
+ *   map       vo_create_map_ex / vo_create_map_rs
+ *   remap     cv::remap's quantisation; blend 0: (sum p*w + 512) >> 10 as the 8-bit path; blend 1 ("fp16 blend"):
+ *             acc = fma16(p00, w00/1024, 0), fma16(p01, w01/1024, acc), fma16(p10, ..), fma16(p11, ..) -- each one
+ *             fused multiply-add rounded once to binary16, ties to even -- then rint (ties to even), clamp to 1023
+ *   output    BGR, 16-bit containers, values 0..1023
+ * ------------------------------------------------------------------------------------------ */
+static inline uint16_t vo_sat10(long long v) { return (uint16_t)(v < 0 ? 0 : v > 1023 ? 1023 : v); }
+
+static inline void vo_yuv10_to_bgr10(int Y, int U, int V, uint16_t *bgr) {
+    long long u = U - 512, v = V - 512;
+    long long ruv = (1 << (VO_YUV_SHIFT - 1)) + VO_CVR * v;
+    long long guv = (1 << (VO_YUV_SHIFT - 1)) + VO_CVG * v + VO_CUG * u;
+    long long buv = (1 << (VO_YUV_SHIFT - 1)) + VO_CUB * u;
+    long long y = (long long)(Y - 64 > 0 ? Y - 64 : 0) * VO_CY;
+    bgr[0] = vo_sat10((y + buv) >> VO_YUV_SHIFT);
+    bgr[1] = vo_sat10((y + guv) >> VO_YUV_SHIFT);
+    bgr[2] = vo_sat10((y + ruv) >> VO_YUV_SHIFT);
+}
+
+static inline int vo_p010_sample(const uint8_t *row, int i) { return (int)(((unsigned)row[2 * i] | ((unsigned)row[2 * i + 1] << 8)) >> 6); }
+
+VO_API void vo_cvt_p010_bgr10(const uint8_t *y, size_t pitch_y, const uint8_t *uv, size_t pitch_uv, int w, int h, uint16_t *bgr) {
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < h; r++) {
+        const uint8_t *yrow = y + (size_t)r * pitch_y, *crow = uv + (size_t)(r >> 1) * pitch_uv;
+        for (int c = 0; c < w; c++)
+            vo_yuv10_to_bgr10(vo_p010_sample(yrow, c), vo_p010_sample(crow, c & ~1), vo_p010_sample(crow, (c & ~1) + 1), bgr + ((size_t)r * w + c) * 3);
+    }
+}
+
+/* round an exactly known real (held in a double) to IEEE binary16, ties to even; returned as a double */
+static inline double vo_round_f16(double v) {
+    if (v == 0.0) return v;
+    int e;
+    frexp(v, &e);                 /* |v| = m * 2^e, m in [0.5, 1) -> binary exponent e - 1 */
+    int ex = e - 1 < -14 ? -14 : e - 1;
+    double q = ldexp(1.0, ex - 10);
+    return nearbyint(v / q) * q;  /* default rounding mode: ties to even */
+}
+
+static inline uint16_t vo_blend_f16(int p00, int p01, int p10, int p11, int w00, int w01, int w10, int w11) {
+    double acc = 0.0;
+    acc = vo_round_f16((double)p00 * ((double)w00 / 1024.0) + acc);  /* operands are exact binary16 values; the sum is exact in double */
+    acc = vo_round_f16((double)p01 * ((double)w01 / 1024.0) + acc);
+    acc = vo_round_f16((double)p10 * ((double)w10 / 1024.0) + acc);
+    acc = vo_round_f16((double)p11 * ((double)w11 / 1024.0) + acc);
+    long v = lrint(acc);
+    return (uint16_t)(v > 1023 ? 1023 : v);
+}
+
+static inline void vo_remap_pixel10(const uint16_t *src, int sw, int sh, float mx, float my, int blend, uint16_t *out) {
+    int sx = vo_cvround(mx * 32.0f), sy = vo_cvround(my * 32.0f);
+    int X = vo_sat16(sx >> 5), Y = vo_sat16(sy >> 5);
+    int fx = sx & 31, fy = sy & 31;
+    if (X >= sw || X + 1 < 0 || Y >= sh || Y + 1 < 0) {
+        out[0] = out[1] = out[2] = 0;
+        return;
+    }
+    int w00 = (32 - fx) * (32 - fy), w01 = fx * (32 - fy), w10 = (32 - fx) * fy, w11 = fx * fy;
+    int in00 = X >= 0 && Y >= 0, in01 = X + 1 < sw && Y >= 0;
+    int in10 = X >= 0 && Y + 1 < sh, in11 = X + 1 < sw && Y + 1 < sh;
+    for (int c = 0; c < 3; c++) {
+        int p00 = in00 ? src[((size_t)Y * sw + X) * 3 + c] : 0;
+        int p01 = in01 ? src[((size_t)Y * sw + X + 1) * 3 + c] : 0;
+        int p10 = in10 ? src[((size_t)(Y + 1) * sw + X) * 3 + c] : 0;
+        int p11 = in11 ? src[((size_t)(Y + 1) * sw + X + 1) * 3 + c] : 0;
+        out[c] = blend ? vo_blend_f16(p00, p01, p10, p11, w00, w01, w10, w11)
+                       : (uint16_t)((p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + 512) >> 10);
+    }
+}
+
+/* work: w*h*6 + 16 + 2*dw*dh*4 bytes.  rot_bottom may be NULL (one rotation for the frame). */
+VO_API void vo_warp_p010(const uint8_t *y, size_t pitch_y, const uint8_t *uv, size_t pitch_uv, int w, int h, const float *p,
+                         const float *rot_bottom, int mode, int blend, uint16_t *dst, int dw, int dh, uint8_t *work) {
+    uint16_t *bgr = (uint16_t *)work;
+    float *mapx = (float *)(work + (((size_t)w * h * 6 + 15) & ~(size_t)15));
+    float *mapy = mapx + (size_t)dw * dh;
+    vo_cvt_p010_bgr10(y, pitch_y, uv, pitch_uv, w, h, bgr);
+    if (rot_bottom)
+        vo_create_map_rs(mapx, mapy, dw, dh, p, rot_bottom, mode);
+    else if (mode == 0)
+        vo_create_map(mapx, mapy, dw, dh, p);
+    else
+        vo_create_map_ex(mapx, mapy, dw, dh, p, mode);
+#pragma omp parallel for schedule(static)
+    for (int yy = 0; yy < dh; yy++)
+        for (int x = 0; x < dw; x++)
+            vo_remap_pixel10(bgr, w, h, mapx[(size_t)yy * dw + x], mapy[(size_t)yy * dw + x], blend, dst + ((size_t)yy * dw + x) * 3);
+}
+
+/* ------------------------------------------------------------------------------------------
  * a3: goodFeaturesToTrack(gray, 200, 0.01, 30), call site FrameSourceWarp.cpp:230.
  * Third-party arithmetic (OpenCV 4.5 imgproc featureselect/corner, CPU path).
  * ------------------------------------------------------------------------------------------ */

@@ -103,6 +103,7 @@ SIGNATURES = {
     "vstab_pyr_down": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp]),
     "vstab_min_eig": (_i, [_vp, _sz, _i, _i, _vp, _vp]),
     "vstab_good_features": (_i, [_vp, _sz, _i, _i, _i, _d, _d, _fp, _ip, _vp]),
+    "vstab_warp_p010": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _fp, _i, _i, _vp, _sz, _i, _i, _vp]),
     "vstab_good_features_ex": (_i, [_vp, _sz, _i, _i, _i, _d, _d, _i, _fp, _ip, _ip, _vp]),
     "vstab_pyr_lk": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _fp, _u8p, _vp]),
     "vstab_estimate_rotation": (_i, [_fp, _fp, _i, _dp, _dp, _u64, _dp, _ip]),
@@ -340,6 +341,23 @@ def warp_nv12_rs(nv12, params, rot_bottom, dw, dh, mode=MAP_CREATEMAP_CL, out_fo
     _check(_L.vstab_warp_nv12_rs(yp, pitch, uvp, pitch, w, h, _fptr(p), _fptr(rb), int(mode), int(out_format), yo.data_ptr(), yo.stride(0),
                                  co.data_ptr(), co.stride(0), dw, dh, _stream()), "vstab_warp_nv12_rs")
     return yo, co
+
+
+BLEND_EXACT, BLEND_FP16 = 0, 1
+
+
+def warp_p010(y, uv, params, dw, dh, rot_bottom=None, mode=MAP_CREATEMAP_CL, blend=BLEND_EXACT, out=None):
+    """vstab_warp_p010 (config 5): y (h, w) / uv (h/2, w) int16-or-uint16 CUDA tensors holding P010 samples ->
+    (dh, dw, 3) int16 tensor of BGR values 0..1023."""
+    import torch
+    h, w = y.shape
+    p = np.ascontiguousarray(params, np.float32)
+    rb = None if rot_bottom is None else np.ascontiguousarray(rot_bottom, np.float32).reshape(9)
+    if out is None:
+        out = torch.empty((dh, dw, 3), dtype=torch.int16, device=y.device)
+    _check(_L.vstab_warp_p010(y.data_ptr(), y.stride(0) * 2, uv.data_ptr(), uv.stride(0) * 2, w, h, _fptr(p), None if rb is None else _fptr(rb),
+                              int(mode), int(blend), out.data_ptr(), out.stride(0) * 2, dw, dh, _stream()), "vstab_warp_p010")
+    return out
 
 
 def quantised_map(params, dw, dh, mode=MAP_CREATEMAP_CL, device="cuda"):

@@ -1,0 +1,141 @@
+// vstab_warp_p010.hip -- BASELINE.json config 5: the undistort-remap with a 10-bit pixel path.
+// No reference counterpart (the reference is 8-bit throughout): the arithmetic is DEFINED in the oracle
+// (vo_warp_p010) and reproduced here bit for bit.
+//   P010 planes (16-bit samples, 10 significant bits at the top)  ->  sample >> 6
+//   BT.601 limited range at 10 bits: the 8-bit cvtColor constants and shift with offsets 64 / 512 (64-bit sums:
+//     959 * CY + 511 * CUB exceeds int32)  ->  B, G, R in [0, 1023]
+//   the map of vstab_create_map_ex (all five projection pairs), optionally with a rotation per output row
+//     (vstab_warp_nv12_rs's interpolation), quantised like cv::remap
+//   blend of the four converted taps: VSTAB_BLEND_EXACT  (sum p*w + 512) >> 10, integers, as the 8-bit path;
+//     VSTAB_BLEND_FP16  four fused multiply-adds in binary16 with the weights as w / 1024 (exact in binary16),
+//     taps in the order 00, 01, 10, 11, then round-to-nearest-even and clamp -- the "fp16 blend" of config 5,
+//     within 2 levels of the exact one
+//   BGR, three 16-bit samples per pixel, values 0..1023.
+// Direct gather, one thread per output pixel: this path is about the format, the 8-bit kernel carries the rate.
+#include "vstab_device.hpp"
+#include "vstab_internal.hpp"
+
+namespace vstab {
+
+struct P010Args {
+    const uint8_t *y, *uv;
+    uint16_t *dst;
+    size_t pitch_y, pitch_uv, pitch_dst;  // bytes
+    int sw, sh, dw, dh;
+    MapParams p;
+    float rs_d[9];  // rotation of the last output row minus rotation of the first (all zero: one rotation)
+    float rs_den;   // (float)max(dh - 1, 1)
+    int rs;
+};
+
+__device__ __forceinline__ int sat10(long long v) { return v < 0 ? 0 : v > 1023 ? 1023 : (int)v; }
+
+// one P010 tap -> B, G, R in [0, 1023]; outside the source -> 0 (BORDER_CONSTANT)
+__device__ __forceinline__ void fetch_tap10(const P010Args &a, int X, int Y, int &b, int &g, int &r) {
+    if ((unsigned)X < (unsigned)a.sw && (unsigned)Y < (unsigned)a.sh) {
+        const int yv = *reinterpret_cast<const uint16_t *>(a.y + (size_t)Y * a.pitch_y + 2 * (size_t)X) >> 6;
+        const uint32_t c = *reinterpret_cast<const uint32_t *>(a.uv + (size_t)(Y >> 1) * a.pitch_uv + 4 * (size_t)(X >> 1));
+        const int u = (int)((c & 0xffffu) >> 6) - 512, v = (int)(c >> 22) - 512;
+        const long long yy = (long long)max(yv - 64, 0) * CY;
+        b = sat10((yy + (1 << 19) + (long long)CUB * u) >> 20);
+        g = sat10((yy + (1 << 19) + (long long)CVG * v + (long long)CUG * u) >> 20);
+        r = sat10((yy + (1 << 19) + (long long)CVR * v) >> 20);
+    } else {
+        b = g = r = 0;
+    }
+}
+
+__device__ __forceinline__ int blend_fp16(int p00, int p01, int p10, int p11, int w00, int w01, int w10, int w11) {
+    const _Float16 k = (_Float16)(1.0f / 1024.0f);
+    _Float16 acc = (_Float16)0.0f;
+    acc = __builtin_fmaf16((_Float16)p00, (_Float16)w00 * k, acc);  // (w * 2^-10 is exact: w <= 1024 has <= 11 significant bits)
+    acc = __builtin_fmaf16((_Float16)p01, (_Float16)w01 * k, acc);
+    acc = __builtin_fmaf16((_Float16)p10, (_Float16)w10 * k, acc);
+    acc = __builtin_fmaf16((_Float16)p11, (_Float16)w11 * k, acc);
+    return min((int)__builtin_rintf((float)acc), 1023);
+}
+
+template <int MODE, int BLEND>
+__global__ void __launch_bounds__(256) k_warp_p010(P010Args a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.dw || y >= a.dh) return;
+    MapParams q = a.p;
+    if (a.rs) {
+        const float t = (float)y / a.rs_den;
+#pragma unroll
+        for (int k = 0; k < 9; k++) q.r[k] = __builtin_fmaf(t, a.rs_d[k], a.p.r[k]);
+    }
+    const float vx = ((float)x - q.ocx) / q.ofx, vy = ((float)y - q.ocy) / q.ofy;
+    const ColTerm ct = {q.r[0] * vx, q.r[3] * vx, q.r[6] * vx};
+    const RowTerm rt = {q.r[1] * vy, q.r[4] * vy, q.r[7] * vy};
+    float mx, my;
+    if constexpr (MODE == MAP_CREATEMAP_CL) {
+        map_pixel(q, ct, rt, mx, my);
+    } else {
+        const MapParams32 in = {q.icx, q.icy, q.ifx, q.ify, q.r[2], q.r[5], q.r[8]};  // unscaled
+        map_pixel_ex<MODE>(in, q, ct, rt, vx, vy, mx, my);
+    }
+    const Tap t = quantise(mx, my);
+    int B = 0, G = 0, R = 0;
+    if (!(t.far || t.X >= a.sw || t.X + 1 < 0 || t.Y >= a.sh || t.Y + 1 < 0)) {
+        const int w00 = (32 - t.fx) * (32 - t.fy), w01 = t.fx * (32 - t.fy), w10 = (32 - t.fx) * t.fy, w11 = t.fx * t.fy;
+        int b0, g0, r0, b1, g1, r1, b2, g2, r2, b3, g3, r3;
+        fetch_tap10(a, t.X, t.Y, b0, g0, r0);
+        fetch_tap10(a, t.X + 1, t.Y, b1, g1, r1);
+        fetch_tap10(a, t.X, t.Y + 1, b2, g2, r2);
+        fetch_tap10(a, t.X + 1, t.Y + 1, b3, g3, r3);
+        if constexpr (BLEND == VSTAB_BLEND_FP16) {
+            B = blend_fp16(b0, b1, b2, b3, w00, w01, w10, w11);
+            G = blend_fp16(g0, g1, g2, g3, w00, w01, w10, w11);
+            R = blend_fp16(r0, r1, r2, r3, w00, w01, w10, w11);
+        } else {
+            B = (b0 * w00 + b1 * w01 + b2 * w10 + b3 * w11 + 512) >> 10;
+            G = (g0 * w00 + g1 * w01 + g2 * w10 + g3 * w11 + 512) >> 10;
+            R = (r0 * w00 + r1 * w01 + r2 * w10 + r3 * w11 + 512) >> 10;
+        }
+    }
+    uint16_t *o = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(a.dst) + (size_t)y * a.pitch_dst) + 3 * (size_t)x;
+    o[0] = (uint16_t)B, o[1] = (uint16_t)G, o[2] = (uint16_t)R;
+}
+
+}  // namespace vstab
+
+using namespace vstab;
+
+extern "C" vstab_status vstab_warp_p010(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh, const float params[17],
+                                        const float *rot_bottom, int map_mode, int blend, void *dst, size_t pitch_dst, int dw, int dh, void *stream) {
+    if (!y || !uv || !dst || !params) return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: null pointer");
+    if (sw <= 0 || sh <= 0 || (sw & 1) || (sh & 1) || dw <= 0 || dh <= 0 || sw > 32767 || sh > 32767 || dw > 32767 || dh > 32767)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: sizes must be in [1, 32767], source even");
+    if (pitch_y < (size_t)sw * 2 || pitch_uv < (size_t)sw * 2 || pitch_dst < (size_t)dw * 6 || pitch_y % 2 || pitch_uv % 4 || pitch_dst % 2 ||
+        reinterpret_cast<uintptr_t>(y) % 2 || reinterpret_cast<uintptr_t>(uv) % 4 || reinterpret_cast<uintptr_t>(dst) % 2)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: bad pitch or alignment (16-bit samples; chroma pairs 4-byte aligned)");
+    if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_RECT_TO_FISH) return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: unknown map mode");
+    if (blend != VSTAB_BLEND_EXACT && blend != VSTAB_BLEND_FP16) return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: unknown blend");
+    P010Args a;
+    a.y = static_cast<const uint8_t *>(y), a.uv = static_cast<const uint8_t *>(uv), a.dst = static_cast<uint16_t *>(dst);
+    a.pitch_y = pitch_y, a.pitch_uv = pitch_uv, a.pitch_dst = pitch_dst;
+    a.sw = sw, a.sh = sh, a.dw = dw, a.dh = dh;
+    a.p = {params[0], params[1], params[2], params[3], params[4], params[5], params[6], params[7],
+           {params[8], params[9], params[10], params[11], params[12], params[13], params[14], params[15], params[16]}};
+    a.rs = rot_bottom != nullptr;
+    for (int k = 0; k < 9; k++) a.rs_d[k] = rot_bottom ? rot_bottom[k] - params[8 + k] : 0.0f;
+    a.rs_den = (float)(dh > 1 ? dh - 1 : 1);
+    const dim3 grid(div_up(dw, 64), div_up(dh, 4));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define VSTAB_LAUNCH(M)                                                                  \
+    if (blend == VSTAB_BLEND_FP16)                                                       \
+        hipLaunchKernelGGL((k_warp_p010<M, VSTAB_BLEND_FP16>), grid, dim3(256), 0, s, a); \
+    else                                                                                 \
+        hipLaunchKernelGGL((k_warp_p010<M, VSTAB_BLEND_EXACT>), grid, dim3(256), 0, s, a)
+    switch (map_mode) {
+        case VSTAB_MAP_CREATEMAP_CL: VSTAB_LAUNCH(MAP_CREATEMAP_CL); break;
+        case VSTAB_MAP_FISH_TO_RECT: VSTAB_LAUNCH(MAP_FISH_TO_RECT); break;
+        case VSTAB_MAP_FISH_TO_FISH: VSTAB_LAUNCH(MAP_FISH_TO_FISH); break;
+        case VSTAB_MAP_RECT_TO_RECT: VSTAB_LAUNCH(MAP_RECT_TO_RECT); break;
+        default: VSTAB_LAUNCH(MAP_RECT_TO_FISH); break;
+    }
+#undef VSTAB_LAUNCH
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
