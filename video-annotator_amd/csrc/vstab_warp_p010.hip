@@ -1,6 +1,6 @@
 // vstab_warp_p010.hip -- BASELINE.json config 5: the undistort-remap with a 10-bit pixel path.
 // No reference counterpart (the reference is 8-bit throughout): the arithmetic is DEFINED in the oracle
-// (vo_warp_p010) and reproduced here bit for bit.
+// (its warp_p010 chain) and reproduced here bit for bit.
 //   P010 planes (16-bit samples, 10 significant bits at the top)  ->  sample >> 6
 //   BT.601 limited range at 10 bits: the 8-bit cvtColor constants and shift with offsets 64 / 512 (64-bit sums:
 //     959 * CY + 511 * CUB exceeds int32)  ->  B, G, R in [0, 1023]
