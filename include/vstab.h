@@ -335,6 +335,11 @@ typedef struct vstab_config {
     double out_cy;       /* out_fy; negative = out_height / 2 */
     int debug;           /* debug (render.ts:678): mark the features tracked into each emitted frame (green 7x7 squares;
                             luma 235 in NV12 output) at the positions the warp sends them to.  Works in both lens modes. */
+    int pixel_depth;     /* 8 (default, 0 = 8): the reference's 8-bit path; P010 input is narrowed on ingest.  10 (BASELINE.json
+                            config 5): upstream must hand P010 device frames (vstab_frame.bit_depth > 8); the tracker runs on
+                            the narrowed luma exactly as in the 8-bit path, the frame is warped from the 16-bit planes with
+                            vstab_warp_p010 and emitted by vstab_pull_frame_bgr16. */
+    int blend;           /* pixel_depth 10: VSTAB_BLEND_EXACT (default) or VSTAB_BLEND_FP16 */
 } vstab_config;
 
 typedef struct vstab_handle vstab_handle;
@@ -361,6 +366,9 @@ VSTAB_API vstab_status vstab_pull_frame_nv12(vstab_handle *h, void *dst_y, size_
 /* pull_frame into HOST memory (what a cv::Mat / imshow consumer of DisplayImage.cpp:63-65 needs): the frame is warped
  * into a buffer of the handle and copied out; returns when the copy has completed. */
 VSTAB_API vstab_status vstab_pull_frame_host(vstab_handle *h, void *dst_bgr_host, size_t pitch_dst);
+/* pull_frame of a handle created with pixel_depth = 10: device BGR, three 16-bit samples per pixel (values 0..1023),
+ * pitch_dst in bytes, >= 6 * width and even.  The 8-bit pull functions refuse such a handle and vice versa. */
+VSTAB_API vstab_status vstab_pull_frame_bgr16(vstab_handle *h, void *dst_bgr16, size_t pitch_dst);
 /* FrameSourceWarp::peek_frame (:478-480) IS pull_frame in the reference (destructive); kept. */
 VSTAB_API vstab_status vstab_peek_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
 VSTAB_API void vstab_destroy(vstab_handle *h);

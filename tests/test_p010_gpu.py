@@ -91,3 +91,76 @@ def test_p010_warp_at_4k_config5(vs, cuda):
     b8 = vs.warp_nv12_rs(torch.from_numpy(f8).to(cuda), p, rb, cw, ch).cpu().numpy().astype(np.int32)
     d8 = np.abs((exact.astype(np.int32) >> 2) - b8)
     assert d8.max() <= 4 and d8.mean() < 1.0
+
+
+def test_pipeline_object_with_10bit_pixels(vs, cuda):
+    """vstab_config.pixel_depth = 10: the tracker sees the narrowed luma, so every decision and rotation equals the 8-bit
+    pipeline's on the narrowed clip; each emitted frame is vstab_warp_p010 of the ORIGINAL 16-bit planes under that
+    rotation (checked against the oracle's definition), for both blends."""
+    import ctypes
+    import torch
+    import synth
+    W, H, n, r = 640, 360, 12, 3
+    K = oracle.get_preset_camera(4, W, H)
+    frames8, _ = synth.shaky_clip(3, K, W, H, n, sigma=0.004)
+    rng = np.random.default_rng(9)
+    # P010 planes whose top 8 bits are the 8-bit clip (what vstab_pack_p010 narrows to), with two more bits of detail and junk below
+    wide = [((f.astype(np.uint16) << 8) | (rng.integers(0, 4, f.shape, dtype=np.uint16) << 6) | rng.integers(0, 64, f.shape, dtype=np.uint16)) for f in frames8]
+    dev = [torch.from_numpy(x.view(np.int16)).to(cuda) for x in wide]
+    Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
+
+    def run(depth, blend):
+        state = {"i": 0}
+
+        def fill(out, advance):
+            i = state["i"]
+            if i >= n:
+                return vs.EOF
+            t = dev[i]
+            o = out.contents
+            o.y, o.uv = t.data_ptr(), t.data_ptr() + H * t.stride(0) * 2
+            o.pitch_y = o.pitch_uv = t.stride(0) * 2
+            o.width, o.height, o.mem, o.pts, o.hold, o.bit_depth = W, H, 0, i, 0, 10
+            if advance:
+                state["i"] += 1
+            return 0
+        pull = vs.PULL_FN(lambda u, o: fill(o, True))
+        peek = vs.PULL_FN(lambda u, o: fill(o, False))
+        src = vs.Source(pull, peek, None)
+        cfg = vs.default_config(smooth_radius=r, seed=5, pixel_depth=depth, blend=blend)
+        h = ctypes.c_void_p()
+        assert vs.lib.vstab_create(ctypes.byref(cfg), ctypes.byref(src), ctypes.byref(h)) == vs.OK, vs.lib.vstab_last_error()
+        outs, rots = [], []
+        while True:
+            if depth == 10:
+                o = torch.empty((ch, cw, 3), dtype=torch.int16, device=cuda)
+                st = vs.lib.vstab_pull_frame_bgr16(h, o.data_ptr(), o.stride(0) * 2)
+            else:
+                o = torch.empty((ch, cw, 3), dtype=torch.uint8, device=cuda)
+                st = vs.lib.vstab_pull_frame(h, o.data_ptr(), o.stride(0))
+            if st == vs.EOF:
+                break
+            assert st == vs.OK, vs.lib.vstab_last_error()
+            outs.append(o.cpu().numpy())
+            R = np.zeros(9)
+            assert vs.lib.vstab_get_warp_rotation(h, len(outs) - 1, R.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == vs.OK
+            rots.append(R.reshape(3, 3))
+        # the wrong pull function for the handle is refused
+        o8 = torch.empty((ch, cw, 3), dtype=torch.uint8, device=cuda)
+        o16 = torch.empty((ch, cw, 3), dtype=torch.int16, device=cuda)
+        if depth == 10:
+            assert vs.lib.vstab_pull_frame(h, o8.data_ptr(), o8.stride(0)) == vs.ERR_INVALID
+        else:
+            assert vs.lib.vstab_pull_frame_bgr16(h, o16.data_ptr(), o16.stride(0) * 2) == vs.ERR_INVALID
+        vs.lib.vstab_destroy(h)
+        return outs, rots
+    outs8, rots8 = run(8, 0)
+    for blend in (vs.BLEND_EXACT, vs.BLEND_FP16):
+        outs, rots = run(10, blend)
+        assert len(outs) == len(outs8) == n - 1
+        for i in range(n - 1):
+            assert np.array_equal(rots[i], rots8[i]), i                     # same tracker input -> same rotations, to the bit
+            p = oracle.map_params(K, Ko, rots[i])
+            y16, uv16 = wide[i + 1][:H], wide[i + 1][H:]
+            assert np.array_equal(outs[i].view(np.uint16), oracle.warp_p010(y16, uv16, p, cw, ch, None, 0, blend)), (blend, i)
+    assert max(oracle.rotation_angle(R) for R in rots8) > 1e-4

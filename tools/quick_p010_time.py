@@ -1,0 +1,29 @@
+"""Time vstab_warp_p010 alone at 4K (config 5 operator): exact / fp16 blend, with and without a rotation per row."""
+import os, sys, importlib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np, torch
+import oracle
+vs = importlib.import_module("video-annotator_amd")
+w, h = 3840, 2160
+K = oracle.get_preset_camera(4, w, h)
+Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
+rng = np.random.default_rng(0)
+ys = [torch.from_numpy((rng.integers(0, 1024, (h, w), dtype=np.uint16) << 6).view(np.int16)).cuda() for _ in range(8)]
+us = [torch.from_numpy((rng.integers(0, 1024, (h // 2, w), dtype=np.uint16) << 6).view(np.int16)).cuda() for _ in range(8)]
+outs = [torch.empty((ch, cw, 3), dtype=torch.int16, device="cuda") for _ in range(8)]
+p = oracle.map_params(K, Ko, oracle.rodrigues((0.004, -0.002, 0.001)))
+rb = oracle.map_params(K, Ko, oracle.rodrigues((0.006, -0.001, 0.002)))[8:]
+for name, blend, rot in (("exact", 0, None), ("fp16", 1, None), ("exact+rs", 0, rb), ("fp16+rs", 1, rb)):
+    for i in range(8):
+        vs.warp_p010(ys[i], us[i], p, cw, ch, rot, 0, blend, out=outs[i])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = 80
+    for i in range(n):
+        vs.warp_p010(ys[i % 8], us[i % 8], p, cw, ch, rot, 0, blend, out=outs[i % 8])
+    e1.record(); torch.cuda.synchronize()
+    us_per = e0.elapsed_time(e1) * 1e3 / n
+    algo = w * h * 3 + cw * ch * 6
+    print(f"{name:9s} {us_per:7.1f} us per 4K frame  -> {algo / us_per / 1e3:7.1f} GB/s algorithmic ({algo/1e6:.1f} MB)")

@@ -56,7 +56,8 @@ class Config(_c.Structure):  # vstab_config
     _fields_ = [("preset", _i), ("scale", _d), ("crop_borders", _i), ("zoom", _d), ("smooth_radius", _i),
                 ("interpolation", _i), ("smoother", _i), ("tracking", _i), ("seed", _u64), ("stream", _vp),
                 ("lens_mode", _i), ("in_projection", _i), ("out_projection", _i), ("in_dfov", _d), ("out_dfov", _d),
-                ("out_width", _i), ("out_height", _i), ("out_cx", _d), ("out_cy", _d), ("debug", _i)]
+                ("out_width", _i), ("out_height", _i), ("out_cx", _d), ("out_cy", _d), ("debug", _i), ("pixel_depth", _i),
+                ("blend", _i)]
 
 
 class FrameLog(_c.Structure):  # vstab_frame_log
@@ -103,6 +104,7 @@ SIGNATURES = {
     "vstab_pyr_down": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp]),
     "vstab_min_eig": (_i, [_vp, _sz, _i, _i, _vp, _vp]),
     "vstab_good_features": (_i, [_vp, _sz, _i, _i, _i, _d, _d, _fp, _ip, _vp]),
+    "vstab_pull_frame_bgr16": (_i, [_vp, _vp, _sz]),
     "vstab_warp_p010": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _fp, _i, _i, _vp, _sz, _i, _i, _vp]),
     "vstab_good_features_ex": (_i, [_vp, _sz, _i, _i, _i, _d, _d, _i, _fp, _ip, _ip, _vp]),
     "vstab_pyr_lk": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _fp, _u8p, _vp]),
@@ -555,6 +557,14 @@ class Stabilizer:
         import torch
         out = torch.empty((self.out_size[1], self.out_size[0], 3), dtype=torch.uint8, device="cuda")
         return out if self.pull_into(out) else None
+
+    def pull_bgr16_into(self, out):
+        """pixel_depth = 10 handles: out is a (h, w, 3) int16 CUDA tensor; values 0..1023."""
+        st = _L.vstab_pull_frame_bgr16(self._h, out.data_ptr(), out.stride(0) * 2)
+        if st == EOF:
+            return False
+        _check(st, "vstab_pull_frame_bgr16")
+        return True
 
     def pull_host(self):
         """-> (h, w, 3) numpy array in host memory, or None at end of stream."""

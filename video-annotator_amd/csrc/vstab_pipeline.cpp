@@ -600,6 +600,7 @@ struct vstab_handle {
         std::vector<float> feats;  // vstab_config.debug: the features tracked into this frame (input pixels)
         bool have_delta = false;  // upstream supplied this frame's rotation since the previous frame (vstab_frame.delta_rotation)
         Mat3 delta;
+        DevBuf buf16;  // pixel_depth 10: the frame's P010 planes (luma rows of 2w bytes, then chroma), copied on ingest
         bool have_readout = false;  // ... and the rotation during the frame's read-out (vstab_frame.readout_rotation): rolling-shutter warp
         Mat3 readout;
         bool queued = false, last = false;
@@ -854,8 +855,16 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
         VSTAB_TRY(vstab_handle::wait_if_pending(H->pstream, H->warp_events[S.warped]));
         S.warp_pending = false, S.warped = -1;
     }
+    if (H->cfg.pixel_depth == 10 && !wide) return fail(VSTAB_ERR_INVALID, "a pixel_depth 10 handle needs P010 device frames (vstab_frame.bit_depth > 8)");
     if (wide) {
         VSTAB_TRY(vstab_pack_p010(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->pstream));
+        if (H->cfg.pixel_depth == 10) {  // the warp reads the 16-bit planes; the tracker the narrowed luma above
+            const size_t row = (size_t)H->w * 2;
+            VSTAB_TRY(S.buf16.ensure(row * H->h * 3 / 2));
+            uint8_t *d16 = S.buf16.as<uint8_t>();
+            VSTAB_HIP_TRY(hipMemcpy2DAsync(d16, row, f.y, f.pitch_y, row, H->h, hipMemcpyDeviceToDevice, H->pstream));
+            VSTAB_HIP_TRY(hipMemcpy2DAsync(d16 + row * H->h, row, f.uv, f.pitch_uv, row, H->h / 2, hipMemcpyDeviceToDevice, H->pstream));
+        }
     } else if (f.mem == 0) {
         VSTAB_TRY(vstab_pack_nv12(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->pstream));
     } else {
@@ -938,8 +947,8 @@ static vstab_status prefetch_next(vstab_handle *H) {
     if (f.delta_rotation) std::memcpy(H->slots[slot].delta.m, f.delta_rotation, sizeof(double) * 9);
     H->slots[slot].have_readout = f.readout_rotation != nullptr;
     if (f.readout_rotation) {
-        if (H->map_mode != VSTAB_MAP_CREATEMAP_CL && H->map_mode != VSTAB_MAP_FISH_TO_RECT)
-            return fail(VSTAB_ERR_INVALID, "vstab_frame.readout_rotation: the rolling-shutter warp exists for the preset and fisheye -> rectilinear maps only");
+        if (H->cfg.pixel_depth != 10 && H->map_mode != VSTAB_MAP_CREATEMAP_CL && H->map_mode != VSTAB_MAP_FISH_TO_RECT)
+            return fail(VSTAB_ERR_INVALID, "vstab_frame.readout_rotation: the 8-bit rolling-shutter warp exists for the preset and fisheye -> rectilinear maps only");
         std::memcpy(H->slots[slot].readout.m, f.readout_rotation, sizeof(double) * 9);
     }
     H->slots[slot].ingest_serial = ++H->ingest_serial;
@@ -1164,6 +1173,7 @@ void vstab_config_default(vstab_config *cfg) {
     cfg->interpolation = 1, cfg->smoother = VSTAB_SMOOTHER_SG, cfg->tracking = 1, cfg->seed = 1, cfg->stream = nullptr;
     cfg->lens_mode = 0, cfg->in_projection = VSTAB_PROJ_FISH, cfg->out_projection = VSTAB_PROJ_RECT;
     cfg->in_dfov = 0, cfg->out_dfov = 0, cfg->out_width = 0, cfg->out_height = 0, cfg->out_cx = -1, cfg->out_cy = -1, cfg->debug = 0;
+    cfg->pixel_depth = 8, cfg->blend = VSTAB_BLEND_EXACT;
 }
 
 vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vstab_handle **out) {
@@ -1173,6 +1183,8 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (!(cfg->scale > 0) || !(cfg->zoom > 0)) return fail(VSTAB_ERR_INVALID, "vstab_create: scale and zoom must be positive");
     if (cfg->smoother < VSTAB_SMOOTHER_SG || cfg->smoother > VSTAB_SMOOTHER_FIXED) return fail(VSTAB_ERR_INVALID, "vstab_create: unknown smoother");
     if (cfg->lens_mode != 0 && cfg->lens_mode != 1) return fail(VSTAB_ERR_INVALID, "vstab_create: lens_mode must be 0 or 1");
+    if (cfg->pixel_depth != 0 && cfg->pixel_depth != 8 && cfg->pixel_depth != 10) return fail(VSTAB_ERR_INVALID, "vstab_create: pixel_depth must be 8 or 10");
+    if (cfg->blend != VSTAB_BLEND_EXACT && cfg->blend != VSTAB_BLEND_FP16) return fail(VSTAB_ERR_INVALID, "vstab_create: unknown blend");
     std::unique_ptr<vstab_handle> H(new vstab_handle);
     H->cfg = *cfg, H->src = *src;
     H->rng = Pcg32(cfg->seed);
@@ -1243,9 +1255,13 @@ vstab_status vstab_get_output_info(const vstab_handle *h, int *width, int *heigh
 
 }  // extern "C"
 
+constexpr int OUT_BGR16 = 2;  // internal: the 10-bit path's output (vstab_pull_frame_bgr16)
+
 // FrameSourceWarp::pull_frame, :452-476
 static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, size_t pitch_dst, void *dst_uv, size_t pitch_dst_uv) {
     if (!H || !dst || (out_format == VSTAB_OUT_NV12 && !dst_uv)) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: null argument");
+    if ((H->cfg.pixel_depth == 10) != (out_format == OUT_BGR16))
+        return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: a pixel_depth 10 handle emits through vstab_pull_frame_bgr16, an 8-bit handle through the others");
     HT t_total(HostTimers::TOTAL);
     while (H->queue.size() <= (size_t)H->cfg.smooth_radius) {  // :453
         // 1. LK results of the frame in flight -> surviving corners; its rotation estimate starts on the
@@ -1308,7 +1324,7 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
     float p_bottom[17];
     if (S.have_readout) map_params(H->Kin, H->Kout, S.readout * warp_R, p_bottom);
     bool cached = false;
-    if (H->map_cache && !S.have_readout) {
+    if (H->map_cache && !S.have_readout && out_format != OUT_BGR16) {
         if (H->qmap_valid && std::memcmp(p, H->qmap_params, sizeof(p)) == 0) {
             cached = true;
         } else if (H->have_last_params && std::memcmp(p, H->last_params, sizeof(p)) == 0) {
@@ -1329,7 +1345,10 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         // the profiling events bracket the launch call and nothing else, so the interval is the kernel
         // (plus its dispatch), not host work between two API calls
         GpuStage gs(H, vstab_handle::ST_WARP);
-        if (cached)
+        if (out_format == OUT_BGR16)
+            st = vstab_warp_p010(S.buf16.p, (size_t)H->w * 2, S.buf16.as<uint8_t>() + (size_t)H->w * 2 * H->h, (size_t)H->w * 2, H->w, H->h, p,
+                                 S.have_readout ? p_bottom + 8 : nullptr, H->map_mode, H->cfg.blend, dst, pitch_dst, H->ow, H->oh, H->stream);
+        else if (cached)
             st = vstab_warp_nv12_mapped(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, H->qmap.p, out_format, dst, pitch_dst, dst_uv, pitch_dst_uv,
                                         H->ow, H->oh, H->stream);
         else if (S.have_readout)
@@ -1339,7 +1358,7 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
             st = vstab_warp_nv12_ex(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, p, H->map_mode, out_format, dst,
                                     pitch_dst, dst_uv, pitch_dst_uv, H->ow, H->oh, H->stream);
     }
-    if (st == VSTAB_OK && H->cfg.debug && !S.feats.empty()) {
+    if (st == VSTAB_OK && H->cfg.debug && !S.feats.empty() && out_format != OUT_BGR16) {  // (markers are drawn into 8-bit outputs)
         // where the warp sends each tracked feature: input pixel -> ray -> R^T -> output projection (the inverse of the map)
         constexpr int SETS = 16, CAP = 256;
         VSTAB_TRY(H->marker_pts.ensure(sizeof(int) * 2 * CAP * SETS));
@@ -1403,6 +1422,10 @@ vstab_status vstab_pull_frame_host(vstab_handle *h, void *dst, size_t pitch_dst)
     VSTAB_HIP_TRY(hipMemcpy2DAsync(dst, pitch_dst, h->host_out.p, dpitch, (size_t)h->ow * 3, h->oh, hipMemcpyDeviceToHost, h->stream));
     VSTAB_HIP_TRY(hipStreamSynchronize(h->stream));
     return VSTAB_OK;
+}
+
+vstab_status vstab_pull_frame_bgr16(vstab_handle *h, void *dst, size_t pitch_dst) {
+    return pull_frame_impl(h, OUT_BGR16, dst, pitch_dst, nullptr, 0);
 }
 
 vstab_status vstab_pull_frame_nv12(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv) {
