@@ -48,7 +48,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4, help="untimed steps ahead of the timed region")
     ap.add_argument("--batch", type=int, default=64, help="frames per step (one pass over the input ring by default)")
     ap.add_argument("--preroll", type=int, default=256, help="untimed frames ahead of --warmup (pipeline mode): steady state before the driver's window")
-    ap.add_argument("--workload", default="4k", choices=["4k", "1080p"])
+    ap.add_argument("--workload", default="4k", choices=["4k", "1080p", "4k-p010"],
+                    help="4k-p010 = BASELINE config 5: P010 frames, 10-bit pixel path with fp16 blend, a read-out rotation per frame")
     ap.add_argument("--mode", default="auto", choices=["auto", "warp", "pipeline"])
     ap.add_argument("--ring", type=int, default=64, help="distinct input frames / output buffers")
     ap.add_argument("--no-tracking", action="store_true",
@@ -154,6 +155,24 @@ def cpu_baseline(w, h, K, Ko, cw, ch, budget_s=10.0):
     return {"value": round(n / el, 3), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{n} frames of {w}x{h} NV12 -> {cw}x{ch} BGR, undistort-remap only "
                       f"(cvtColor+createMap+remap, identity rotation), OpenMP over rows, {el:.1f} s"}
+
+
+def cpu_baseline_p010(frame16, w, h, K, Ko, cw, ch, budget_s=10.0):
+    """The oracle's definition of the config-5 warp (10-bit conversion, per-row map, fp16 blend) on the host cores."""
+    import oracle
+    p = oracle.map_params(K, Ko, np.eye(3))
+    rb = oracle.map_params(K, Ko, oracle.rodrigues((0.002, 0.001, -0.001)))[8:]
+    y, uv = frame16[:h], frame16[h:]
+    threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    oracle.lib().vo_set_num_threads(threads)
+    oracle.warp_p010(y, uv, p, cw, ch, rb, 0, 1)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        oracle.warp_p010(y, uv, p, cw, ch, rb, 0, 1)
+        n += 1
+    el = time.perf_counter() - t0
+    return {"value": round(n / el, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n} frames of the oracle's 10-bit warp chain (conversion, per-row map planes, fp16 blend) in {el:.1f} s"}
 
 
 def cpu_baseline_full(frames, K, Ko, cw, ch, w, h, budget_s=12.0):
@@ -288,7 +307,11 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
-    w, h = (3840, 2160) if args.workload == "4k" else (1920, 1080)
+    w, h = (1920, 1080) if args.workload == "1080p" else (3840, 2160)
+    p010 = args.workload == "4k-p010"
+    if p010 and (args.mode == "warp" or args.out_format != "bgr" or args.no_tracking):
+        print("bench.py: --workload 4k-p010 runs the full pipeline with 16-bit BGR output", file=sys.stderr)
+        return 2
     preset = vs.GOPRO_H4B_WIDE169_MEASURED
     K = vs.get_preset_camera(preset, w, h)
     Ko, (cw, ch) = vs.get_output_camera(K, w, h, 1.0, False, 1.0)
@@ -302,6 +325,8 @@ def main():
     nv12_out = args.out_format == "nv12"
     if nv12_out:
         outs = [vs.nv12_out_planes(cw, ch, dev) for _ in range(args.ring)]
+    elif p010:
+        outs = [torch.empty((ch, cw, 3), dtype=torch.int16, device=dev) for _ in range(args.ring)]
     else:
         outs = [torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(args.ring)]
     out_name = "NV12" if nv12_out else "BGR"
@@ -334,8 +359,19 @@ def main():
     else:
         clip, _ = shaky_ring(torch, dev, w, h, K, args.ring, seed=rank)
         preroll = max(0, args.preroll)
+        extra, readouts = {}, None
+        if p010:
+            # the 8-bit ring widened to P010: its bytes on top (so the tracker, which sees the narrowed luma, does what it
+            # does in the 8-bit run), two more bits of detail, junk in the six unused bits; plus the camera's rotation
+            # during each frame's read-out (a tenth of the per-frame shake schedule)
+            g = torch.Generator(device=dev).manual_seed(77 + rank)
+            clip = [((f.to(torch.int32) << 8) | torch.randint(0, 256, f.shape, generator=g, device=dev, dtype=torch.int32)).to(torch.int16) for f in clip]
+            readouts = [rot(i) @ rot(i + 1).T for i in range(len(clip))]
+            readouts = [np.eye(3) + 0.1 * (R - np.eye(3)) for R in readouts]
+            readouts = [np.linalg.svd(R)[0] @ np.linalg.svd(R)[2] for R in readouts]   # back onto SO(3)
+            extra = dict(bit_depth=10, readouts=readouts, pixel_depth=10, blend=vs.BLEND_FP16)
         stab = vs.Stabilizer(clip, total=preroll + (args.warmup + args.steps) * args.batch + 1000, preset=preset, smooth_radius=30, seed=1234 + rank,
-                             tracking=0 if args.no_tracking else 1)
+                             tracking=0 if args.no_tracking else 1, **extra)
         assert stab.out_size == (cw, ch)
 
         def step(i, timed):
@@ -344,10 +380,15 @@ def main():
                 stab._prof0 = stab.profile()
             assert pull(i)
         pull = (lambda i: stab.pull_nv12_into(*outs[i % args.ring])) if nv12_out else (lambda i: stab.pull_into(outs[i % args.ring]))
+        if p010:
+            pull = lambda i: stab.pull_bgr16_into(outs[i % args.ring])
         stab.enable_profiling(1)  # timed region: HIP events around the warp launches only
         workload = f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, full pipeline: NV12 ingest, corner detect, pyramidal LK, rotation estimate, SG smoothing (r=30), fused undistort-remap"
         if args.no_tracking:
             workload = f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, undistort only (tracking off, identity rotations): NV12 ingest + fused undistort-remap"
+        if p010:
+            workload = (f"4k P010 {w}x{h} -> BGR 16-bit (10 significant) {cw}x{ch}, BASELINE config 5: full pipeline on the narrowed luma (corner detect, "
+                        "pyramidal LK, rotation estimate, SG r=30), 10-bit undistort-remap with fp16 blend and a rotation per output row")
 
     for i in range(preroll):  # pipeline mode: untimed, ahead of the warm-up the driver asks for
         assert pull(i)
@@ -381,7 +422,11 @@ def main():
         src = clip[(n_emit + 1) % len(clip)].cpu().numpy()
         pr = oracle.map_params(K, Ko, stab.warp_rotation(n_emit))
         got = outs[n_emit % args.ring]
-        if nv12_out:
+        if p010:
+            rb = oracle.map_params(K, Ko, readouts[(n_emit + 1) % len(clip)] @ stab.warp_rotation(n_emit))[8:]
+            s16 = src.view(np.uint16)
+            same = np.array_equal(got.cpu().numpy().view(np.uint16), oracle.warp_p010(s16[:h], s16[h:], pr, cw, ch, rb, 0, 1))
+        elif nv12_out:
             exp_y, exp_uv = oracle.warp_nv12_ex(src, pr, cw, ch, 0, 1)
             same = np.array_equal(got[0].cpu().numpy().reshape(-1), exp_y.reshape(-1)) and np.array_equal(got[1].cpu().numpy().reshape(-1), exp_uv.reshape(-1))
         else:
@@ -432,6 +477,10 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             run_alone = lambda i: vs.warp_nv12(clip[i % len(clip)], pa, cw, ch, vs.MAP_CREATEMAP_CL, vs.OUT_NV12 if nv12_out else vs.OUT_BGR8,
                                                out=outs[i % args.ring])  # cycling inputs and outputs: nothing stays in the caches
+            if p010:
+                pb = vs.map_params(K, Ko, rot(8))[8:]
+                run_alone = lambda i: vs.warp_p010(clip[i % len(clip)][:h], clip[i % len(clip)][h:], pa, cw, ch, pb, vs.MAP_CREATEMAP_CL, vs.BLEND_FP16,
+                                                   out=outs[i % args.ring])
             for i in range(10):
                 run_alone(i)
             torch.cuda.synchronize()
@@ -445,6 +494,9 @@ def main():
         if nv12_out:
             alg_bytes = w * h * 1.5 + cw * ch + 2 * ((cw + 1) // 2) * ((ch + 1) // 2)
         kernel_name = "k_warp_fused"
+        if p010:
+            alg_bytes = w * h * 3 + cw * ch * 6  # P010 read once + 16-bit BGR written once
+            kernel_name = "k_warp_p010<CREATEMAP_CL, FP16> (direct gather)"
         base_bytes = alg_bytes  # of the kernel that evaluates the map (what "alone" runs)
         cached = mode == "pipeline" and args.no_tracking
         if cached:
@@ -458,7 +510,7 @@ def main():
             traffic = float(args.traffic)
         else:
             tf = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-            if os.path.exists(tf) and not nv12_out and not cached:
+            if os.path.exists(tf) and not nv12_out and not cached and not p010:
                 prof = json.load(open(tf))
                 traffic, rocprof_us = prof.get("hbm_bytes_per_launch"), prof.get("rocprof_avg_launch_us")
                 valu_busy = prof.get("valu_busy")  # SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x launch time x shader clock), same PMC passes
@@ -466,7 +518,7 @@ def main():
             "metric": "stabilized frames/sec at 4K NV12, 1/2/4/8 GPU; remap % HBM roofline",
             "value": round(world * n_timed / el, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8 pixels / f32 map / f64 rotations", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": ("u10 pixels (fp16 blend)" if p010 else "u8 pixels") + " / f32 map / f64 rotations", "data": "synthetic",
             "config": {"workload": workload, "mode": mode, "clips": len(records), "ring_frames": args.ring, "frames_per_step": args.batch,
                        "preset": "GOPRO_H4B_WIDE169_MEASURED", "parallelism": f"clip-per-gpu x{world}"},
             "preroll": preroll, "parity_check": parity, "rank_cpus": pinned,
@@ -478,14 +530,16 @@ def main():
                          # the HIP-event bracket also counts dispatch latency while other streams' kernels hold the CUs
                          "rocprof_avg_launch_us_committed": rocprof_us, "valu_busy": valu_busy,
                          "alone": None if alone_us is None else {"avg_launch_us": round(alone_us, 2),
-                                                                   "kernel": "k_warp_fused",
+                                                                   "kernel": "k_warp_p010" if p010 else "k_warp_fused",
                                                                    "achieved": round(base_bytes / alone_us / 1e3, 1),
                                                                    "frac": round(base_bytes / alone_us / 1e3 / HBM_PEAK_GBS, 4)}},
         }
         if stages:
             line["stages"] = stages  # every GPU stage timed (extra pass outside the timed region; chained LK launches off)
             line["stages_timed_region"] = timed_stages  # host waits + warp launches as they were in the timed region
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and p010:
+            line["cpu_baseline"] = cpu_baseline_p010(clip[0].cpu().numpy().view(np.uint16), w, h, K, Ko, cw, ch)
+        elif world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, h, K, Ko, cw, ch)
             if mode == "pipeline" and not args.no_tracking:
                 host_ring = [f.cpu().numpy() for f in clip]

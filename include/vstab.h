@@ -413,6 +413,12 @@ typedef struct vstab_ring_source vstab_ring_source;
 VSTAB_API vstab_status vstab_ring_source_create(const void *const *frames, int n_frames, int width, int height,
                                                 size_t pitch, long total_frames, vstab_ring_source **out,
                                                 vstab_source *as_source);
+/* The same for P010-style frames (bit_depth 10 / 12 / 16: 16-bit samples, pitch in bytes, chroma plane at
+ * frame + pitch * height) and/or with a read-out rotation per ring frame (9 doubles each, copied; may be NULL). */
+VSTAB_API vstab_status vstab_ring_source_create_ex(const void *const *frames, int n_frames, int width, int height,
+                                                   size_t pitch, long total_frames, int bit_depth,
+                                                   const double *readout_rotations, vstab_ring_source **out,
+                                                   vstab_source *as_source);
 VSTAB_API void vstab_ring_source_destroy(vstab_ring_source *s);
 
 #ifdef __cplusplus

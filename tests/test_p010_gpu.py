@@ -164,3 +164,32 @@ def test_pipeline_object_with_10bit_pixels(vs, cuda):
             y16, uv16 = wide[i + 1][:H], wide[i + 1][H:]
             assert np.array_equal(outs[i].view(np.uint16), oracle.warp_p010(y16, uv16, p, cw, ch, None, 0, blend)), (blend, i)
     assert max(oracle.rotation_angle(R) for R in rots8) > 1e-4
+
+
+def test_p010_ring_source_with_readout_rotations(vs, cuda):
+    """vstab_ring_source_create_ex (what bench.py --workload 4k-p010 drives): P010 ring frames used in place, a read-out
+    rotation per ring frame, fp16 blend; every emitted frame against the oracle under the rotations the handle reports."""
+    import torch
+    import synth
+    W, H, n, r = 640, 360, 10, 2
+    K = oracle.get_preset_camera(4, W, H)
+    Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
+    frames8, _ = synth.shaky_clip(5, K, W, H, n, sigma=0.004)
+    rng = np.random.default_rng(4)
+    wide = [((f.astype(np.uint16) << 8) | rng.integers(0, 256, f.shape, dtype=np.uint16)) for f in frames8]
+    dev = [torch.from_numpy(x.view(np.int16)).to(cuda) for x in wide]
+    readouts = [oracle.rodrigues(np.array([0.003 * np.sin(k), -0.002 * np.cos(k), 0.004 * np.sin(2 * k + 1)])) for k in range(n)]
+    stab = vs.Stabilizer(dev, total=n, bit_depth=10, readouts=readouts, smooth_radius=r, seed=3, pixel_depth=10, blend=vs.BLEND_FP16)
+    assert stab.out_size == (cw, ch)
+    i = 0
+    while True:
+        o = torch.empty((ch, cw, 3), dtype=torch.int16, device=cuda)
+        if not stab.pull_bgr16_into(o):
+            break
+        Wr = stab.warp_rotation(i)
+        p = oracle.map_params(K, Ko, Wr)
+        rb = oracle.map_params(K, Ko, readouts[i + 1] @ Wr)[8:]
+        exp = oracle.warp_p010(wide[i + 1][:H], wide[i + 1][H:], p, cw, ch, rb, 0, 1)
+        assert np.array_equal(o.cpu().numpy().view(np.uint16), exp), i
+        i += 1
+    assert i == n - 1

@@ -129,6 +129,7 @@ SIGNATURES = {
     "vstab_enable_profiling": (_i, [_vp, _i]),
     "vstab_get_profile": (_i, [_vp, _c.POINTER(Profile)]),
     "vstab_ring_source_create": (_i, [_pp, _i, _i, _i, _sz, _c.c_long, _pp, _c.POINTER(Source)]),
+    "vstab_ring_source_create_ex": (_i, [_c.POINTER(_vp), _i, _i, _i, _sz, _c.c_long, _i, _dp, _c.POINTER(_vp), _c.POINTER(Source)]),
     "vstab_ring_source_destroy": (None, [_vp]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
@@ -492,9 +493,11 @@ class Stabilizer:
     """vstab_handle wrapper.  `frames`: list of packed NV12 CUDA tensors (cycled by the C ring
     source for `total` pulls) or a Python iterable of such tensors (python callback source)."""
 
-    def __init__(self, frames, total=None, use_torch_stream=True, hold=12, **cfg_kw):
+    def __init__(self, frames, total=None, use_torch_stream=True, hold=12, bit_depth=8, readouts=None, **cfg_kw):
         """hold (iterable sources): vstab_frame.hold -- how many further pulls each tensor is kept alive and unchanged
-        for; from smooth_radius + 14 on the library uses the tensors in place instead of copying them."""
+        for; from smooth_radius + 14 on the library uses the tensors in place instead of copying them.
+        bit_depth / readouts (list sources): P010 frames as int16 tensors of shape (h * 3 / 2, w); one 3x3 read-out
+        rotation per ring frame (vstab_frame.readout_rotation)."""
         import torch
         self._keep = []
         self._src = Source()
@@ -506,8 +509,11 @@ class Stabilizer:
             ptrs = (_vp * len(frames))(*[f.data_ptr() for f in frames])
             self._keep += [frames, ptrs]
             self._ring = _vp()
-            _check(_L.vstab_ring_source_create(ptrs, len(frames), w, h, f0.stride(0), len(frames) if total is None else total,
-                                               _c.byref(self._ring), _c.byref(self._src)), "vstab_ring_source_create")
+            ro = None if readouts is None else np.ascontiguousarray(np.stack([np.asarray(r, np.float64).reshape(9) for r in readouts]))
+            assert ro is None or ro.shape == (len(frames), 9)
+            _check(_L.vstab_ring_source_create_ex(ptrs, len(frames), w, h, f0.stride(0) * f0.element_size(), len(frames) if total is None else total,
+                                                  int(bit_depth), None if ro is None else _dptr(ro), _c.byref(self._ring), _c.byref(self._src)),
+                   "vstab_ring_source_create_ex")
         else:
             it = iter(frames)
             state = {"next": None, "done": False}

@@ -600,7 +600,9 @@ struct vstab_handle {
         std::vector<float> feats;  // vstab_config.debug: the features tracked into this frame (input pixels)
         bool have_delta = false;  // upstream supplied this frame's rotation since the previous frame (vstab_frame.delta_rotation)
         Mat3 delta;
-        DevBuf buf16;  // pixel_depth 10: the frame's P010 planes (luma rows of 2w bytes, then chroma), copied on ingest
+        DevBuf buf16;  // pixel_depth 10: the frame's P010 planes (luma rows of 2w bytes, then chroma), copied on ingest ...
+        const uint8_t *y16 = nullptr, *uv16 = nullptr;  // ... or left where they are when upstream keeps them for good (hold >= 1 << 29)
+        size_t pitch_y16 = 0, pitch_uv16 = 0;
         bool have_readout = false;  // ... and the rotation during the frame's read-out (vstab_frame.readout_rotation): rolling-shutter warp
         Mat3 readout;
         bool queued = false, last = false;
@@ -860,10 +862,15 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
         VSTAB_TRY(vstab_pack_p010(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->pstream));
         if (H->cfg.pixel_depth == 10) {  // the warp reads the 16-bit planes; the tracker the narrowed luma above
             const size_t row = (size_t)H->w * 2;
-            VSTAB_TRY(S.buf16.ensure(row * H->h * 3 / 2));
-            uint8_t *d16 = S.buf16.as<uint8_t>();
-            VSTAB_HIP_TRY(hipMemcpy2DAsync(d16, row, f.y, f.pitch_y, row, H->h, hipMemcpyDeviceToDevice, H->pstream));
-            VSTAB_HIP_TRY(hipMemcpy2DAsync(d16 + row * H->h, row, f.uv, f.pitch_uv, row, H->h / 2, hipMemcpyDeviceToDevice, H->pstream));
+            if (f.hold >= vstab_handle::HOLD_FOREVER) {
+                S.y16 = static_cast<const uint8_t *>(f.y), S.uv16 = static_cast<const uint8_t *>(f.uv), S.pitch_y16 = f.pitch_y, S.pitch_uv16 = f.pitch_uv;
+            } else {
+                VSTAB_TRY(S.buf16.ensure(row * H->h * 3 / 2));
+                uint8_t *d16 = S.buf16.as<uint8_t>();
+                VSTAB_HIP_TRY(hipMemcpy2DAsync(d16, row, f.y, f.pitch_y, row, H->h, hipMemcpyDeviceToDevice, H->pstream));
+                VSTAB_HIP_TRY(hipMemcpy2DAsync(d16 + row * H->h, row, f.uv, f.pitch_uv, row, H->h / 2, hipMemcpyDeviceToDevice, H->pstream));
+                S.y16 = d16, S.uv16 = d16 + row * H->h, S.pitch_y16 = S.pitch_uv16 = row;
+            }
         }
     } else if (f.mem == 0) {
         VSTAB_TRY(vstab_pack_nv12(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->pstream));
@@ -1346,7 +1353,7 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         // (plus its dispatch), not host work between two API calls
         GpuStage gs(H, vstab_handle::ST_WARP);
         if (out_format == OUT_BGR16)
-            st = vstab_warp_p010(S.buf16.p, (size_t)H->w * 2, S.buf16.as<uint8_t>() + (size_t)H->w * 2 * H->h, (size_t)H->w * 2, H->w, H->h, p,
+            st = vstab_warp_p010(S.y16, S.pitch_y16, S.uv16, S.pitch_uv16, H->w, H->h, p,
                                  S.have_readout ? p_bottom + 8 : nullptr, H->map_mode, H->cfg.blend, dst, pitch_dst, H->ow, H->oh, H->stream);
         else if (cached)
             st = vstab_warp_nv12_mapped(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, H->qmap.p, out_format, dst, pitch_dst, dst_uv, pitch_dst_uv,
@@ -1494,6 +1501,8 @@ struct vstab_ring_source {
     int w, h;
     size_t pitch;
     long total, pos;
+    int bit_depth = 8;
+    std::vector<double> readout;  // optional: 9 doubles per ring frame (vstab_frame.readout_rotation)
 };
 
 static int ring_fill(vstab_ring_source *s, vstab_frame *out) {
@@ -1502,6 +1511,8 @@ static int ring_fill(vstab_ring_source *s, vstab_frame *out) {
     out->y = p, out->uv = p + s->pitch * s->h, out->pitch_y = out->pitch_uv = s->pitch;
     out->width = s->w, out->height = s->h, out->mem = 0, out->pts = s->pos;
     out->hold = 1 << 30;  // the caller owns the frames for the life of the source and never rewrites them
+    out->bit_depth = s->bit_depth;
+    if (!s->readout.empty()) out->readout_rotation = &s->readout[9 * (size_t)(s->pos % (long)s->frames.size())];
     return 0;
 }
 static int ring_pull(void *user, vstab_frame *out) {
@@ -1521,6 +1532,16 @@ vstab_status vstab_ring_source_create(const void *const *frames, int n_frames, i
     s->w = width, s->h = height, s->pitch = pitch, s->total = total_frames, s->pos = 0;
     as_source->pull = ring_pull, as_source->peek = ring_peek, as_source->user = s;
     *out = s;
+    return VSTAB_OK;
+}
+
+vstab_status vstab_ring_source_create_ex(const void *const *frames, int n_frames, int width, int height, size_t pitch, long total_frames, int bit_depth,
+                                         const double *readout_rotations, vstab_ring_source **out, vstab_source *as_source) {
+    if (bit_depth != 8 && bit_depth != 10 && bit_depth != 12 && bit_depth != 16) return fail(VSTAB_ERR_INVALID, "vstab_ring_source_create: bit_depth must be 8, 10, 12 or 16");
+    if (pitch < (size_t)width * (bit_depth > 8 ? 2 : 1)) return fail(VSTAB_ERR_INVALID, "vstab_ring_source_create: bad argument");
+    VSTAB_TRY(vstab_ring_source_create(frames, n_frames, width, height, pitch, total_frames, out, as_source));
+    (*out)->bit_depth = bit_depth;
+    if (readout_rotations) (*out)->readout.assign(readout_rotations, readout_rotations + 9 * (size_t)n_frames);
     return VSTAB_OK;
 }
 
