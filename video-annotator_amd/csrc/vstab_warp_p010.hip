@@ -2,8 +2,8 @@
 // No reference counterpart (the reference is 8-bit throughout): the arithmetic is DEFINED in the oracle
 // (its warp_p010 chain) and reproduced here bit for bit.
 //   P010 planes (16-bit samples, 10 significant bits at the top)  ->  sample >> 6
-//   BT.601 limited range at 10 bits: the 8-bit cvtColor constants and shift with offsets 64 / 512 (64-bit sums:
-//     959 * CY + 511 * CUB exceeds int32)  ->  B, G, R in [0, 1023]
+//   BT.601 limited range at 10 bits: the 8-bit cvtColor constants and shift with offsets 64 / 512 (the definition sums in
+//     64 bits: 959 * CY + 511 * CUB exceeds int32)  ->  B, G, R in [0, 1023]
 //   the map of vstab_create_map_ex (all five projection pairs), optionally with a rotation per output row
 //     (vstab_warp_nv12_rs's interpolation), quantised like cv::remap
 //   blend of the four converted taps: VSTAB_BLEND_EXACT  (sum p*w + 512) >> 10, integers, as the 8-bit path;
@@ -28,7 +28,11 @@ struct P010Args {
     int rs;
 };
 
-__device__ __forceinline__ int sat10(long long v) { return v < 0 ? 0 : v > 1023 ? 1023 : (int)v; }
+__device__ __forceinline__ int sat10(int v) { return min(max(v, 0), 1023); }
+// luma term + chroma term: the exact sum needs 33 bits (959 * CY + 511 * CUB = 2.25e9), but whenever it exceeds INT_MAX the
+// pixel is saturated anyway ((2^31 - 1) >> 20 = 2047 > 1023), and it never goes below -1.09e9: a saturating 32-bit add
+// (v_add_i32 ... clamp) gives the same channel value as the 64-bit sum of the definition.
+__device__ __forceinline__ int channel10(int yy, int c) { return sat10(__builtin_elementwise_add_sat(yy, c) >> 20); }
 
 // one P010 tap -> B, G, R in [0, 1023]; outside the source -> 0 (BORDER_CONSTANT)
 __device__ __forceinline__ void fetch_tap10(const P010Args &a, int X, int Y, int &b, int &g, int &r) {
@@ -36,10 +40,10 @@ __device__ __forceinline__ void fetch_tap10(const P010Args &a, int X, int Y, int
         const int yv = *reinterpret_cast<const uint16_t *>(a.y + (size_t)Y * a.pitch_y + 2 * (size_t)X) >> 6;
         const uint32_t c = *reinterpret_cast<const uint32_t *>(a.uv + (size_t)(Y >> 1) * a.pitch_uv + 4 * (size_t)(X >> 1));
         const int u = (int)((c & 0xffffu) >> 6) - 512, v = (int)(c >> 22) - 512;
-        const long long yy = (long long)max(yv - 64, 0) * CY;
-        b = sat10((yy + (1 << 19) + (long long)CUB * u) >> 20);
-        g = sat10((yy + (1 << 19) + (long long)CVG * v + (long long)CUG * u) >> 20);
-        r = sat10((yy + (1 << 19) + (long long)CVR * v) >> 20);
+        const int yy = max(yv - 64, 0) * CY;  // <= 959 * 1220542 < 2^31
+        b = channel10(yy, (1 << 19) + CUB * u);
+        g = channel10(yy, (1 << 19) + CVG * v + CUG * u);
+        r = channel10(yy, (1 << 19) + CVR * v);
     } else {
         b = g = r = 0;
     }
