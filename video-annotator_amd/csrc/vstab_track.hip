@@ -453,16 +453,19 @@ __global__ void __launch_bounds__(256) k_filter_keys(const unsigned long long *_
         if (n > CF_SLOTS) {
             if (lane == 0) atomicAdd(&n_spilled, 1u);
             const int ty0 = t / tiles_x, ox = (t - ty0 * tiles_x) * CF_TW, oy = ty0 * CF_TH;
+            float v[CF_TH];  // all 31 rows in flight at once: one memory latency, not 31
+#pragma unroll
+            for (int r = 0; r < CF_TH; r++) v[r] = spill[(size_t)t * (CF_TW * CF_TH) + r * CF_TW + lane];
+#pragma unroll
             for (int r = 0; r < CF_TH; r++) {
-                const float v = spill[(size_t)t * (CF_TW * CF_TH) + r * CF_TW + lane];
-                const bool keep = v > thr;
+                const bool keep = v[r] > thr;
                 const unsigned long long ballot = __ballot(keep);
                 if (ballot) {
                     unsigned int b = 0;
                     if (lane == 0) b = atomicAdd(&counts[0], (unsigned int)__popcll(ballot));
                     b = __builtin_amdgcn_readfirstlane(b);
                     const unsigned int slot = b + __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0));
-                    if (keep && slot < cap_out) out[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)((oy + r) * w + ox + lane);
+                    if (keep && slot < cap_out) out[slot] = ((unsigned long long)__float_as_uint(v[r]) << 32) | (unsigned int)((oy + r) * w + ox + lane);
                 }
             }
             continue;
