@@ -8,6 +8,8 @@ python bench.py --steps 20 --warmup 5 --out-format nv12 --no-cpu-baseline > $O/b
 python bench.py --steps 20 --warmup 5 --no-tracking --no-cpu-baseline > $O/bench_undistort_only_4k.json 2>> $O/bench.err
 python bench.py --workload 1080p --steps 20 --warmup 5 --no-tracking > $O/bench_undistort_only_1080p.json 2>> $O/bench.err
 python bench.py --mode warp --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_warp_only_4k.json 2>> $O/bench.err
+python bench.py --workload 4k-p010 --steps 20 --warmup 5 > $O/bench_pipeline_4k_p010_config5.json 2>> $O/bench.err
+python tools/quick_p010_time.py > $O/p010_operator_times.txt 2>> $O/bench.err
 ./tools/probe_rate > $O/valu_issue_rates.txt 2>&1
 VSTAB_LIB_PATH=video-annotator_amd/lib/libvstab_dev.so python tools/wg_timeline.py > $O/warp_workgroup_timeline.txt 2>&1
 for a in 0 1 2 4 8 3 7 15; do echo "VSTAB_ABLATE=$a"; VSTAB_LIB_PATH=video-annotator_amd/lib/libvstab_dev.so VSTAB_ABLATE=$a python tools/quick_warp_time.py; done > $O/warp_ablations.txt 2>&1
