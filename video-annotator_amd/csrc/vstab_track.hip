@@ -537,12 +537,33 @@ struct LkExchange {
     int part[2][LK_WAVES][6];  // [parity][wave][hi/lo of up to three quantities]
 };
 
+// The 2 * NQ wave reductions advance in lockstep: every DPP step is applied to all of them before the next one, so the
+// two wait states a DPP read needs behind the write of its source are filled by the other chains instead of s_nop
+// (written one chain after the other, the compiler serialised the first pair: 12 steps with a nop each).
+template <int N>
+__device__ __forceinline__ void wave_sums_i32(int (&t)[N]) {
+#define VSTAB_DPP_STEP(ctrl, rows)                                                          \
+    _Pragma("unroll") for (int i = 0; i < N; i++) t[i] += __builtin_amdgcn_update_dpp(0, t[i], ctrl, rows, 0xf, false)
+    VSTAB_DPP_STEP(0x111, 0xf);
+    VSTAB_DPP_STEP(0x112, 0xf);
+    VSTAB_DPP_STEP(0x114, 0xf);
+    VSTAB_DPP_STEP(0x118, 0xf);
+    VSTAB_DPP_STEP(0x142, 0xa);
+    VSTAB_DPP_STEP(0x143, 0xc);
+#undef VSTAB_DPP_STEP
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = __builtin_amdgcn_readlane(t[i], 63);
+}
+
 template <int NQ>
 __device__ __forceinline__ void lk_block_sums(LkExchange &ex, int parity, int wave, int lane, const int (&v)[NQ], float (&out)[NQ]) {
+    int t[2 * NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        const int hi = wave_sum_i32(v[q] >> 16), lo = wave_sum_i32(v[q] & 0xffff);  // uniform (SGPR) results
-        if (lane == 0) ex.part[parity][wave][2 * q] = hi, ex.part[parity][wave][2 * q + 1] = lo;
+    for (int q = 0; q < NQ; q++) t[2 * q] = v[q] >> 16, t[2 * q + 1] = v[q] & 0xffff;
+    wave_sums_i32(t);  // uniform (SGPR) results
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 2 * NQ; i++) ex.part[parity][wave][i] = t[i];
     }
     __syncthreads();
 #pragma unroll
