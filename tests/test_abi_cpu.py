@@ -64,6 +64,19 @@ def test_bad_arguments_are_reported(vs):
     assert vs.lib.vstab_pack_nv12(1, 16, 1, 16, 15, 8, 1, None) == vs.ERR_INVALID
     assert b"Mismatched image dimensions" in vs.lib.vstab_last_error()   # FrameSourceFfmpegOpenCl.cpp:54
     assert vs.lib.vstab_create_map(1, 4, 1, 4, 40000, 1, p, None) == vs.ERR_INVALID
+    # round-2 entry points: the 10-bit operator, the detector choice, the P010 ring source, the 10-bit handle
+    assert vs.lib.vstab_warp_p010(16, 128, 16, 128, 64, 36, p, None, 0, 5, 16, 1024, 10, 10, None) == vs.ERR_INVALID and b"blend" in vs.lib.vstab_last_error()
+    assert vs.lib.vstab_warp_p010(16, 128, 16, 128, 64, 36, p, None, 9, 0, 16, 1024, 10, 10, None) == vs.ERR_INVALID and b"map mode" in vs.lib.vstab_last_error()
+    assert vs.lib.vstab_warp_p010(16, 126, 16, 128, 64, 36, p, None, 0, 0, 16, 1024, 10, 10, None) == vs.ERR_INVALID     # luma pitch < 2 * width
+    assert vs.lib.vstab_warp_p010(16, 128, 18, 128, 64, 36, p, None, 0, 0, 16, 1024, 10, 10, None) == vs.ERR_INVALID     # chroma pairs not 4-byte aligned
+    xy, n = np.zeros(8, np.float32), ctypes.c_int()
+    assert vs.lib.vstab_good_features_ex(16, 64, 64, 36, 4, 0.01, 3.0, 7, xy.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), ctypes.byref(n), None,
+                                         None) == vs.ERR_INVALID
+    ptrs, ring, src = (ctypes.c_void_p * 1)(16), ctypes.c_void_p(), vs.Source()
+    assert vs.lib.vstab_ring_source_create_ex(ptrs, 1, 64, 36, 128, 10, 9, None, ctypes.byref(ring), ctypes.byref(src)) == vs.ERR_INVALID   # bit depth 9
+    assert vs.lib.vstab_ring_source_create_ex(ptrs, 1, 64, 36, 64, 10, 10, None, ctypes.byref(ring), ctypes.byref(src)) == vs.ERR_INVALID   # pitch < 2 * width
+    cfg = vs.default_config(pixel_depth=12)
+    assert (cfg.pixel_depth, vs.default_config().pixel_depth, vs.default_config().blend) == (12, 8, vs.BLEND_EXACT)
 
 
 def test_cameras_match_oracle_and_golden(vs):
