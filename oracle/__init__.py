@@ -75,6 +75,7 @@ def lib():
         L.vo_pyramid_levels.argtypes = [c.c_int, c.c_int]
         L.vo_pyramid_levels.restype = c.c_int
         L.vo_pyr_lk.argtypes = [u8p, c.c_size_t, u8p, c.c_size_t, c.c_int, c.c_int, f32p, c.c_int, f32p, u8p]
+        L.vo_pyr_lk_iterations.argtypes = [u8p, c.c_size_t, u8p, c.c_size_t, c.c_int, c.c_int, f32p, c.c_int, f32p, u8p, c.c_void_p]
         L.vo_pyr_lk.restype = c.c_int
         _LIB = L
     return _LIB
@@ -337,6 +338,21 @@ def cvt_p010_bgr10(y, uv):
     lib().vo_cvt_p010_bgr10(ya.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(ya.strides[0]), ua.ctypes.data_as(ctypes.c_void_p),
                             ctypes.c_size_t(ua.strides[0]), w, h, out.ctypes.data_as(ctypes.c_void_p))
     return out
+
+
+def pyr_lk_iterations(prev, nxt, pts):
+    """pyr_lk plus the Gauss-Newton iterations every feature ran on each pyramid level: -> (next, status, (n, 4) ints)."""
+    a, ap = _u8(prev)
+    b, bp = _u8(nxt)
+    h, w = a.shape
+    p, pp = _f32(np.asarray(pts, np.float32).reshape(-1, 2))
+    n = p.shape[0]
+    out = np.zeros((n, 2), np.float32)
+    st = np.zeros(n, np.uint8)
+    it = np.zeros((n, 4), np.int32)
+    lib().vo_pyr_lk_iterations(ap, a.strides[0], bp, b.strides[0], w, h, pp, n, _p(out, ctypes.c_float), _p(st, ctypes.c_uint8),
+                               it.ctypes.data_as(ctypes.c_void_p))
+    return out, st, it
 
 
 def pyr_lk(prev, nxt, pts):

@@ -773,8 +773,9 @@ static inline int vo_cvfloor(float v) { return (int)floorf(v); }
 static int vo_lk_float_acc = 0;
 VO_API void vo_set_lk_accumulation(int mode) { vo_lk_float_acc = mode != 0; }
 
+/* iters (may be NULL): incremented once per Gauss-Newton iteration this call starts (vo_pyr_lk_iterations) */
 static void vo_lk_point(const vo_level *I, const vo_level *J, int level, int max_level,
-                        const float *prev_pt, float *next_pt, uint8_t *status) {
+                        const float *prev_pt, float *next_pt, uint8_t *status, int *iters) {
     const float half = (VO_LK_WIN - 1) * 0.5f;
     const float lscale = (float)(1.0 / (1 << level));
     float ppx = prev_pt[0] * lscale, ppy = prev_pt[1] * lscale;
@@ -834,6 +835,7 @@ static void vo_lk_point(const vo_level *I, const vo_level *J, int level, int max
     float pdx = 0, pdy = 0;
     const double eps2 = 0.01 * 0.01;
     for (int j = 0; j < 30; j++) {
+        if (iters) ++*iters;
         int inx = vo_cvfloor(npx), iny = vo_cvfloor(npy);
         if (inx < -VO_LK_WIN || inx >= J->w || iny < -VO_LK_WIN || iny >= J->h) {
             if (level == 0) *status = 0;
@@ -872,19 +874,27 @@ static void vo_lk_point(const vo_level *I, const vo_level *J, int level, int max
 }
 
 /* prev_pts/next_pts: n (x,y) pairs; status: n bytes.  Returns number of pyramid levels used. */
-VO_API int vo_pyr_lk(const uint8_t *prev, size_t ppitch, const uint8_t *next, size_t npitch, int w,
-                     int h, const float *prev_pts, int n, float *next_pts, uint8_t *status) {
+/* iterations (may be NULL): n x 4 ints, the Gauss-Newton iterations each feature ran on pyramid levels 0..3 -- what
+ * decides how long the slowest workgroup of the GPU tracker runs. */
+VO_API int vo_pyr_lk_iterations(const uint8_t *prev, size_t ppitch, const uint8_t *next, size_t npitch, int w,
+                                int h, const float *prev_pts, int n, float *next_pts, uint8_t *status, int *iterations) {
     vo_level I[VO_LK_MAXLEVEL + 1], J[VO_LK_MAXLEVEL + 1];
     int nl = vo_build_pyramid(prev, ppitch, w, h, I, 1);
     vo_build_pyramid(next, npitch, w, h, J, 0);
     for (int i = 0; i < n; i++) status[i] = 1;
+    if (iterations) memset(iterations, 0, sizeof(int) * 4 * (size_t)n);
     for (int level = nl - 1; level >= 0; level--) {
 #pragma omp parallel for schedule(dynamic, 4)
         for (int i = 0; i < n; i++)
             vo_lk_point(&I[level], &J[level], level, nl - 1, prev_pts + 2 * i, next_pts + 2 * i,
-                        status + i);
+                        status + i, iterations ? iterations + 4 * i + level : NULL);
     }
     vo_free_pyramid(I, nl);
     vo_free_pyramid(J, nl);
     return nl;
+}
+
+VO_API int vo_pyr_lk(const uint8_t *prev, size_t ppitch, const uint8_t *next, size_t npitch, int w,
+                     int h, const float *prev_pts, int n, float *next_pts, uint8_t *status) {
+    return vo_pyr_lk_iterations(prev, ppitch, next, npitch, w, h, prev_pts, n, next_pts, status, NULL);
 }

@@ -292,3 +292,18 @@ def test_lk_accumulation_order_gap_is_quantified():
     d = np.concatenate(diffs)
     assert len(d) > 400 and flips == 0
     assert (d == 0).mean() > 0.6 and d.mean() < 5e-4 and np.percentile(d, 99) < 5e-3 and d.max() < 0.05
+
+
+def test_tracker_iteration_counts_are_a_by_product_not_a_different_tracker():
+    """oracle.pyr_lk_iterations (tools/lk_iteration_histogram.py): same tracks and status as pyr_lk, and
+    counts inside the algorithm's limits (<= 30 per level; a level that is skipped counts 0)."""
+    import synth
+    w, h = 320, 180
+    g0 = synth.luma(4, w, h)
+    g1 = synth.shifted(g0, 1.7, -0.9)
+    pts = oracle.good_features(g0, 60, 0.01, 8.0)
+    a, sa = oracle.pyr_lk(g0, g1, pts)
+    b, sb, it = oracle.pyr_lk_iterations(g0, g1, pts)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(sa, sb)
+    assert it.shape == (len(pts), 4) and it.min() >= 0 and it.max() <= 30
+    assert (it[:, :oracle.pyramid_levels(w, h)].sum(1) >= 1).all() if hasattr(oracle, "pyramid_levels") else it.sum() > len(pts)
