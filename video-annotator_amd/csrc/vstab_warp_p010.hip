@@ -11,7 +11,7 @@
 //     taps in the order 00, 01, 10, 11, then round-to-nearest-even and clamp -- the "fp16 blend" of config 5,
 //     within 2 levels of the exact one
 //   BGR, three 16-bit samples per pixel, values 0..1023.
-// Direct gather, one thread per output pixel: this path is about the format, the 8-bit kernel carries the rate.
+// Direct gather, two output pixels per thread: this path is about the format, the 8-bit kernel carries the rate.
 #include "vstab_device.hpp"
 #include "vstab_internal.hpp"
 
@@ -59,35 +59,20 @@ __device__ __forceinline__ int blend_fp16(int p00, int p01, int p10, int p11, in
     return min((int)__builtin_rintf((float)acc), 1023);
 }
 
-template <int MODE, int BLEND>
-__global__ void __launch_bounds__(256) k_warp_p010(P010Args a) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= a.dw || y >= a.dh) return;
-    MapParams q = a.p;
-    if (a.rs) {
-        const float t = (float)y / a.rs_den;
-#pragma unroll
-        for (int k = 0; k < 9; k++) q.r[k] = __builtin_fmaf(t, a.rs_d[k], a.p.r[k]);
-    }
-    const float vx = ((float)x - q.ocx) / q.ofx, vy = ((float)y - q.ocy) / q.ofy;
-    const ColTerm ct = {q.r[0] * vx, q.r[3] * vx, q.r[6] * vx};
-    const RowTerm rt = {q.r[1] * vy, q.r[4] * vy, q.r[7] * vy};
-    float mx, my;
-    if constexpr (MODE == MAP_CREATEMAP_CL) {
-        map_pixel(q, ct, rt, mx, my);
-    } else {
-        const MapParams32 in = {q.icx, q.icy, q.ifx, q.ify, q.r[2], q.r[5], q.r[8]};  // unscaled
-        map_pixel_ex<MODE>(in, q, ct, rt, vx, vy, mx, my);
-    }
-    const Tap t = quantise(mx, my);
+// the four taps of one output pixel, converted and blended; sx, sy = cvRound(32 * map)
+template <int BLEND>
+__device__ __forceinline__ void sample10(const P010Args &a, float ax, float ay, uint16_t *o) {
+    const bool far = !(fabsf(ax) < 1073741824.0f) || !(fabsf(ay) < 1073741824.0f);
+    const int sx = (int)__builtin_rintf(ax), sy = (int)__builtin_rintf(ay);
+    const int X = sx >> 5, Y = sy >> 5, fx = sx & 31, fy = sy & 31;
     int B = 0, G = 0, R = 0;
-    if (!(t.far || t.X >= a.sw || t.X + 1 < 0 || t.Y >= a.sh || t.Y + 1 < 0)) {
-        const int w00 = (32 - t.fx) * (32 - t.fy), w01 = t.fx * (32 - t.fy), w10 = (32 - t.fx) * t.fy, w11 = t.fx * t.fy;
+    if (!(far || X >= a.sw || X + 1 < 0 || Y >= a.sh || Y + 1 < 0)) {
+        const int w00 = (32 - fx) * (32 - fy), w01 = fx * (32 - fy), w10 = (32 - fx) * fy, w11 = fx * fy;
         int b0, g0, r0, b1, g1, r1, b2, g2, r2, b3, g3, r3;
-        fetch_tap10(a, t.X, t.Y, b0, g0, r0);
-        fetch_tap10(a, t.X + 1, t.Y, b1, g1, r1);
-        fetch_tap10(a, t.X, t.Y + 1, b2, g2, r2);
-        fetch_tap10(a, t.X + 1, t.Y + 1, b3, g3, r3);
+        fetch_tap10(a, X, Y, b0, g0, r0);
+        fetch_tap10(a, X + 1, Y, b1, g1, r1);
+        fetch_tap10(a, X, Y + 1, b2, g2, r2);
+        fetch_tap10(a, X + 1, Y + 1, b3, g3, r3);
         if constexpr (BLEND == VSTAB_BLEND_FP16) {
             B = blend_fp16(b0, b1, b2, b3, w00, w01, w10, w11);
             G = blend_fp16(g0, g1, g2, g3, w00, w01, w10, w11);
@@ -98,8 +83,53 @@ __global__ void __launch_bounds__(256) k_warp_p010(P010Args a) {
             R = (r0 * w00 + r1 * w01 + r2 * w10 + r3 * w11 + 512) >> 10;
         }
     }
-    uint16_t *o = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(a.dst) + (size_t)y * a.pitch_dst) + 3 * (size_t)x;
     o[0] = (uint16_t)B, o[1] = (uint16_t)G, o[2] = (uint16_t)R;
+}
+
+// A thread owns two vertically adjacent output pixels, so that the map of the fisheye-input modes runs as packed fp32
+// (map_pixel32_x2: the hand-scheduled IEEE sequences of the 8-bit kernel, two pixels per instruction; 32 * map, an
+// exact power-of-two scaling of the map the definition quantises).
+template <int MODE, int BLEND>
+__global__ void __launch_bounds__(256) k_warp_p010(P010Args a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 2;
+    if (x >= a.dw || y0 >= a.dh) return;
+    float m[2][9];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const float t = (float)(y0 + r) / a.rs_den;
+#pragma unroll
+        for (int k = 0; k < 9; k++) m[r][k] = a.rs ? __builtin_fmaf(t, a.rs_d[k], a.p.r[k]) : a.p.r[k];
+    }
+    const float vx = ((float)x - a.p.ocx) / a.p.ofx;
+    const float vy[2] = {((float)y0 - a.p.ocy) / a.p.ofy, ((float)(y0 + 1) - a.p.ocy) / a.p.ofy};
+    float ax[2], ay[2];
+    if constexpr (MODE == MAP_CREATEMAP_CL || MODE == MAP_FISH_TO_RECT) {
+        f32x2 px, py;
+        map_pixel32_x2<MODE == MAP_FISH_TO_RECT>(a.p.icx * 32.0f, a.p.icy * 32.0f, a.p.ifx * 32.0f, a.p.ify * 32.0f, (f32x2){m[0][2], m[1][2]},
+                                                 (f32x2){m[0][5], m[1][5]}, (f32x2){m[0][8], m[1][8]}, (f32x2){m[0][0] * vx, m[1][0] * vx},
+                                                 (f32x2){m[0][3] * vx, m[1][3] * vx}, (f32x2){m[0][6] * vx, m[1][6] * vx},
+                                                 (f32x2){m[0][1] * vy[0], m[1][1] * vy[1]}, (f32x2){m[0][4] * vy[0], m[1][4] * vy[1]},
+                                                 (f32x2){m[0][7] * vy[0], m[1][7] * vy[1]}, px, py);
+        ax[0] = px.x, ax[1] = px.y, ay[0] = py.x, ay[1] = py.y;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            MapParams q = a.p;
+#pragma unroll
+            for (int k = 0; k < 9; k++) q.r[k] = m[r][k];
+            const ColTerm ct = {q.r[0] * vx, q.r[3] * vx, q.r[6] * vx};
+            const RowTerm rt = {q.r[1] * vy[r], q.r[4] * vy[r], q.r[7] * vy[r]};
+            const MapParams32 in = {q.icx, q.icy, q.ifx, q.ify, q.r[2], q.r[5], q.r[8]};  // unscaled
+            float mx, my;
+            map_pixel_ex<MODE>(in, q, ct, rt, vx, vy[r], mx, my);
+            ax[r] = mx * 32.0f, ay[r] = my * 32.0f;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (y0 + r >= a.dh) break;
+        sample10<BLEND>(a, ax[r], ay[r], reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(a.dst) + (size_t)(y0 + r) * a.pitch_dst) + 3 * (size_t)x);
+    }
 }
 
 }  // namespace vstab
@@ -125,7 +155,7 @@ extern "C" vstab_status vstab_warp_p010(const void *y, size_t pitch_y, const voi
     a.rs = rot_bottom != nullptr;
     for (int k = 0; k < 9; k++) a.rs_d[k] = rot_bottom ? rot_bottom[k] - params[8 + k] : 0.0f;
     a.rs_den = (float)(dh > 1 ? dh - 1 : 1);
-    const dim3 grid(div_up(dw, 64), div_up(dh, 4));
+    const dim3 grid(div_up(dw, 64), div_up(dh, 8));  // 64 columns x 4 pairs of rows per workgroup
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define VSTAB_LAUNCH(M)                                                                  \
     if (blend == VSTAB_BLEND_FP16)                                                       \
