@@ -34,19 +34,39 @@ __device__ __forceinline__ int sat10(int v) { return min(max(v, 0), 1023); }
 // (v_add_i32 ... clamp) gives the same channel value as the 64-bit sum of the definition.
 __device__ __forceinline__ int channel10(int yy, int c) { return sat10(__builtin_elementwise_add_sat(yy, c) >> 20); }
 
-// one P010 tap -> B, G, R in [0, 1023]; outside the source -> 0 (BORDER_CONSTANT)
-__device__ __forceinline__ void fetch_tap10(const P010Args &a, int X, int Y, int &b, int &g, int &r) {
-    if ((unsigned)X < (unsigned)a.sw && (unsigned)Y < (unsigned)a.sh) {
-        const int yv = *reinterpret_cast<const uint16_t *>(a.y + (size_t)Y * a.pitch_y + 2 * (size_t)X) >> 6;
-        const uint32_t c = *reinterpret_cast<const uint32_t *>(a.uv + (size_t)(Y >> 1) * a.pitch_uv + 4 * (size_t)(X >> 1));
-        const int u = (int)((c & 0xffffu) >> 6) - 512, v = (int)(c >> 22) - 512;
-        const int yy = max(yv - 64, 0) * CY;  // <= 959 * 1220542 < 2^31
-        b = channel10(yy, (1 << 19) + CUB * u);
-        g = channel10(yy, (1 << 19) + CVG * v + CUG * u);
-        r = channel10(yy, (1 << 19) + CVR * v);
-    } else {
-        b = g = r = 0;
-    }
+// B, G, R in [0, 1023] of one tap from its luma sample and chroma pair (both still P010 words); !valid -> 0 (BORDER_CONSTANT)
+__device__ __forceinline__ void convert_tap10(uint32_t ys, uint32_t c, bool valid, int &b, int &g, int &r) {
+    const int yv = (int)(ys >> 6);
+    const int u = (int)((c & 0xffffu) >> 6) - 512, v = (int)(c >> 22) - 512;
+    const int yy = max(yv - 64, 0) * CY;  // <= 959 * 1220542 < 2^31
+    b = valid ? channel10(yy, (1 << 19) + CUB * u) : 0;
+    g = valid ? channel10(yy, (1 << 19) + CVG * v + CUG * u) : 0;
+    r = valid ? channel10(yy, (1 << 19) + CVR * v) : 0;
+}
+
+struct Dword2 {  // 4-byte aligned pair of dwords / 2-byte aligned dword: the loads below are narrower than their natural alignment
+    uint32_t lo, hi;
+} __attribute__((packed, aligned(4)));
+struct Dword1 {
+    uint32_t v;
+} __attribute__((packed, aligned(2)));
+
+// The two horizontally adjacent taps (X, Yr), (X + 1, Yr) of a pixel's footprint with TWO loads: one dword holding both
+// luma samples and one pair of dwords holding the (at most two) chroma pairs they use; positions are clamped into the
+// row so that every load is in bounds, and taps outside the source come back as 0.  Needs sw >= 4.
+__device__ __forceinline__ void fetch_row10(const P010Args &a, int X, int Yr, int &b0, int &g0, int &r0, int &b1, int &g1, int &r1) {
+    const bool row_ok = (unsigned)Yr < (unsigned)a.sh;
+    const int Yc = min(max(Yr, 0), a.sh - 1);
+    const int col0 = min(max(X, 0), a.sw - 2);          // samples col0, col0 + 1
+    const uint32_t yy = reinterpret_cast<const Dword1 *>(a.y + (size_t)Yc * a.pitch_y + 2 * (size_t)col0)->v;
+    const int np = a.sw >> 1, pX = X >> 1, pX1 = (X + 1) >> 1;
+    const int pc0 = min(max(pX, 0), np - 2);            // chroma pairs pc0, pc0 + 1
+    const Dword2 cc = *reinterpret_cast<const Dword2 *>(a.uv + (size_t)(Yc >> 1) * a.pitch_uv + 4 * (size_t)pc0);
+    const int d = X - col0;                             // 0 inside; -1 at X = -1; 1 at X = sw - 1
+    const uint32_t yl = d == 1 ? yy >> 16 : yy & 0xffffu, yr = d == -1 ? yy & 0xffffu : yy >> 16;
+    const uint32_t cl = pX - pc0 == 1 ? cc.hi : cc.lo, cr = pX1 - pc0 == 1 ? cc.hi : cc.lo;
+    convert_tap10(yl << 0, cl, row_ok && (unsigned)X < (unsigned)a.sw, b0, g0, r0);
+    convert_tap10(yr << 0, cr, row_ok && (unsigned)(X + 1) < (unsigned)a.sw, b1, g1, r1);
 }
 
 __device__ __forceinline__ int blend_fp16(int p00, int p01, int p10, int p11, int w00, int w01, int w10, int w11) {
@@ -69,10 +89,8 @@ __device__ __forceinline__ void sample10(const P010Args &a, float ax, float ay, 
     if (!(far || X >= a.sw || X + 1 < 0 || Y >= a.sh || Y + 1 < 0)) {
         const int w00 = (32 - fx) * (32 - fy), w01 = fx * (32 - fy), w10 = (32 - fx) * fy, w11 = fx * fy;
         int b0, g0, r0, b1, g1, r1, b2, g2, r2, b3, g3, r3;
-        fetch_tap10(a, X, Y, b0, g0, r0);
-        fetch_tap10(a, X + 1, Y, b1, g1, r1);
-        fetch_tap10(a, X, Y + 1, b2, g2, r2);
-        fetch_tap10(a, X + 1, Y + 1, b3, g3, r3);
+        fetch_row10(a, X, Y, b0, g0, r0, b1, g1, r1);
+        fetch_row10(a, X, Y + 1, b2, g2, r2, b3, g3, r3);
         if constexpr (BLEND == VSTAB_BLEND_FP16) {
             B = blend_fp16(b0, b1, b2, b3, w00, w01, w10, w11);
             G = blend_fp16(g0, g1, g2, g3, w00, w01, w10, w11);
@@ -139,8 +157,8 @@ using namespace vstab;
 extern "C" vstab_status vstab_warp_p010(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh, const float params[17],
                                         const float *rot_bottom, int map_mode, int blend, void *dst, size_t pitch_dst, int dw, int dh, void *stream) {
     if (!y || !uv || !dst || !params) return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: null pointer");
-    if (sw <= 0 || sh <= 0 || (sw & 1) || (sh & 1) || dw <= 0 || dh <= 0 || sw > 32767 || sh > 32767 || dw > 32767 || dh > 32767)
-        return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: sizes must be in [1, 32767], source even");
+    if (sw < 4 || sh < 2 || (sw & 1) || (sh & 1) || dw <= 0 || dh <= 0 || sw > 32767 || sh > 32767 || dw > 32767 || dh > 32767)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: sizes must be in [1, 32767], source even and at least 4 x 2");
     if (pitch_y < (size_t)sw * 2 || pitch_uv < (size_t)sw * 2 || pitch_dst < (size_t)dw * 6 || pitch_y % 2 || pitch_uv % 4 || pitch_dst % 2 ||
         reinterpret_cast<uintptr_t>(y) % 2 || reinterpret_cast<uintptr_t>(uv) % 4 || reinterpret_cast<uintptr_t>(dst) % 2)
         return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: bad pitch or alignment (16-bit samples; chroma pairs 4-byte aligned)");
