@@ -49,6 +49,10 @@ def test_p010_warp_lens_modes_pitched_planes_and_bad_arguments(vs, cuda):
         p = oracle.map_params(Ki, Ko, oracle.rodrigues((0.05, -0.1, 0.2)))
         got = host(vs.warp_p010(dev16(y, cuda), dev16(uv, cuda), p, 301, 171, None, mode, vs.BLEND_EXACT))
         assert np.array_equal(got, oracle.warp_p010(y, uv, p, 301, 171, None, mode, 0)), mode
+        # a rotation per output row with every projection pair (the 8-bit kernel has it for the fisheye-input pairs only)
+        rb = oracle.map_params(Ki, Ko, oracle.rodrigues((0.07, -0.09, 0.18)))[8:]
+        got = host(vs.warp_p010(dev16(y, cuda), dev16(uv, cuda), p, 301, 171, rb, mode, vs.BLEND_FP16))
+        assert np.array_equal(got, oracle.warp_p010(y, uv, p, 301, 171, rb, mode, 1)), ("rs", mode)
     # planes that are views into wider buffers, destination with a padded pitch
     K = oracle.get_preset_camera(4, w, h)
     Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
