@@ -197,3 +197,16 @@ def test_p010_ring_source_with_readout_rotations(vs, cuda):
         assert np.array_equal(o.cpu().numpy().view(np.uint16), exp), i
         i += 1
     assert i == n - 1
+
+
+def test_p010_identity_map_is_the_colour_conversion_at_4k(vs, cuda):
+    """Size-independent property (cf. test_warp_properties_at_full_size...): pinhole cameras with a power-of-two focal
+    length and integer principal points make the rect -> rect map exact, so with identical cameras the 10-bit warp IS the
+    10-bit colour conversion, for either blend (one tap has weight 1024: 1.0 in binary16)."""
+    w, h = 3840, 2160
+    y, uv, _, _ = p010_frame(35, w, h)
+    K = np.array([[2048.0, 0, 1920.0], [0, 2048.0, 1080.0], [0, 0, 1]])
+    p = oracle.map_params(K, K, np.eye(3))
+    exp = oracle.cvt_p010_bgr10(y, uv)
+    for blend in (vs.BLEND_EXACT, vs.BLEND_FP16):
+        assert np.array_equal(host(vs.warp_p010(dev16(y, cuda), dev16(uv, cuda), p, w, h, None, vs.MAP_RECT_TO_RECT, blend)), exp), blend

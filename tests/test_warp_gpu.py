@@ -168,3 +168,35 @@ def test_fused_warp_pitched_output_and_unaligned_tail(vs, cuda):
         vs.warp_nv12_bgr(dev(frame, cuda), p, dw, ch, out=out)
         assert np.array_equal(out.cpu().numpy(), exp[:, :dw])
         assert int(big[:, dw * 3:].sum()) == 0   # padding untouched
+
+
+def test_warp_properties_at_full_size_identity_shift_and_half_pixel(vs, cuda):
+    """Size-independent properties at BASELINE's 4K (no oracle warp involved).  With pinhole cameras whose focal length
+    is a power of two and whose principal points are integers, the rect -> rect map is exact in fp32:
+      identical cameras          -> the output IS cvtColor(input), byte for byte;
+      principal point moved by k -> the image shifted by k pixels, zeros where the source ends (BORDER_CONSTANT);
+      moved by half a pixel      -> every pixel the rounded mean of two neighbours, (a + b + 1) >> 1 (weights 512 / 512)."""
+    import torch
+    w, h = 3840, 2160
+    frame = synth.nv12(44, w, h)
+    fd = dev(frame, cuda)
+    bgr = vs.cvt_nv12_bgr(fd)
+    K = np.array([[2048.0, 0, 1920.0], [0, 2048.0, 1080.0], [0, 0, 1]])
+    ident = vs.warp_nv12(fd, oracle.map_params(K, K, np.eye(3)), w, h, vs.MAP_RECT_TO_RECT, vs.OUT_BGR8)
+    assert bool((ident == bgr).all())
+    Ks = K.copy()
+    Ks[0, 2], Ks[1, 2] = 1920.0 + 37, 1080.0 - 5           # output pixel (x, y) looks at source (x - 37, y + 5)
+    sh = vs.warp_nv12(fd, oracle.map_params(K, Ks, np.eye(3)), w, h, vs.MAP_RECT_TO_RECT, vs.OUT_BGR8)
+    exp = torch.zeros_like(bgr)
+    exp[: h - 5, 37:] = bgr[5:, : w - 37]
+    assert bool((sh == exp).all())
+    Kh = K.copy()
+    Kh[0, 2] = 1920.0 - 0.5                                 # source x + 0.5: mean of columns x and x + 1
+    half = vs.warp_nv12(fd, oracle.map_params(K, Kh, np.eye(3)), w, h, vs.MAP_RECT_TO_RECT, vs.OUT_BGR8)
+    a, b = bgr[:, :-1].to(torch.int32), bgr[:, 1:].to(torch.int32)
+    assert bool((half[:, :-1].to(torch.int32) == ((a + b + 1) >> 1)).all())
+    assert bool((half[:, -1].to(torch.int32) == ((bgr[:, -1].to(torch.int32) + 1) >> 1)).all())   # last column: half of it, half border
+    # NV12 output of the identity is the conversion of that BGR image (the encoder hand-off adds nothing else)
+    yo, uvo = vs.warp_nv12(fd, oracle.map_params(K, K, np.eye(3)), w, h, vs.MAP_RECT_TO_RECT, vs.OUT_NV12)
+    ey, euv = oracle.cvt_bgr_nv12(bgr.cpu().numpy())
+    assert np.array_equal(yo.cpu().numpy(), ey) and np.array_equal(uvo.cpu().numpy().reshape(euv.shape), euv)
