@@ -354,3 +354,20 @@ def test_rolling_shutter_warp_at_4k_and_bad_modes(vs, cuda):
     assert np.array_equal(got, oracle.warp_nv12_rs(frame, p, rb, cw, ch))
     with pytest.raises(vs.VstabError):
         vs.warp_nv12_rs(dev(frame, cuda), p, rb, cw, ch, mode=2)   # fisheye output: no per-row variant
+
+
+def test_fused_warp_extreme_box_shapes(vs, cuda):
+    """Staging of a tile's source box walks it in units of 8 x 2 pixels with an integer divmod by the box width in units
+    (the old magic-number division failed for wide, flat boxes such as 992 x 10).  Anisotropic pinhole cameras
+    give exactly such boxes -- a 64 x 32 output tile reading ~970 x 10 source pixels, and the transpose, ~16 x 480 -- and
+    the result must still equal the oracle in every byte."""
+    for sw, sh, dw, dh, sx, sy in [(2048, 32, 128, 64, 15.0, 0.25), (64, 1024, 128, 64, 0.125, 15.0), (4096, 64, 200, 70, 15.5, 0.3)]:
+        frame = synth.nv12(61, sw, sh)
+        Ki = np.array([[100.0 * sx, 0, sw / 2], [0, 100.0 * sy, sh / 2], [0, 0, 1]])
+        Ko = np.array([[100.0, 0, dw / 2], [0, 100.0, dh / 2], [0, 0, 1]])
+        for rot in [(0.0, 0.0, 0.0), (0.0, 0.0, 0.002)]:
+            p = oracle.map_params(Ki, Ko, oracle.rodrigues(rot))
+            got = vs.warp_nv12(dev(frame, cuda), p, dw, dh, vs.MAP_RECT_TO_RECT, vs.OUT_BGR8).cpu().numpy()
+            exp = oracle.warp_nv12_ex(frame, p, dw, dh, 3, 0)
+            assert np.array_equal(got, exp), (sw, sh, rot, int((got != exp).sum()))
+            assert exp.any()
