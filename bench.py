@@ -7,7 +7,7 @@ One "step" = one pass of the hot path over one batch of synthetic input: --batch
 input ring) consecutive frames of this rank's clip, each emitted as one output frame; `value` is
 frames/s.  Inputs (a ring of distinct synthetic NV12 frames) are resident in HBM before the timed
 region, and an untimed pre-roll
-(--preroll, default 256 frames) ahead of --warmup fills the look-ahead queue and brings clocks,
+(--preroll, default 1024 frames) ahead of --warmup fills the look-ahead queue and brings clocks,
 prefetch depth and the speculative detector to steady state.  N > 1: one rank per GPU, one
 independent clip per rank (weak scaling, no data-path collective), timing
 = max over ranks between barriers.  `bench.py --gpus N` without a torch.distributed environment
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=40, help="timed steps; one step = one batch of --batch frames")
     ap.add_argument("--warmup", type=int, default=4, help="untimed steps ahead of the timed region")
     ap.add_argument("--batch", type=int, default=64, help="frames per step (one pass over the input ring by default)")
-    ap.add_argument("--preroll", type=int, default=256, help="untimed frames ahead of --warmup (pipeline mode): steady state before the driver's window")
+    ap.add_argument("--preroll", type=int, default=1024, help="untimed frames ahead of --warmup (pipeline mode): steady state before the driver's window")
     ap.add_argument("--workload", default="4k", choices=["4k", "1080p", "4k-p010"],
                     help="4k-p010 = BASELINE config 5: P010 frames, 10-bit pixel path with fp16 blend, a read-out rotation per frame")
     ap.add_argument("--mode", default="auto", choices=["auto", "warp", "pipeline"])
