@@ -25,4 +25,9 @@ inline vstab_status fail(vstab_status st, const std::string &msg) {
 
 inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
+// vstab_pack_p010 with a choice of planes (vstab_warp.hip): luma_only narrows the luma plane alone -- what the 10-bit
+// pipeline needs for its tracker
+vstab_status pack_p010_planes(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width, int height, void *dst, bool luma_only,
+                              void *stream);
+
 }  // namespace vstab

@@ -859,7 +859,7 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
     }
     if (H->cfg.pixel_depth == 10 && !wide) return fail(VSTAB_ERR_INVALID, "a pixel_depth 10 handle needs P010 device frames (vstab_frame.bit_depth > 8)");
     if (wide) {
-        VSTAB_TRY(vstab_pack_p010(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->pstream));
+        VSTAB_TRY(pack_p010_planes(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->cfg.pixel_depth == 10, H->pstream));
         if (H->cfg.pixel_depth == 10) {  // the warp reads the 16-bit planes; the tracker the narrowed luma above
             const size_t row = (size_t)H->w * 2;
             if (f.hold >= vstab_handle::HOLD_FOREVER) {

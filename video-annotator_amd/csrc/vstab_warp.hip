@@ -44,9 +44,8 @@ __global__ void __launch_bounds__(256) k_pack_nv12(const uint8_t *__restrict__ y
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_pack_p010(const uint8_t *__restrict__ y, size_t pitch_y,
                                                    const uint8_t *__restrict__ uv, size_t pitch_uv, int row_units,
-                                                   int h, uint8_t *__restrict__ dst, size_t pitch_dst) {
-    const int rows = h + h / 2;
-    const long total = (long)rows * row_units;
+                                                   int h, int rows, uint8_t *__restrict__ dst, size_t pitch_dst) {
+    const long total = (long)rows * row_units;  // rows = h + h / 2, or h when only the luma plane is wanted
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int row = (int)(e / row_units), i = (int)(e - (long)row * row_units);
         const uint8_t *s = row < h ? y + (size_t)row * pitch_y : uv + (size_t)(row - h) * pitch_uv;
@@ -321,6 +320,31 @@ static inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<u
 
 using namespace vstab;
 
+namespace vstab {
+// luma_only: the 10-bit pipeline narrows the luma plane for the tracker and warps from the 16-bit planes
+vstab_status pack_p010_planes(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width, int height, void *dst, bool luma_only,
+                                     void *stream) {
+    if (!y || !uv || !dst) return fail(VSTAB_ERR_INVALID, "vstab_pack_p010: null pointer");
+    if (width <= 0 || height <= 0 || (width & 1) || (height & 1)) return fail(VSTAB_ERR_INVALID, "Mismatched image dimensions");
+    if (pitch_y < (size_t)width * 2 || pitch_uv < (size_t)width * 2) return fail(VSTAB_ERR_INVALID, "vstab_pack_p010: pitch smaller than row");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rows = luma_only ? height : height + height / 2;
+    const bool vec = aligned(y, 16) && aligned(uv, 16) && aligned(dst, 8) && pitch_y % 16 == 0 && pitch_uv % 16 == 0 && width % 8 == 0;
+    if (vec) {
+        const int units = width / 8;
+        dim3 grid(std::min<unsigned>(div_up((unsigned)((long)units * rows), 256), 2048));
+        hipLaunchKernelGGL(k_pack_p010<true>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y, (const uint8_t *)uv, pitch_uv, units, height, rows,
+                           (uint8_t *)dst, (size_t)width);
+    } else {
+        dim3 grid(std::min<unsigned>(div_up((unsigned)((long)width * rows), 256), 2048));
+        hipLaunchKernelGGL(k_pack_p010<false>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y, (const uint8_t *)uv, pitch_uv, width, height, rows,
+                           (uint8_t *)dst, (size_t)width);
+    }
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+}  // namespace vstab
+
 extern "C" {
 
 vstab_status vstab_pack_nv12(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width,
@@ -360,24 +384,7 @@ vstab_status vstab_pack_nv12(const void *y, size_t pitch_y, const void *uv, size
 
 vstab_status vstab_pack_p010(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width, int height,
                              void *dst, void *stream) {
-    if (!y || !uv || !dst) return fail(VSTAB_ERR_INVALID, "vstab_pack_p010: null pointer");
-    if (width <= 0 || height <= 0 || (width & 1) || (height & 1)) return fail(VSTAB_ERR_INVALID, "Mismatched image dimensions");
-    if (pitch_y < (size_t)width * 2 || pitch_uv < (size_t)width * 2) return fail(VSTAB_ERR_INVALID, "vstab_pack_p010: pitch smaller than row");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int rows = height + height / 2;
-    const bool vec = aligned(y, 16) && aligned(uv, 16) && aligned(dst, 8) && pitch_y % 16 == 0 && pitch_uv % 16 == 0 && width % 8 == 0;
-    if (vec) {
-        const int units = width / 8;
-        dim3 grid(std::min<unsigned>(div_up((unsigned)((long)units * rows), 256), 2048));
-        hipLaunchKernelGGL(k_pack_p010<true>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y, (const uint8_t *)uv, pitch_uv, units, height,
-                           (uint8_t *)dst, (size_t)width);
-    } else {
-        dim3 grid(std::min<unsigned>(div_up((unsigned)((long)width * rows), 256), 2048));
-        hipLaunchKernelGGL(k_pack_p010<false>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y, (const uint8_t *)uv, pitch_uv, width, height,
-                           (uint8_t *)dst, (size_t)width);
-    }
-    VSTAB_HIP_TRY(hipGetLastError());
-    return VSTAB_OK;
+    return pack_p010_planes(y, pitch_y, uv, pitch_uv, width, height, dst, false, stream);
 }
 
 vstab_status vstab_cvt_nv12_bgr(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width,
