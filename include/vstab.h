@@ -129,7 +129,13 @@ typedef enum vstab_map_mode {
     VSTAB_MAP_FISH_TO_RECT = 1, /* fisheye input -> pinhole output: createMap.cl's arithmetic without those two quirks */
     VSTAB_MAP_FISH_TO_FISH = 2,
     VSTAB_MAP_RECT_TO_RECT = 3,
-    VSTAB_MAP_RECT_TO_FISH = 4
+    VSTAB_MAP_RECT_TO_FISH = 4,
+    /* createMap.cl with the arithmetic the reference's OWN kernel has when ROCm's OpenCL compiler builds it for this GPU
+     * (oracle/_ref/createMap.gfx950.co: contracted multiply-adds, reciprocal-based division, v_sqrt_f32, ocml's atan --
+     * all inside OpenCL 1.2's error bounds, none IEEE-rounded).  Bit-identical to that code object run on the same
+     * device (tests/test_refcl_gpu.py); mode 0 is the same kernel with every operation IEEE-rounded, reproducible on a
+     * CPU.  The two differ in the last bits of the map. */
+    VSTAB_MAP_CREATEMAP_CL_OPENCL = 5
 } vstab_map_mode;
 typedef enum vstab_out_format {
     VSTAB_OUT_BGR8 = 0, /* what FrameSourceWarp emits (FrameSourceWarp.cpp:313) */

@@ -29,7 +29,12 @@ def build(force=False):
     src = os.path.join(_HERE, "vstab_oracle.c")
     need = force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)
     ref_so = os.path.join(_HERE, "_ref", "libcreatemap_ref.so")
-    if os.path.exists("/root/reference/opencv/createMap.cl") and not os.path.exists(ref_so):
+    ref_co = os.path.join(_HERE, "_ref", "createMap.gfx950.co")
+    runner = os.path.join(_HERE, "_build", "libref_cl_runner.so")
+    runner_src = os.path.join(_HERE, "ref_cl_runner.cpp")
+    if os.path.exists("/root/reference/opencv/createMap.cl") and not (os.path.exists(ref_so) and os.path.exists(ref_co)):
+        need = True
+    if not os.path.exists(runner) or os.path.getmtime(runner) < os.path.getmtime(runner_src):
         need = True
     if need:
         subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
@@ -98,6 +103,41 @@ def ref_lib():
         R.createmap_ref_run.argtypes = [f32p, f32p, ctypes.c_int, ctypes.c_int, f32p]
         _REF = R
     return _REF
+
+
+_RUNNER = None
+REF_GFX950_CO = os.path.join(_HERE, "_ref", "createMap.gfx950.co")
+
+
+def ref_gfx950_available():
+    """True when the reference kernel's gfx950 code object and its launcher are built (running it needs a GPU)."""
+    return os.path.exists(REF_GFX950_CO) and os.path.exists(os.path.join(_HERE, "_build", "libref_cl_runner.so"))
+
+
+def create_map_ref_gfx950(params, cols, rows, block=(64, 4)):
+    """The reference's own createMap.cl, compiled unmodified by ROCm's OpenCL front end for gfx950
+    (oracle/_ref/createMap.gfx950.co), launched on the current GPU exactly as FrameSourceWarp.cpp:272-304 does
+    (global size {cols, rows}; arguments of :275-300).  -> (map_x, map_y) float32 (rows, cols)."""
+    global _RUNNER
+    if _RUNNER is None:
+        build()
+        R = ctypes.CDLL(os.path.join(_HERE, "_build", "libref_cl_runner.so"))
+        f32p = ctypes.POINTER(ctypes.c_float)
+        R.refcl_create_map.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, f32p, f32p, f32p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_char_p, ctypes.c_int]
+        R.refcl_create_map.restype = ctypes.c_int
+        _RUNNER = R
+    if not os.path.exists(REF_GFX950_CO):
+        raise RuntimeError("oracle/_ref/createMap.gfx950.co not built")
+    p, pp = _f32(np.asarray(params, np.float32).reshape(17))
+    mx = np.empty((rows, cols), np.float32)
+    my = np.empty((rows, cols), np.float32)
+    err = ctypes.create_string_buffer(512)
+    rc = _RUNNER.refcl_create_map(REF_GFX950_CO.encode(), cols, rows, pp, _p(mx, ctypes.c_float), _p(my, ctypes.c_float), int(block[0]),
+                                  int(block[1]), err, 512)
+    if rc:
+        raise RuntimeError("reference createMap (gfx950 code object): " + err.value.decode())
+    return mx, my
 
 
 def _p(a, t):
@@ -312,6 +352,11 @@ def scharr(img):
 def set_lk_accumulation(float_raster_order):
     """False (normative): exact int64 LK sums.  True: fp32 raster-order accumulation, for measuring the gap."""
     lib().vo_set_lk_accumulation(1 if float_raster_order else 0)
+
+
+def set_lk_final_check(on):
+    """True (normative): OpenCV's re-test of the final position behind the iteration loop (level 0).  False: without it."""
+    lib().vo_set_lk_final_check(1 if on else 0)
 
 
 def warp_p010(y, uv, params, dw, dh, rot_bottom=None, mode=0, blend=0):

@@ -772,6 +772,10 @@ static inline int vo_cvfloor(float v) { return (int)floorf(v); }
  * deviation is worth (tests/test_oracle_cpu.py); OpenCV's SIMD builds use yet another, lane-wise order. */
 static int vo_lk_float_acc = 0;
 VO_API void vo_set_lk_accumulation(int mode) { vo_lk_float_acc = mode != 0; }
+/* 1 (normative): OpenCV's test of the final position behind the iteration loop.  0: without it -- only to let a test
+ * find and show inputs on which the rule decides (tests/test_oracle_cpu.py). */
+static int vo_lk_final_check = 1;
+VO_API void vo_set_lk_final_check(int on) { vo_lk_final_check = on != 0; }
 
 /* iters (may be NULL): incremented once per Gauss-Newton iteration this call starts (vo_pyr_lk_iterations) */
 static void vo_lk_point(const vo_level *I, const vo_level *J, int level, int max_level,
@@ -870,6 +874,16 @@ static void vo_lk_point(const vo_level *I, const vo_level *J, int level, int max
             break;
         }
         pdx = dx, pdy = dy;
+    }
+    /* OpenCV 4.x LKTrackerInvoker, behind the iteration loop, when the caller asks for `err` -- the reference does
+     * (FrameSourceWarp.cpp:250-259) -- and the level is 0: the FINAL position (the stored next point minus the half
+     * window, recomputed in float) is tested against [-win, cols) x [-win, rows) once more and the feature is
+     * dropped when its window has left the image, e.g. through the last Gauss-Newton step or the half-step
+     * correction above.  (The error measure itself is computed there and never used by the reference.) */
+    if (level == 0 && *status && vo_lk_final_check) {
+        const float fx = next_pt[0] - half, fy = next_pt[1] - half;
+        const int inx = vo_cvfloor(fx), iny = vo_cvfloor(fy);
+        if (inx < -VO_LK_WIN || inx >= J->w || iny < -VO_LK_WIN || iny >= J->h) *status = 0;
     }
 }
 

@@ -119,3 +119,23 @@ def shaky_clip(seed, K, w, h, n, sigma=0.004, projection="fish"):
         frames.append(f)
         rots.append(R.copy())
     return frames, rots
+
+
+def edge_leaving_pair(seed, w=160, h=120, n=60):
+    """A smooth random texture and the same texture shifted by 6..22 px towards the right (even seeds) or the bottom
+    (odd seeds) edge, plus n feature points in the 14-px band along that edge: inputs on which features are tracked
+    out of the image -- some by the last Gauss-Newton step only, which is where OpenCV's test of the final position
+    (LKTrackerInvoker behind its loop) decides.  -> (prev u8, next u8, pts float32 (n, 2))."""
+    from scipy.ndimage import gaussian_filter, shift as nd_shift
+    rng = np.random.default_rng(1000 + seed)
+    base = rng.integers(0, 256, (h // 4 + 13, w // 4 + 13)).astype(np.float32)
+    img = gaussian_filter(np.kron(base, np.ones((4, 4), np.float32))[:h + 40, :w + 40], 1.5)
+    along, across = rng.uniform(6, 22), rng.uniform(-3, 3)
+    sx, sy = (along, across) if seed % 2 == 0 else (across, along)
+    prev = np.clip(img[:h, :w], 0, 255).astype(np.uint8)
+    nxt = np.clip(nd_shift(img, (sy, sx), order=1, mode="nearest")[:h, :w], 0, 255).astype(np.uint8)
+    if seed % 2 == 0:
+        pts = np.stack([rng.uniform(w - 14, w - 1, n), rng.uniform(5, h - 5, n)], 1)
+    else:
+        pts = np.stack([rng.uniform(5, w - 5, n), rng.uniform(h - 14, h - 1, n)], 1)
+    return prev, nxt, pts.astype(np.float32)

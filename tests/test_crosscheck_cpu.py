@@ -147,3 +147,9 @@ def test_opencv_itself_when_present():
     c_pts, c_st, _ = cv2.calcOpticalFlowPyrLK(gray, nxt, ours.reshape(-1, 1, 2), None)
     both = (o_st > 0) & (c_st.reshape(-1) > 0)
     assert (o_st > 0).sum() == (c_st > 0).sum() and np.abs(o_pts - c_pts.reshape(-1, 2))[both].max() < 0.05
+    # a4, the rule behind the iteration loop (err requested): features tracked out of the image by their last step
+    for seed in (1, 39, 81):
+        prev, nxt2, pts = synth.edge_leaving_pair(seed)
+        o_pts, o_st = oracle.pyr_lk(prev, nxt2, pts)
+        c_pts, c_st, _err = cv2.calcOpticalFlowPyrLK(prev, nxt2, pts.reshape(-1, 1, 2), None)
+        assert np.array_equal(o_st > 0, c_st.reshape(-1) > 0), seed

@@ -307,3 +307,33 @@ def test_tracker_iteration_counts_are_a_by_product_not_a_different_tracker():
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(sa, sb)
     assert it.shape == (len(pts), 4) and it.min() >= 0 and it.max() <= 30
     assert (it[:, :oracle.pyramid_levels(w, h)].sum(1) >= 1).all() if hasattr(oracle, "pyramid_levels") else it.sum() > len(pts)
+
+
+LK_EDGE_SEEDS = (1, 39, 81, 97, 112, 168, 218, 230)   # synth.edge_leaving_pair seeds on which the final-position rule decides
+
+
+def test_lk_final_position_rule_decides_on_features_leaving_the_image():
+    """OpenCV's LKTrackerInvoker re-tests the FINAL position (stored point - half window) against
+    [-21, cols) x [-21, rows) behind its iteration loop when the caller passes `err`, as the reference does
+    (FrameSourceWarp.cpp:250-259), and drops the feature when its window has left the image.  These seeded pairs each
+    hold a feature that every in-loop test lets through and only that rule drops: its last Gauss-Newton step carries
+    it across the limit.  Positions are untouched by the rule; only the status byte differs."""
+    decided = 0
+    for seed in LK_EDGE_SEEDS:
+        prev, nxt, pts = synth.edge_leaving_pair(seed)
+        h, w = prev.shape
+        oracle.set_lk_final_check(False)
+        try:
+            b, sb = oracle.pyr_lk(prev, nxt, pts)
+        finally:
+            oracle.set_lk_final_check(True)
+        a, sa = oracle.pyr_lk(prev, nxt, pts)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        flipped = np.nonzero(sa != sb)[0]
+        assert len(flipped) >= 1 and (sb[flipped] == 1).all() and (sa[flipped] == 0).all()
+        fx, fy = np.floor(a[:, 0] - np.float32(10)), np.floor(a[:, 1] - np.float32(10))
+        outside = (fx < -21) | (fx >= w) | (fy < -21) | (fy >= h)
+        assert outside[flipped].all()            # the rule fired because the final window is outside ...
+        assert not (outside & (sa == 1)).any()   # ... and no surviving feature is outside
+        decided += len(flipped)
+    assert decided >= len(LK_EDGE_SEEDS)

@@ -180,3 +180,25 @@ def test_tracking_parity_at_4k(vs, cuda):
     onxt, ost = oracle.pyr_lk(g0, g1, exp)
     assert np.array_equal(st, ost) and np.array_equal(nxt.view(np.uint32), onxt.view(np.uint32))
     assert st.sum() > 150
+
+
+def test_lk_features_leaving_the_image_final_position_rule(vs, cuda):
+    """OpenCV's test of the final position behind the iteration loop (the reference passes `err`,
+    FrameSourceWarp.cpp:250-259): seeded pairs in which a feature is dropped by that rule alone
+    (tests/test_oracle_cpu.py shows it decides); HIP = oracle in every coordinate bit and every status byte."""
+    from test_oracle_cpu import LK_EDGE_SEEDS
+    dropped = 0
+    for seed in LK_EDGE_SEEDS:
+        prev, nxt, pts = synth.edge_leaving_pair(seed)
+        exp, est = oracle.pyr_lk(prev, nxt, pts)
+        got, gst = vs.pyr_lk(dev(prev, cuda), dev(nxt, cuda), pts)
+        assert np.array_equal(gst, est), (seed, np.nonzero(gst != est)[0])
+        ok = est > 0
+        assert np.array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32)), seed
+        oracle.set_lk_final_check(False)
+        try:
+            _, loose = oracle.pyr_lk(prev, nxt, pts)
+        finally:
+            oracle.set_lk_final_check(True)
+        dropped += int((loose != est).sum())
+    assert dropped >= len(LK_EDGE_SEEDS)

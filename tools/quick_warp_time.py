@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 vs = importlib.import_module("video-annotator_amd")
 w, h = int(os.environ.get("QW", 3840)), int(os.environ.get("QH", 2160))
 mode, fmt = int(os.environ.get("QMODE", 0)), int(os.environ.get("QFMT", 0))
-if mode == 0:
+if mode in (0, 5):
     K = vs.get_preset_camera(4, w, h); Ko, (cw, ch) = vs.get_output_camera(K, w, h)
 else:
     in_fish, out_fish = mode in (1, 2), mode in (2, 4)

@@ -74,7 +74,7 @@ class Profile(_c.Structure):  # vstab_profile
 
 SMOOTHER_SG, SMOOTHER_KALMAN, SMOOTHER_NONE, SMOOTHER_FIXED = 0, 1, 2, 3
 PROJ_RECT, PROJ_FISH = 0, 1
-MAP_CREATEMAP_CL, MAP_FISH_TO_RECT, MAP_FISH_TO_FISH, MAP_RECT_TO_RECT, MAP_RECT_TO_FISH = range(5)
+MAP_CREATEMAP_CL, MAP_FISH_TO_RECT, MAP_FISH_TO_FISH, MAP_RECT_TO_RECT, MAP_RECT_TO_FISH, MAP_CREATEMAP_CL_OPENCL = range(6)
 OUT_BGR8, OUT_NV12 = 0, 1
 _pp = _c.POINTER(_vp)
 

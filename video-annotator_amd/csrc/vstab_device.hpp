@@ -212,13 +212,102 @@ __device__ __forceinline__ void map_pixel32_x2(float icx32, float icy32, float i
 // (axis ray: correction factor 1 instead of 0/0; rays behind the camera: outside instead of mirrored).
 // ---------------------------------------------------------------------------------------------
 enum MapMode { MAP_CREATEMAP_CL = 0, MAP_FISH_TO_RECT = 1, MAP_FISH_TO_FISH = 2, MAP_RECT_TO_RECT = 3, MAP_RECT_TO_FISH = 4,
+               // createMap.cl with the arithmetic ROCm's OpenCL compiler gives it on gfx950 (below)
+               MAP_CREATEMAP_CL_OPENCL = 5,
                // internal: modes 0 / 1 with a per-row rotation (rolling shutter, BASELINE config 5)
-               MAP_RS_CREATEMAP_CL = 5, MAP_RS_FISH_TO_RECT = 6 };
+               MAP_RS_CREATEMAP_CL = 6, MAP_RS_FISH_TO_RECT = 7 };
 template <int MODE>
 struct ModeTraits {
     static constexpr bool out_fish = MODE == MAP_FISH_TO_FISH || MODE == MAP_RECT_TO_FISH;
-    static constexpr bool in_fish = MODE == MAP_FISH_TO_RECT || MODE == MAP_FISH_TO_FISH || MODE == MAP_CREATEMAP_CL;
+    static constexpr bool in_fish = MODE == MAP_FISH_TO_RECT || MODE == MAP_FISH_TO_FISH || MODE == MAP_CREATEMAP_CL || MODE == MAP_CREATEMAP_CL_OPENCL;
 };
+
+// ---------------------------------------------------------------------------------------------
+// createMap.cl:13-50 AS THE REFERENCE'S OWN KERNEL COMPUTES IT ON THIS GPU.  The reference hands createMap.cl to the
+// OpenCL runtime (FrameSourceWarp.cpp:224,301), whose compiler is free to contract a*b+c (FP_CONTRACT is ON in OpenCL
+// C), to divide within 2.5 ulp, to take length() within 3 and atan() within 5.  oracle/_ref/createMap.gfx950.co is
+// that file built by ROCm's OpenCL front end for gfx950; its instruction stream is (llvm-objdump -d):
+//   a / b      = ldexp(frexp_mant(a) * v_rcp_f32(frexp_mant(b)), frexp_exp(a) - frexp_exp(b))
+//   dot(r, v)  = fma(r1, vy, r0 * vx) + r2           (the * 1 of the third component folded away)
+//   length(p)  = v_sqrt_f32(fma(py, py, px * px))      with ocml's rescaling outside [2^-126, inf)
+//   atan(x)    = ocml's: t = x > 1 ? v_rcp_f32(x) : x, odd polynomial of degree 17 in t, pi/2 - . when reciprocated
+//   map        = fma(focal, p * k, centre)
+// The functions below are that stream, operation for operation; tests/test_refcl_gpu.py compares them bit for bit with
+// the code object run on the same device.  v_rcp_f32 / v_sqrt_f32 are hardware approximations (1 ulp), so this mode
+// has no CPU restatement: its checker is the reference's own kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr float f32_bits(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ float ocl_div(float a, float b) {
+    const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_frexp_mantf(b));
+    const float m = __builtin_amdgcn_frexp_mantf(a) * r;
+    return __builtin_ldexpf(m, __builtin_amdgcn_frexp_expf(a) - __builtin_amdgcn_frexp_expf(b));
+}
+__device__ __forceinline__ float ocl_sqrt_scaled(float x) {  // ocml's native-precision sqrt: denormal inputs rescaled
+    const bool small = 0x1p-126f > x;
+    const float y = __builtin_amdgcn_sqrtf(__builtin_ldexpf(x, small ? 32 : 0));
+    return __builtin_ldexpf(y, small ? -16 : 0);
+}
+__device__ __forceinline__ float ocl_length2(float px, float py) {
+    const float q = __builtin_fmaf(py, py, px * px);
+    if (!(0x1p-126f > q)) {  // also NaN
+        if (q != __builtin_inff()) return __builtin_amdgcn_sqrtf(q);
+        const float a = px * 0x1p-65f, b = py * 0x1p-65f;
+        return 0x1p65f * ocl_sqrt_scaled(__builtin_fmaf(b, b, a * a));
+    }
+    const float a = px * 0x1p86f, b = py * 0x1p86f;
+    return 0x1p-86f * ocl_sqrt_scaled(__builtin_fmaf(b, b, a * a));
+}
+// ocml atan, given t = |x| > 1 ? 1 / |x| : |x| (the reciprocal is a raw v_rcp_f32 there)
+__device__ __forceinline__ float ocl_atan_poly(float t, bool inv) {
+    const float s = t * t;
+    float p = __builtin_fmaf(f32_bits(0x3b2d2a58u), s, f32_bits(0xbc7a590cu));
+    p = __builtin_fmaf(s, p, f32_bits(0x3d29fb3fu));
+    p = __builtin_fmaf(s, p, f32_bits(0xbd97d4d7u));
+    p = __builtin_fmaf(s, p, f32_bits(0x3dd931b2u));
+    p = __builtin_fmaf(s, p, f32_bits(0xbe1160e6u));
+    p = __builtin_fmaf(s, p, f32_bits(0x3e4cb8bfu));
+    p = __builtin_fmaf(s, p, f32_bits(0xbeaaaa62u));
+    const float r = __builtin_fmaf(t, s * p, t);
+    return inv ? f32_bits(0x3fc90fdbu) - r : r;
+}
+__device__ __forceinline__ float ocl_atan(float x) {
+    const float a = __builtin_fabsf(x);
+    const bool inv = a > 1.0f;
+    return __builtin_copysignf(ocl_atan_poly(inv ? __builtin_amdgcn_rcpf(a) : a, inv), x);
+}
+// One pixel, the code object's stream literally.  vx, vy = ocl_div(x - ocx, ofx), ocl_div(y - ocy, ofy); a = r_i0 * vx.
+// c = centre, f = focal length of the input camera (both may carry cv::remap's exact factor 32).
+__device__ __forceinline__ void map_pixel_ocl_literal(float icx, float icy, float ifx, float ify, const MapParams &P, float a0, float a1, float a2,
+                                                      float vy, float &ax, float &ay) {
+    const float wz = __builtin_fmaf(P.r[7], vy, a2) + P.r[8];
+    const float wx = __builtin_fmaf(P.r[1], vy, a0) + P.r[2];
+    const float wy = __builtin_fmaf(P.r[4], vy, a1) + P.r[5];
+    const float px = ocl_div(wx, wz), py = ocl_div(wy, wz);
+    const float rad = ocl_length2(px, py);
+    const float k = ocl_div(ocl_atan(rad), rad);
+    ax = __builtin_fmaf(ifx, px * k, icx);
+    ay = __builtin_fmaf(ify, py * k, icy);
+}
+// The same results from fewer instructions wherever no intermediate leaves the normal range: a multiplication's
+// rounding does not depend on its operands' exponents and v_rcp_f32 works on the significand alone, so
+// frexp / ldexp around `a * rcp(b)` change nothing, and the reciprocal of the radius serves both atan's argument
+// reduction and the final division.  `regular` says whether that holds for this pixel (else: the literal stream).
+__device__ __forceinline__ bool map_pixel_ocl_fast(float icx, float icy, float ifx, float ify, const MapParams &P, float a0, float a1, float a2,
+                                                   float vy, float &ax, float &ay) {
+    const float wz = __builtin_fmaf(P.r[7], vy, a2) + P.r[8];
+    const float wx = __builtin_fmaf(P.r[1], vy, a0) + P.r[2];
+    const float wy = __builtin_fmaf(P.r[4], vy, a1) + P.r[5];
+    const float rz = __builtin_amdgcn_rcpf(wz);
+    const float px = wx * rz, py = wy * rz;
+    const float q = __builtin_fmaf(py, py, px * px);
+    const float rad = __builtin_amdgcn_sqrtf(q), rr = __builtin_amdgcn_rcpf(rad);
+    const bool inv = rad > 1.0f;
+    const float k = ocl_atan_poly(inv ? rr : rad, inv) * rr;
+    ax = __builtin_fmaf(ifx, px * k, icx);
+    ay = __builtin_fmaf(ify, py * k, icy);
+    const float az = __builtin_fabsf(wz);
+    return az >= 0x1p-40f && az <= 0x1p40f && q >= 0x1p-80f && q <= 0x1p80f;  // false for NaN
+}
 
 // sin, cos on [0, pi]: quadrant reduction with a two-constant pi/2, Cephes single-precision polynomials
 __device__ __forceinline__ void sincos_pos(float t, float &sn, float &cs) {
@@ -234,6 +323,13 @@ __device__ __forceinline__ void sincos_pos(float t, float &sn, float &cs) {
     cs = k == 1.0f ? -s : k == 2.0f ? -c : c;
 }
 
+// Normalised output coordinate (createMap.cl:16-17) as the mode divides: IEEE, or the OpenCL build's reciprocal form.
+template <int MODE>
+__device__ __forceinline__ float norm_coord(float n, float d, float rcp_refined_d) {
+    if constexpr (MODE == MAP_CREATEMAP_CL_OPENCL) return ocl_div(n, d);
+    else return div_with_rcp(n, d, rcp_refined_d);
+}
+
 // One pixel of the generalised map.  p holds the input camera (scaled by 32 in the fused kernel, unscaled in
 // the map-plane kernel -- the scaling is an exact power of two either way), P the output camera and rotation.
 // c / r are the hoisted column / row products for pinhole output; vx, vy the normalised output coordinates for
@@ -243,6 +339,9 @@ __device__ __forceinline__ void map_pixel_ex(const MapParams32 &p, const MapPara
                                              float vx, float vy, float &ax, float &ay) {
     if constexpr (MODE == MAP_CREATEMAP_CL) {
         map_pixel32(p, c, r, ax, ay);
+    } else if constexpr (MODE == MAP_CREATEMAP_CL_OPENCL) {
+        if (!map_pixel_ocl_fast(p.icx32, p.icy32, p.ifx32, p.ify32, P, c.a0, c.a1, c.a2, vy, ax, ay))
+            map_pixel_ocl_literal(p.icx32, p.icy32, p.ifx32, p.ify32, P, c.a0, c.a1, c.a2, vy, ax, ay);
     } else {
         float wx, wy, wz;
         bool ok = true;

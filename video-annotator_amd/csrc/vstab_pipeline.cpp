@@ -298,8 +298,7 @@ class Tracker {
         spec_state_.store(0, std::memory_order_release), spec_tag_ = -1;
     }
     ~Tracker() {
-        for (hipEvent_t e : {spec_ev_, ev_a_, ev_b_})
-            if (e) (void)hipEventDestroy(e);
+        // the helper thread polls spec_ev_ while a selection is running: stop and join it BEFORE the events go
         if (spec_thread_started_) {
             {
                 std::lock_guard<std::mutex> lk(spec_m_);
@@ -308,6 +307,8 @@ class Tracker {
             spec_cv_.notify_one();
             spec_thread_.join();
         }
+        for (hipEvent_t e : {spec_ev_, ev_a_, ev_b_})
+            if (e) (void)hipEventDestroy(e);
     }
     // returns true and fills xy if the speculative result is usable (candidate count within SPEC_CAP)
     bool spec_finish(int max_corners, double min_distance, std::vector<float> &xy) {
@@ -841,6 +842,8 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
     if (f.bit_depth != 0 && f.bit_depth != 8 && f.bit_depth != 10 && f.bit_depth != 12 && f.bit_depth != 16)
         return fail(VSTAB_ERR_INVALID, "vstab_frame.bit_depth must be 8, 10, 12 or 16");
     if (wide && f.mem != 0) return fail(VSTAB_ERR_INVALID, "16-bit frames must be in device memory");
+    if (H->cfg.pixel_depth == 10 && !wide) return fail(VSTAB_ERR_INVALID, "a pixel_depth 10 handle needs P010 device frames (vstab_frame.bit_depth > 8)");
+    S.y16 = S.uv16 = nullptr;  // set again below when this frame has 16-bit planes to warp from
     if (f.mem == 0 && !wide && f.hold >= H->borrow_hold) {
         // zero copy: track, build the pyramid from and warp upstream's planes where they are
         S.y = static_cast<const uint8_t *>(f.y), S.uv = static_cast<const uint8_t *>(f.uv), S.pitch_y = f.pitch_y, S.pitch_uv = f.pitch_uv;
@@ -857,7 +860,6 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
         VSTAB_TRY(vstab_handle::wait_if_pending(H->pstream, H->warp_events[S.warped]));
         S.warp_pending = false, S.warped = -1;
     }
-    if (H->cfg.pixel_depth == 10 && !wide) return fail(VSTAB_ERR_INVALID, "a pixel_depth 10 handle needs P010 device frames (vstab_frame.bit_depth > 8)");
     if (wide) {
         VSTAB_TRY(pack_p010_planes(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->cfg.pixel_depth == 10, H->pstream));
         if (H->cfg.pixel_depth == 10) {  // the warp reads the 16-bit planes; the tracker the narrowed luma above

@@ -816,6 +816,13 @@ __global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid 
                 }
                 pdx = dx, pdy = dy;
             }
+            // OpenCV's LKTrackerInvoker, behind the loop (the reference passes `err`, FrameSourceWarp.cpp:250-259): at
+            // level 0 the final position -- the stored point minus the half window -- is tested against the image once
+            // more, and a feature whose last step (or half-step correction) carried its window out is dropped.
+            if (level == 0 && st) {
+                const int fnx = (int)floorf(np.x - half), fny = (int)floorf(np.y - half);
+                if (fnx < -LKW || fnx >= w || fny < -LKW || fny >= h) st = 0;
+            }
         } while (false);
         // the block fetched for the next level goes into the other buffer (its last readers left at the barrier of
         // the level before this one; the next level's first barrier publishes it)

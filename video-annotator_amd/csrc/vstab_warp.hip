@@ -152,14 +152,18 @@ __global__ void __launch_bounds__(256) k_create_map_ex(float *__restrict__ mapx,
     const int y = blockIdx.y * 16 + threadIdx.y;
     if (x0 >= cols || y >= rows) return;
     const MapParams32 in = {p.icx, p.icy, p.ifx, p.ify, p.r[2], p.r[5], p.r[8]};  // unscaled here
-    const float vy = ((float)y - p.ocy) / p.ofy;
+    constexpr bool OCL = MODE == MAP_CREATEMAP_CL_OPENCL;
+    const float vy = OCL ? ocl_div((float)y - p.ocy, p.ofy) : ((float)y - p.ocy) / p.ofy;
     const RowTerm rt = {p.r[1] * vy, p.r[4] * vy, p.r[7] * vy};
     float mx[4], my[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const float vx = ((float)(x0 + i) - p.ocx) / p.ofx;
+        const float vx = OCL ? ocl_div((float)(x0 + i) - p.ocx, p.ofx) : ((float)(x0 + i) - p.ocx) / p.ofx;
         const ColTerm ct = {p.r[0] * vx, p.r[3] * vx, p.r[6] * vx};
-        map_pixel_ex<MODE>(in, p, ct, rt, vx, vy, mx[i], my[i]);
+        // the map-plane operator runs the OpenCL build's instruction stream literally; the fused kernel and the
+        // quantised map use its shortened form with this one as the fall-back (vstab_device.hpp)
+        if constexpr (OCL) map_pixel_ocl_literal(p.icx, p.icy, p.ifx, p.ify, p, ct.a0, ct.a1, ct.a2, vy, mx[i], my[i]);
+        else map_pixel_ex<MODE>(in, p, ct, rt, vx, vy, mx[i], my[i]);
     }
     float *px = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(mapx) + (size_t)y * pitch_x) + x0;
     float *py = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(mapy) + (size_t)y * pitch_y) + x0;
@@ -274,12 +278,12 @@ __global__ void __launch_bounds__(256) k_quantised_map(int2 *__restrict__ qmap, 
     const int x0 = (blockIdx.x * 16 + (threadIdx.x & 15)) * 4, y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x0 >= qpitch || y >= dh) return;
     const float rfx = rcp_refined(p.ofx), rfy = rcp_refined(p.ofy);
-    const float vy = div_with_rcp((float)y - p.ocy, p.ofy, rfy);
+    const float vy = norm_coord<MODE>((float)y - p.ocy, p.ofy, rfy);
     const RowTerm rt = {p.r[1] * vy, p.r[4] * vy, p.r[7] * vy};
     int q[8];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const float vx = div_with_rcp((float)(x0 + i) - p.ocx, p.ofx, rfx);
+        const float vx = norm_coord<MODE>((float)(x0 + i) - p.ocx, p.ofx, rfx);
         const ColTerm ct = {p.r[0] * vx, p.r[3] * vx, p.r[6] * vx};
         float ax, ay;
         map_pixel_ex<MODE>(p32, p, ct, rt, vx, vy, ax, ay);
@@ -411,7 +415,7 @@ vstab_status vstab_create_map_ex(void *map_x, size_t pitch_x, void *map_y, size_
         return fail(VSTAB_ERR_INVALID, "vstab_create_map: size must be in [1, 32767] (createMap.cl:10-11)");
     if (pitch_x < (size_t)cols * 4 || pitch_y < (size_t)cols * 4 || pitch_x % 4 || pitch_y % 4)
         return fail(VSTAB_ERR_INVALID, "vstab_create_map: bad pitch");
-    if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_RECT_TO_FISH) return fail(VSTAB_ERR_INVALID, "vstab_create_map: unknown map mode");
+    if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_CREATEMAP_CL_OPENCL) return fail(VSTAB_ERR_INVALID, "vstab_create_map: unknown map mode");
     const int vec_ok = aligned(map_x, 16) && aligned(map_y, 16) && pitch_x % 16 == 0 && pitch_y % 16 == 0;
     dim3 grid(div_up(div_up(cols, 4), 16), div_up(rows, 16));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -421,7 +425,8 @@ vstab_status vstab_create_map_ex(void *map_x, size_t pitch_x, void *map_y, size_
         case VSTAB_MAP_FISH_TO_RECT: VSTAB_LAUNCH(k_create_map_ex<MAP_FISH_TO_RECT>); break;
         case VSTAB_MAP_FISH_TO_FISH: VSTAB_LAUNCH(k_create_map_ex<MAP_FISH_TO_FISH>); break;
         case VSTAB_MAP_RECT_TO_RECT: VSTAB_LAUNCH(k_create_map_ex<MAP_RECT_TO_RECT>); break;
-        default: VSTAB_LAUNCH(k_create_map_ex<MAP_RECT_TO_FISH>); break;
+        case VSTAB_MAP_RECT_TO_FISH: VSTAB_LAUNCH(k_create_map_ex<MAP_RECT_TO_FISH>); break;
+        default: VSTAB_LAUNCH(k_create_map_ex<MAP_CREATEMAP_CL_OPENCL>); break;
     }
 #undef VSTAB_LAUNCH
     VSTAB_HIP_TRY(hipGetLastError());
@@ -468,7 +473,7 @@ static vstab_status warp_impl(const void *y, size_t pitch_y, const void *uv, siz
         return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: source must be even-sized and <= 32767");
     if (dw <= 0 || dh <= 0 || dw > 32767 || dh > 32767)
         return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: output size must be in [1, 32767]");
-    if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_RECT_TO_FISH) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: unknown map mode");
+    if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_CREATEMAP_CL_OPENCL) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: unknown map mode");
     if (out_format != VSTAB_OUT_BGR8 && out_format != VSTAB_OUT_NV12) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: unknown output format");
     const bool nv12_out = out_format == VSTAB_OUT_NV12;
     if (pitch_y < (size_t)sw || pitch_uv < (size_t)sw || pitch_dst < (size_t)dw * (nv12_out ? 1 : 3))
@@ -537,7 +542,7 @@ size_t vstab_quantised_map_bytes(int dst_width, int dst_height) {
 
 vstab_status vstab_quantised_map(void *qmap, int dw, int dh, const float params[17], int map_mode, void *stream) {
     if (!qmap || !params || dw <= 0 || dh <= 0 || dw > 32767 || dh > 32767) return fail(VSTAB_ERR_INVALID, "vstab_quantised_map: bad argument");
-    if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_RECT_TO_FISH) return fail(VSTAB_ERR_INVALID, "vstab_quantised_map: unknown map mode");
+    if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_CREATEMAP_CL_OPENCL) return fail(VSTAB_ERR_INVALID, "vstab_quantised_map: unknown map mode");
     if (!aligned(qmap, 16)) return fail(VSTAB_ERR_INVALID, "vstab_quantised_map: the buffer must be 16-byte aligned");
     const int qpitch = (dw + 3) & ~3;
     const MapParams p = to_params(params);
@@ -550,7 +555,8 @@ vstab_status vstab_quantised_map(void *qmap, int dw, int dh, const float params[
         case VSTAB_MAP_FISH_TO_RECT: VSTAB_LAUNCH(MAP_FISH_TO_RECT); break;
         case VSTAB_MAP_FISH_TO_FISH: VSTAB_LAUNCH(MAP_FISH_TO_FISH); break;
         case VSTAB_MAP_RECT_TO_RECT: VSTAB_LAUNCH(MAP_RECT_TO_RECT); break;
-        default: VSTAB_LAUNCH(MAP_RECT_TO_FISH); break;
+        case VSTAB_MAP_RECT_TO_FISH: VSTAB_LAUNCH(MAP_RECT_TO_FISH); break;
+        default: VSTAB_LAUNCH(MAP_CREATEMAP_CL_OPENCL); break;
     }
 #undef VSTAB_LAUNCH
     VSTAB_HIP_TRY(hipGetLastError());

@@ -95,7 +95,7 @@ __device__ __forceinline__ void probe_tile(const FusedArgs &ta, int tile_x, int 
         qx = q.x, qy = q.y;
     } else {
         float ax, ay;
-        if constexpr (BASE == MAP_CREATEMAP_CL || BASE == MAP_FISH_TO_RECT) {
+        if constexpr (BASE == MAP_CREATEMAP_CL || BASE == MAP_FISH_TO_RECT || BASE == MAP_CREATEMAP_CL_OPENCL) {
             // The box needs the map to a fraction of a pixel only (it has a pixel of margin and never decides a result),
             // so the probe uses the approximate reciprocal / rsqrt instructions and fused operations: a third of the
             // dependent chain of the exact evaluation, on the one wave the other three are waiting for.
@@ -255,14 +255,14 @@ __global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
             qxb[j] = q.x, qyb[j] = q.y;
         }
     } else {
-        float vx = div_with_rcp((float)x - a.p.ocx, a.p.ofx, rfx);
+        float vx = norm_coord<BASE>((float)x - a.p.ocx, a.p.ofx, rfx);
         // the compiler would sink each map evaluation to its use behind the barrier; these two statements pin the map
         // phase between the loads above (memory clobber) and the conversion below (the coordinates pass through)
         asm volatile("" : "+v"(vx) : : "memory");
         const ColTerm ct = {a.p.r[0] * vx, a.p.r[3] * vx, a.p.r[6] * vx};
         // row terms: lane l < R evaluates row l of this wave once; every lane then reads them from that lane
         const int y_l = y0 + wave * R + (lane & (R - 1));
-        const float vy_l = div_with_rcp((float)y_l - a.p.ocy, a.p.ofy, rfy);
+        const float vy_l = norm_coord<BASE>((float)y_l - a.p.ocy, a.p.ofy, rfy);
         float m_l[9];  // the rotation of row y_l: the frame's, or interpolated towards the last row's (rolling shutter)
 #pragma unroll
         for (int k = 0; k < 9; k++) m_l[k] = a.p.r[k];
@@ -526,6 +526,7 @@ vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int ma
             case VSTAB_MAP_FISH_TO_FISH: VSTAB_LAUNCH_RF(MAP_FISH_TO_FISH, false); break;
             case VSTAB_MAP_RECT_TO_RECT: VSTAB_LAUNCH_RF(MAP_RECT_TO_RECT, false); break;
             case VSTAB_MAP_RECT_TO_FISH: VSTAB_LAUNCH_RF(MAP_RECT_TO_FISH, false); break;
+            case VSTAB_MAP_CREATEMAP_CL_OPENCL: VSTAB_LAUNCH_RF(MAP_CREATEMAP_CL_OPENCL, false); break;
             case MAP_RS_CREATEMAP_CL: VSTAB_LAUNCH_RF(MAP_RS_CREATEMAP_CL, false); break;
             default: VSTAB_LAUNCH_RF(MAP_RS_FISH_TO_RECT, false); break;
         }
