@@ -225,8 +225,8 @@ struct ModeTraits {
 // ---------------------------------------------------------------------------------------------
 // createMap.cl:13-50 AS THE REFERENCE'S OWN KERNEL COMPUTES IT ON THIS GPU.  The reference hands createMap.cl to the
 // OpenCL runtime (FrameSourceWarp.cpp:224,301), whose compiler is free to contract a*b+c (FP_CONTRACT is ON in OpenCL
-// C), to divide within 2.5 ulp, to take length() within 3 and atan() within 5.  oracle/_ref/createMap.gfx950.co is
-// that file built by ROCm's OpenCL front end for gfx950; its instruction stream is (llvm-objdump -d):
+// C), to divide within 2.5 ulp, to take length() within 3 and atan() within 5.  The test infrastructure holds
+// that file built by ROCm's OpenCL front end for gfx950 (createMap.gfx950.co); its instruction stream is (llvm-objdump -d):
 //   a / b      = ldexp(frexp_mant(a) * v_rcp_f32(frexp_mant(b)), frexp_exp(a) - frexp_exp(b))
 //   dot(r, v)  = fma(r1, vy, r0 * vx) + r2           (the * 1 of the third component folded away)
 //   length(p)  = v_sqrt_f32(fma(py, py, px * px))      with ocml's rescaling outside [2^-126, inf)
