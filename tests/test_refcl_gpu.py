@@ -164,9 +164,12 @@ def test_ieee_mode_deviation_from_the_reference_kernel_on_gfx950_is_pinned(refcl
         json.dump(table, f, indent=1)
     for i in range(3):
         for t in (table[f"params_{i}"]["x"], table[f"params_{i}"]["y"]):
-            assert t["identical"] > 0.40 and t["max_ulp"] <= 32 and t["rel_max_x2p23"] <= 8 and t["bucket_flips"] < 0.006, (i, t)
+            # measured (profiles/r03_a9_ieee_vs_reference_gfx950.json): 51-58 % of the entries identical, 9-16 % differ by more
+            # than one ULP, at most 21; <= 4.1 x 2^-23 of the (map - centre) term; 0.19-0.31 % of the 1/32-px buckets flip
+            assert t["identical"] > 0.45 and t["gt1ulp"] < 0.20 and t["max_ulp"] <= 28 and t["rel_max_x2p23"] <= 5.5 and t["bucket_flips"] < 0.004, (i, t)
         grey = table[f"params_{i}"]["grey"]
-        assert grey["bytes_changed"] < 1e-3 and grey["max_levels"] <= 16 and grey["more_than_one"] < 1e-4, (i, grey)
+        # after cv::remap: 2.0e-4 of the output bytes change, by at most 7 levels, 1.2e-5 of them by more than one
+        assert grey["bytes_changed"] < 3e-4 and grey["max_levels"] <= 10 and grey["more_than_one"] < 2e-5, (i, grey)
 
 
 def test_x86_cross_check_build_vs_the_gfx950_build_of_the_same_kernel(refcl, cuda):
