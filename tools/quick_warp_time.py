@@ -3,7 +3,12 @@ env: QW, QH source size; QMODE 0..4 (map mode; 0 = createMap.cl preset cameras);
 import importlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-vs = importlib.import_module("video-annotator_amd")
+if os.environ.get("QDEV"):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import devlib
+    vs = devlib.load()
+else:
+    vs = importlib.import_module("video-annotator_amd")
 w, h = int(os.environ.get("QW", 3840)), int(os.environ.get("QH", 2160))
 mode, fmt = int(os.environ.get("QMODE", 0)), int(os.environ.get("QFMT", 0))
 if mode in (0, 5):
@@ -27,9 +32,22 @@ for i in range(nf): run(i)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 n = 200
-e0.record()
-for i in range(n): run(i)
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / n
+ns = int(os.environ.get("QSTREAMS", 1))   # > 1: consecutive frames on alternating streams (their kernels may overlap)
+if ns == 1:
+    e0.record()
+    for i in range(n): run(i)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+else:
+    import time
+    streams = [torch.cuda.Stream() for _ in range(ns)]
+    for i in range(2 * ns):
+        with torch.cuda.stream(streams[i % ns]): run(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        with torch.cuda.stream(streams[i % ns]): run(i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / n
 b = w * h * 1.5 + out_bytes
 print(f"warp {w}x{h} -> {cw}x{ch} mode {mode} fmt {fmt}: {ms*1000:.1f} us/frame  {b/ms/1e6:.1f} GB/s  ({b/ms/1e6/8000*100:.1f}% of 8 TB/s)")

@@ -14,7 +14,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("VSTAB_LIB_PATH") or os.path.join(_HERE, "lib", "libvstab.so")  # override: A/B runs of two builds
+# Always the in-tree product library.  (Development tools that want another build load this module by hand and plant a
+# path in its namespace first -- tools/devlib.py; no environment variable can swap the library under the tests.)
+LIB_PATH = globals().get("_VSTAB_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libvstab.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

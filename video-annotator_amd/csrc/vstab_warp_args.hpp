@@ -26,6 +26,8 @@ struct FusedArgs {
     int qpitch;        // its row pitch in pixels (a multiple of 4)
     float rs_d[9];     // rolling-shutter modes: rotation of the last output row minus rotation of the first (w.p.r), fp32
     float rs_den;      // and (float)max(dh - 1, 1)
+    int band_y[9];     // XCD k (= blockIdx % 8) owns output rows [band_y[k], band_y[k + 1])
+    int split_y[8];    // in its band: rows below split_y[k] in tall tiles (4 RWB rows), from it on in half-height tiles
 #ifdef VSTAB_DEV
     unsigned long long *timing;  // development builds: 4 qwords per workgroup {memrealtime, memtime at entry and exit}
     int ablate;                  // timing-only ablations (wrong pixels): 1 linear map, 2 xor blend, 4 raw conversion, 8 no stores

@@ -5,23 +5,27 @@
 // Converting each tap and then blending is exactly what the reference's cvtColor-then-remap sequence computes, so the
 // output is bit-identical to the un-fused operators.  Compiled with -ffp-contract=off.
 //
-// One workgroup (4 waves) per 64 x 4R output tile; lane = output column, a wave owns R consecutive output rows.
-//   probe    wave 0 evaluates the map on 64 perimeter pixels of the tile and reduces them (DPP) to the tile's source
-//            bounding box.  A continuous map attains its coordinate extremes on the perimeter.  One barrier.
+// One workgroup (4 waves) per output tile of 64 columns x 4 RW rows; lane = output column, a wave owns RW consecutive
+// rows.  A launch mixes two tile heights: RW = RWB for the bulk of the image and RW = RWB / 2 for the last rows of every
+// XCD's band, so that the last round of workgroups -- which cannot fill the chip -- is made of tiles half as long.
+//   probe    wave 0 evaluates the map on 64 perimeter pixels of the tile (approximate arithmetic) and reduces them (DPP)
+//            to the tile's source bounding box.  A continuous map attains its coordinate extremes on the perimeter.
 //   load     all global loads of the thread's share of the box (8 x 2 blocks: two luma rows + one chroma row, 8-byte
 //            loads) are issued at once ...
-//   map      ... and the R exact map evaluations of the thread (hand-scheduled IEEE arithmetic, two rows at a time
-//            through the packed-fp32 pipe) run underneath their latency.  Quantised coordinates stay in registers.
+//   map      ... and the RW exact map evaluations of the thread run underneath their latency: two rows per packed-fp32
+//            instruction, the RW / 2 row pairs advanced in lock-step so that no instruction waits for its predecessor.
 //   convert  the loaded blocks are converted ONCE per source pixel to BGRx with the cvtColor fixed-point arithmetic and
 //            written to LDS (ds_write_b128); blocks outside the source become the zero border of BORDER_CONSTANT.
-//            One barrier.
-//   sample   four ds_read per pixel (lanes walk along a source row: at most 2-way bank conflicts), exact fixed-point
-//            blend, rows transposed to 4-byte-per-lane stores with ds_bpermute.
+//   sample   when every footprint of the wave lies inside the staged box (the normal case, one wave-uniform test) all
+//            2 RW tap-pair reads of a thread are issued before the first blend; otherwise pixel by pixel with the
+//            global-memory gather for footprints outside the box.
+//   store    rows transposed to 4-byte-per-lane stores with ds_bpermute.
 // Bit-exactness never depends on the box: a pixel whose 2x2 footprint is not inside the staged box (degenerate
 // rotations, a box larger than the LDS budget, unaligned planes) is sampled straight from global memory with per-tap
 // zeroing (gather_pixel), which computes the same integers.  HBM traffic = the NV12 frame once + the output once.
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstdlib>
 
 #include "vstab_device.hpp"
@@ -70,18 +74,21 @@ __device__ __forceinline__ uint32_t gather_pixel_far(const WarpArgs &a, int sx, 
     return gather_pixel(a, sx, sy);
 }
 
-// The source bounding box of output tile (tile_x, tile_y), from the map on 64 perimeter pixels of the tile (one per lane;
-// a continuous map attains its coordinate extremes on the perimeter).  Lane 0 writes {bx0, by0, wb, hb, use_lds, tile
-// index} to hdr.  Run by one wave.
-template <int R, int MODE, bool CACHED>
-__device__ __forceinline__ void probe_tile(const FusedArgs &ta, int tile_x, int tile_y, int lane, float rfx, float rfy, uint32_t *hdr) {
-    constexpr int TH = 4 * R;
-    constexpr int STAGE_MAX = R == 8 ? 3 : 2;
-    constexpr bool RS = MODE >= MAP_RS_CREATEMAP_CL;          // per-row rotation
+// Trips of the staging loop: STAGE_MAX * 256 blocks of 8 x 2 source pixels must cover the largest box the tile's LDS
+// budget admits (40 KB for kernels whose tall tiles have 32 rows, 24 KB for 16; half-height tiles have smaller boxes).
+template <int RWB, int RW>
+struct StageTrips {
+    static constexpr int value = RW == 8 ? 3 : RW == 4 ? 2 : (RWB == 8 ? 2 : 1);
+};
+
+// The source bounding box of the output tile at (x0, y0), 64 x TH pixels, from the map on 64 perimeter pixels of the
+// tile (one per lane; a continuous map attains its coordinate extremes on the perimeter).  Lane 0 writes
+// {bx0, by0, wb, hb, use_lds} to hdr.  Run by one wave.
+template <int TH, int STAGE_MAX, int MODE, bool CACHED>
+__device__ __forceinline__ void probe_tile(const FusedArgs &ta, int x0, int y0, int lane, float rfx, float rfy, uint32_t *hdr) {
+    constexpr bool RS = MODE >= MAP_RS_CREATEMAP_CL;              // per-row rotation
     constexpr int BASE = RS ? MODE - MAP_RS_CREATEMAP_CL : MODE;  // the projection pair
     const WarpArgs &a = ta.w;
-    const int x0 = tile_x * 64, y0 = tile_y * TH;
-    // ---- probe: the map on 64 perimeter pixels -> source bounding box of the tile --------------------------
     int px, py;  // tile-local perimeter point of this lane: 16 along the top, 16 along the bottom, 16 per side
     const int l16 = lane & 15, side = (l16 * (TH - 1) + 7) / 15;
     if (lane < 16) px = 4 * l16, py = 0;
@@ -135,9 +142,6 @@ __device__ __forceinline__ void probe_tile(const FusedArgs &ta, int tile_x, int 
             const RowTerm rt = {a.p.r[1] * vy, a.p.r[4] * vy, a.p.r[7] * vy};
             map_pixel_ex<BASE>(ta.p32, a.p, ct, rt, vx, vy, ax, ay);
         }
-#ifdef VSTAB_DEV
-        if (ta.ablate & 1) ax = (float)(x0 + px) * (32.0f * (float)a.sw / (float)a.dw), ay = (float)(y0 + py) * (32.0f * (float)a.sh / (float)a.dh);
-#endif
         qx = __float_as_int(ax + QMAGIC) - QMAGIC_BITS, qy = __float_as_int(ay + QMAGIC) - QMAGIC_BITS;
     }
     // clamp to one step outside the source: pixels that map outside pull the box to the nearest edge only
@@ -156,57 +160,163 @@ __device__ __forceinline__ void probe_tile(const FusedArgs &ta, int tile_x, int 
     const bool have = mnx < a.sw && mxx >= -1 && mny < a.sh && mxy >= -1;  // else every pixel of the tile is outside
     // staged as whole 8 x 2 blocks with aligned 8-byte loads: unaligned planes, and boxes that reach the last,
     // partial block column of a source whose width is not a multiple of 8, are sampled straight from global memory
-    const bool use_lds = have && a.sw >= 8 && wb * hb <= ta.lds_capacity_px && (wb >> 3) * (hb >> 1) <= STAGE_MAX * 256 && ta.src_vec_ok &&
-                         ((a.sw & 7) == 0 || bx0 + wb <= (a.sw & ~7));
+    const bool stageable = have && a.sw >= 8 && ta.src_vec_ok && ((a.sw & 7) == 0 || bx0 + wb <= (a.sw & ~7));
+    const bool fits = wb * hb <= ta.lds_capacity_px && (wb >> 3) * (hb >> 1) <= STAGE_MAX * 256;
     if (lane == 0) {
         *reinterpret_cast<uint4 *>(hdr) = make_uint4((uint32_t)bx0, (uint32_t)by0, (uint32_t)wb, (uint32_t)hb);
-        *reinterpret_cast<uint2 *>(hdr + 4) = make_uint2(use_lds ? 1u : 0u, (uint32_t)(tile_y * ta.tiles_x + tile_x));
+        hdr[4] = stageable ? (fits ? 1u : 2u) : 0u;  // 2: the box is over the LDS budget -- a tall tile is then done as two half-height tiles
     }
 }
 
-template <int R, int MODE, int FMT, bool CACHED>
-__global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
-    constexpr int TH = 4 * R;                  // tile height
-    constexpr int STAGE_MAX = R == 8 ? 3 : 2;  // trips of the staging loop: STAGE_MAX * 256 blocks of 8 x 2 source pixels cover the LDS budget
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t *const tile = smem + 8;  // smem[0..5]: the tile header (box, flag, tile index), written by wave 0
+// ---------------------------------------------------------------------------------------------------------------------
+// The exact map of NP row pairs of one column (lane), IEEE mode (MAP_CREATEMAP_CL / MAP_FISH_TO_RECT): the operation
+// sequence of map_pixel32_x2 (vstab_device.hpp) for every pair, written step by step ACROSS the pairs, so that NP
+// independent packed instructions stand between an instruction and the one that needs its result (the compiler
+// otherwise emits the chains one after the other, separated by the s_nop a dependent packed-fp32 instruction needs).
+// ---------------------------------------------------------------------------------------------------------------------
+#define VSTAB_EACH _Pragma("unroll") for (int c = 0; c < NP; c++)
+template <int NP, bool FISH_TO_RECT>
+__device__ __forceinline__ void map_pairs_ieee(float icx32, float icy32, float ifx32, float ify32, const f32x2 (&wx)[NP], const f32x2 (&wy)[NP],
+                                               const f32x2 (&wz)[NP], f32x2 (&ax)[NP], f32x2 (&ay)[NP]) {
+    f32x2 rz[NP], e[NP], px[NP], py[NP], ex[NP], ey[NP], q[NP], y[NP], g[NP], h[NP], d[NP], rad[NP], rr[NP], t[NP], s[NP], at[NP], k[NP];
+    i32x2 inv[NP];
+    const f32x2 one = splat2(1.0f), half = splat2(0.5f);
+    // rz = rcp_refined2(wz)
+    VSTAB_EACH rz[c] = (f32x2){__builtin_amdgcn_rcpf(wz[c].x), __builtin_amdgcn_rcpf(wz[c].y)};
+    VSTAB_EACH e[c] = fma2(-wz[c], rz[c], one);
+    VSTAB_EACH rz[c] = fma2(e[c], rz[c], rz[c]);
+    // px = div_with_rcp2(wx, wz, rz), py = div_with_rcp2(wy, wz, rz)
+    VSTAB_EACH px[c] = wx[c] * rz[c], py[c] = wy[c] * rz[c];
+    VSTAB_EACH ex[c] = fma2(-wz[c], px[c], wx[c]), ey[c] = fma2(-wz[c], py[c], wy[c]);
+    VSTAB_EACH px[c] = fma2(ex[c], rz[c], px[c]), py[c] = fma2(ey[c], rz[c], py[c]);
+    VSTAB_EACH ex[c] = fma2(-wz[c], px[c], wx[c]), ey[c] = fma2(-wz[c], py[c], wy[c]);
+    VSTAB_EACH px[c] = fma2(ex[c], rz[c], px[c]), py[c] = fma2(ey[c], rz[c], py[c]);
+    // q = px * px + py * py ; rad = sqrt_rn2(q)
+    VSTAB_EACH q[c] = px[c] * px[c] + py[c] * py[c];
+    VSTAB_EACH y[c] = (f32x2){__builtin_amdgcn_rsqf(q[c].x), __builtin_amdgcn_rsqf(q[c].y)};
+    VSTAB_EACH g[c] = q[c] * y[c], h[c] = half * y[c];
+    VSTAB_EACH e[c] = fma2(-h[c], g[c], half);
+    VSTAB_EACH h[c] = fma2(h[c], e[c], h[c]), g[c] = fma2(g[c], e[c], g[c]);
+    VSTAB_EACH d[c] = fma2(-g[c], g[c], q[c]);
+    VSTAB_EACH rad[c] = fma2(d[c], h[c], g[c]);
+    // rr = rcp_refined2(rad)
+    VSTAB_EACH rr[c] = (f32x2){__builtin_amdgcn_rcpf(rad[c].x), __builtin_amdgcn_rcpf(rad[c].y)};
+    VSTAB_EACH e[c] = fma2(-rad[c], rr[c], one);
+    VSTAB_EACH rr[c] = fma2(e[c], rr[c], rr[c]);
+    // t = inv ? div_with_rcp2(1, rad, rr) : rad
+    VSTAB_EACH inv[c] = rad[c] > one, t[c] = one * rr[c];
+    VSTAB_EACH e[c] = fma2(-rad[c], t[c], one);
+    VSTAB_EACH t[c] = fma2(e[c], rr[c], t[c]);
+    VSTAB_EACH e[c] = fma2(-rad[c], t[c], one);
+    VSTAB_EACH t[c] = fma2(e[c], rr[c], t[c]);
+    VSTAB_EACH t[c] = inv[c] ? t[c] : rad[c];
+    VSTAB_EACH s[c] = t[c] * t[c];
+    // atan_pos polynomial
+    VSTAB_EACH g[c] = fma2(splat2(0.0028423243202269077f), s[c], splat2(-0.016053270548582077f));
+    VSTAB_EACH g[c] = fma2(g[c], s[c], splat2(0.04269874095916748f));
+    VSTAB_EACH g[c] = fma2(g[c], s[c], splat2(-0.07508683204650879f));
+    VSTAB_EACH g[c] = fma2(g[c], s[c], splat2(0.1064559817314148f));
+    VSTAB_EACH g[c] = fma2(g[c], s[c], splat2(-0.14205896854400635f));
+    VSTAB_EACH g[c] = fma2(g[c], s[c], splat2(0.19993145763874054f));
+    VSTAB_EACH g[c] = fma2(g[c], s[c], splat2(-0.33333125710487366f));
+    VSTAB_EACH at[c] = fma2(t[c] * s[c], g[c], t[c]);
+    VSTAB_EACH at[c] = inv[c] ? (splat2(1.57079637050628662109375f) - at[c]) + splat2(-4.37113900018624283e-8f) : at[c];
+    // k = div_with_rcp2(at, rad, rr)
+    VSTAB_EACH k[c] = at[c] * rr[c];
+    VSTAB_EACH e[c] = fma2(-rad[c], k[c], at[c]);
+    VSTAB_EACH k[c] = fma2(e[c], rr[c], k[c]);
+    VSTAB_EACH e[c] = fma2(-rad[c], k[c], at[c]);
+    VSTAB_EACH k[c] = fma2(e[c], rr[c], k[c]);
+    if constexpr (FISH_TO_RECT) {
+        VSTAB_EACH k[c] = (q[c] == splat2(0.0f)) ? one : k[c];
+    }
+    VSTAB_EACH ax[c] = splat2(icx32) + (px[c] * k[c]) * splat2(ifx32), ay[c] = splat2(icy32) + (py[c] * k[c]) * splat2(ify32);
+    if constexpr (FISH_TO_RECT) {
+        VSTAB_EACH {
+            const i32x2 ok = wz[c] > splat2(0.0f);
+            ax[c] = ok ? ax[c] : splat2(__builtin_nanf("")), ay[c] = ok ? ay[c] : splat2(__builtin_nanf(""));
+        }
+    }
+}
+
+// The same for MAP_CREATEMAP_CL_OPENCL: map_pixel_ocl_fast (vstab_device.hpp) on NP row pairs in lock-step.  Returns
+// non-zero when some intermediate may have left the normal range: the caller then re-evaluates the wave's pixels with the
+// code object's literal instruction stream.  q in [2^-80, 2^80] is the whole test: a rotated ray has a component >= 1/2,
+// so a reciprocal, quotient or square that over- or underflows shows up as q = inf / NaN / tiny (q's bits as unsigned).
+template <int NP>
+__device__ __forceinline__ uint32_t map_pairs_ocl(float icx32, float icy32, float ifx32, float ify32, const f32x2 (&wx)[NP], const f32x2 (&wy)[NP],
+                                                  const f32x2 (&wz)[NP], f32x2 (&ax)[NP], f32x2 (&ay)[NP]) {
+    f32x2 rz[NP], px[NP], py[NP], q[NP], rad[NP], rr[NP], t[NP], s[NP], p[NP], r[NP], k[NP];
+    i32x2 inv[NP];
+    uint32_t qmin = 0xffffffffu, qmax = 0u;
+    VSTAB_EACH rz[c] = (f32x2){__builtin_amdgcn_rcpf(wz[c].x), __builtin_amdgcn_rcpf(wz[c].y)};
+    VSTAB_EACH px[c] = wx[c] * rz[c], py[c] = wy[c] * rz[c];
+    VSTAB_EACH q[c] = fma2(py[c], py[c], px[c] * px[c]);
+    VSTAB_EACH rad[c] = (f32x2){__builtin_amdgcn_sqrtf(q[c].x), __builtin_amdgcn_sqrtf(q[c].y)};
+    VSTAB_EACH {
+        qmin = min(min(qmin, __float_as_uint(q[c].x)), __float_as_uint(q[c].y));
+        qmax = max(max(qmax, __float_as_uint(q[c].x)), __float_as_uint(q[c].y));
+    }
+    VSTAB_EACH rr[c] = (f32x2){__builtin_amdgcn_rcpf(rad[c].x), __builtin_amdgcn_rcpf(rad[c].y)};
+    VSTAB_EACH inv[c] = rad[c] > splat2(1.0f), t[c] = inv[c] ? rr[c] : rad[c];
+    VSTAB_EACH s[c] = t[c] * t[c];
+    VSTAB_EACH p[c] = fma2(splat2(f32_bits(0x3b2d2a58u)), s[c], splat2(f32_bits(0xbc7a590cu)));
+    VSTAB_EACH p[c] = fma2(s[c], p[c], splat2(f32_bits(0x3d29fb3fu)));
+    VSTAB_EACH p[c] = fma2(s[c], p[c], splat2(f32_bits(0xbd97d4d7u)));
+    VSTAB_EACH p[c] = fma2(s[c], p[c], splat2(f32_bits(0x3dd931b2u)));
+    VSTAB_EACH p[c] = fma2(s[c], p[c], splat2(f32_bits(0xbe1160e6u)));
+    VSTAB_EACH p[c] = fma2(s[c], p[c], splat2(f32_bits(0x3e4cb8bfu)));
+    VSTAB_EACH p[c] = fma2(s[c], p[c], splat2(f32_bits(0xbeaaaa62u)));
+    VSTAB_EACH r[c] = fma2(t[c], s[c] * p[c], t[c]);
+    VSTAB_EACH r[c] = inv[c] ? splat2(f32_bits(0x3fc90fdbu)) - r[c] : r[c];
+    VSTAB_EACH k[c] = r[c] * rr[c];
+    VSTAB_EACH ax[c] = fma2(splat2(ifx32), px[c] * k[c], splat2(icx32)), ay[c] = fma2(splat2(ify32), py[c] * k[c], splat2(icy32));
+    return (qmin < 0x17800000u /* 2^-80 */ || qmax > 0x67800000u /* 2^80 */) ? 1u : 0u;
+}
+#undef VSTAB_EACH
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One output tile: 64 columns x 4 RW rows at (x0, y0).  All 256 threads of the workgroup take part.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifdef VSTAB_DEV
+// development builds: eight 100 MHz wall-clock stamps per wave (tools/wg_timeline.py)
+#define VSTAB_STAMP(k)                                                                                                   \
+    if (ta.timing && lane == 0) ta.timing[((size_t)blockIdx.x * 4 + (size_t)wave) * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define VSTAB_STAMP(k)
+#endif
+
+// Returns false -- right behind the probe, before anything else is done -- when SPLIT is set and the tile's box is over the
+// LDS budget: the caller then covers the tile with two tiles of half the height.
+template <int RWB, int RW, int MODE, int FMT, bool CACHED, bool SPLIT>
+__device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, const int x0, const int y0) {
+    constexpr int TH = 4 * RW;
+    constexpr int STAGE_MAX = StageTrips<RWB, RW>::value;
+    constexpr int QB = CACHED ? 0 : QMAGIC_BITS;  // offset of the quantised-coordinate representation kept in registers
+    constexpr bool RS = MODE >= MAP_RS_CREATEMAP_CL;              // per-row rotation (BASELINE config 5)
+    constexpr int BASE = RS ? MODE - MAP_RS_CREATEMAP_CL : MODE;  // the projection pair
+    uint32_t *const tile = smem + 8;  // smem[0..4]: the tile header (box, flag), written by wave 0
     const WarpArgs &a = ta.w;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float rfx = rcp_refined(a.p.ofx), rfy = rcp_refined(a.p.ofy);
-    constexpr int QB = CACHED ? 0 : QMAGIC_BITS;  // offset of the quantised-coordinate representation kept in registers
-    constexpr bool RS = MODE >= MAP_RS_CREATEMAP_CL;          // per-row rotation (BASELINE config 5)
-    constexpr int BASE = RS ? MODE - MAP_RS_CREATEMAP_CL : MODE;  // the projection pair
 
-    // ---- tile of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), so every XCD
-    // gets one contiguous band of tile rows in raster order: horizontally and vertically adjacent tiles then share an
-    // L2 and the 128-B lines their source and output rows straddle move once (cutting the image into 16 chunks and
-    // pairing a central with an outer chunk per XCD, to balance the larger source boxes of the centre, ran no faster and
-    // fetched 20 % more).  Placement only affects speed, never results.
-    int tile_x, tile_y;
-    {
-        const int k = (int)(blockIdx.x & 7u);
-        const int idx = (int)(blockIdx.x >> 3);
-        const int r0 = (k * ta.tiles_y) >> 3, r1 = ((k + 1) * ta.tiles_y) >> 3;
-        if (idx >= (r1 - r0) * ta.tiles_x) return;  // uniform for the workgroup (before any barrier)
-        tile_y = r0 + idx / ta.tiles_x;
-        tile_x = idx - (tile_y - r0) * ta.tiles_x;
-    }
+    VSTAB_STAMP(0);
     // ---- probe (wave 0 only; the other waves wait at the barrier without taking issue slots) --------------------
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);  // three waves wait for this one
-        probe_tile<R, MODE, CACHED>(ta, tile_x, tile_y, lane, rfx, rfy, smem);
+        probe_tile<TH, STAGE_MAX, MODE, CACHED>(ta, x0, y0, lane, rfx, rfy, smem);
         __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     const int bx0 = __builtin_amdgcn_readfirstlane((int)smem[0]), by0 = __builtin_amdgcn_readfirstlane((int)smem[1]);
     const int wb = __builtin_amdgcn_readfirstlane((int)smem[2]), hb = __builtin_amdgcn_readfirstlane((int)smem[3]);
-    const bool use_lds = __builtin_amdgcn_readfirstlane((int)smem[4]) != 0;
-    const int x0 = tile_x * 64, y0 = tile_y * TH;
+    const int box_state = __builtin_amdgcn_readfirstlane((int)smem[4]);
+    if constexpr (SPLIT) {
+        if (box_state == 2) return false;  // uniform
+    }
+    const bool use_lds = box_state == 1;
     const int x = x0 + lane;
-#ifdef VSTAB_DEV
-    unsigned long long t_rt0 = 0, t_ck0 = 0;
-    if (ta.timing) t_rt0 = __builtin_amdgcn_s_memrealtime(), t_ck0 = __builtin_amdgcn_s_memtime();
-#endif
+    VSTAB_STAMP(1);
 
     // ---- load: this thread's 8x2 blocks of the box, all loads in flight at once --------------------------------
     const int ux_n = wb >> 3, units = use_lds ? ux_n * (hb >> 1) : 0;
@@ -245,23 +355,36 @@ __global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
         for (int it = 0; it < STAGE_MAX; it++) y0w[it] = y1w[it] = uvw[it] = make_uint2(0, 0), ldsoff[it] = -1;
     }
 
-    // ---- map: R exact evaluations per thread (lane = column, rows y0 + wave * R + j) ---------------------------
-    int qxb[R], qyb[R];  // quantised coordinates + QB
+    VSTAB_STAMP(2);
+    // ---- map: RW exact evaluations per thread (lane = column, rows y0 + wave * RW + j) -------------------------
+    // Columns right of the image and rows below it are evaluated as the last column / row: their results are never
+    // stored, and so they stay inside the box like their neighbours.
+    int qxb[RW], qyb[RW];  // quantised coordinates + QB
     if constexpr (CACHED) {
 #pragma unroll
-        for (int j = 0; j < R; j++) {
-            const int y = min(y0 + wave * R + j, a.dh - 1);
-            const int2 q = ta.qmap[(size_t)y * ta.qpitch + min(x, ta.qpitch - 1)];
+        for (int j = 0; j < RW; j++) {
+            const int y = min(y0 + wave * RW + j, a.dh - 1);
+            const int2 q = ta.qmap[(size_t)y * ta.qpitch + min(x, a.dw - 1)];
             qxb[j] = q.x, qyb[j] = q.y;
         }
-    } else {
-        float vx = norm_coord<BASE>((float)x - a.p.ocx, a.p.ofx, rfx);
+    } else
+#ifdef VSTAB_DEV
+    if (ta.ablate & 1) {  // timing only: a linear map in place of the exact one
+#pragma unroll
+        for (int j = 0; j < RW; j++) {
+            const float fx = (float)x * (32.0f * (float)a.sw / (float)a.dw), fy = (float)(y0 + wave * RW + j) * (32.0f * (float)a.sh / (float)a.dh);
+            qxb[j] = __float_as_int(fx + QMAGIC), qyb[j] = __float_as_int(fy + QMAGIC);
+        }
+    } else
+#endif
+    {
+        float vx = norm_coord<BASE>((float)min(x, a.dw - 1) - a.p.ocx, a.p.ofx, rfx);
         // the compiler would sink each map evaluation to its use behind the barrier; these two statements pin the map
         // phase between the loads above (memory clobber) and the conversion below (the coordinates pass through)
         asm volatile("" : "+v"(vx) : : "memory");
         const ColTerm ct = {a.p.r[0] * vx, a.p.r[3] * vx, a.p.r[6] * vx};
-        // row terms: lane l < R evaluates row l of this wave once; every lane then reads them from that lane
-        const int y_l = y0 + wave * R + (lane & (R - 1));
+        // row terms: lane l < RW evaluates row l of this wave once; every lane then reads them from that lane
+        const int y_l = min(y0 + wave * RW + (lane & (RW - 1)), a.dh - 1);
         const float vy_l = norm_coord<BASE>((float)y_l - a.p.ocy, a.p.ofy, rfy);
         float m_l[9];  // the rotation of row y_l: the frame's, or interpolated towards the last row's (rolling shutter)
 #pragma unroll
@@ -274,49 +397,71 @@ __global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
         const float b0_l = m_l[1] * vy_l, b1_l = m_l[4] * vy_l, b2_l = m_l[7] * vy_l;
         const float icx32 = ta.p32.icx32, icy32 = ta.p32.icy32, ifx32 = ta.p32.ifx32, ify32 = ta.p32.ify32;
         auto bcast = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-#ifdef VSTAB_DEV
-        if (ta.ablate & 1) {
-#pragma unroll
-            for (int j = 0; j < R; j++) {
-                const float fx = (float)x * (32.0f * (float)a.sw / (float)a.dw), fy = (float)(y0 + wave * R + j) * (32.0f * (float)a.sh / (float)a.dh);
-                qxb[j] = __float_as_int(fx + QMAGIC), qyb[j] = __float_as_int(fy + QMAGIC);
-            }
-        } else
-#endif
+        auto bcast2 = [&bcast](float v, int j) { return (f32x2){bcast(v, j), bcast(v, j + 1)}; };
         if constexpr (BASE == MAP_CREATEMAP_CL || BASE == MAP_FISH_TO_RECT) {
-            // two rows at a time through the packed-fp32 pipe
+            constexpr int NP = RW / 2;
+            f32x2 wx[NP], wy[NP], wz[NP], ax[NP], ay[NP];
 #pragma unroll
-            for (int j = 0; j < R; j += 2) {
-                const f32x2 b0 = {bcast(b0_l, j), bcast(b0_l, j + 1)}, b1 = {bcast(b1_l, j), bcast(b1_l, j + 1)}, b2 = {bcast(b2_l, j), bcast(b2_l, j + 1)};
-                f32x2 a0 = splat2(ct.a0), a1 = splat2(ct.a1), a2 = splat2(ct.a2), r02 = splat2(a.p.r[2]), r12 = splat2(a.p.r[5]), r22 = splat2(a.p.r[8]);
+            for (int c = 0; c < NP; c++) {
                 if constexpr (RS) {  // every row has its own matrix: column products and third column per row
-                    a0 = (f32x2){bcast(m_l[0], j), bcast(m_l[0], j + 1)} * splat2(vx);
-                    a1 = (f32x2){bcast(m_l[3], j), bcast(m_l[3], j + 1)} * splat2(vx);
-                    a2 = (f32x2){bcast(m_l[6], j), bcast(m_l[6], j + 1)} * splat2(vx);
-                    r02 = (f32x2){bcast(m_l[2], j), bcast(m_l[2], j + 1)};
-                    r12 = (f32x2){bcast(m_l[5], j), bcast(m_l[5], j + 1)};
-                    r22 = (f32x2){bcast(m_l[8], j), bcast(m_l[8], j + 1)};
+                    wx[c] = (bcast2(m_l[0], 2 * c) * splat2(vx) + bcast2(b0_l, 2 * c)) + bcast2(m_l[2], 2 * c);
+                    wy[c] = (bcast2(m_l[3], 2 * c) * splat2(vx) + bcast2(b1_l, 2 * c)) + bcast2(m_l[5], 2 * c);
+                    wz[c] = (bcast2(m_l[6], 2 * c) * splat2(vx) + bcast2(b2_l, 2 * c)) + bcast2(m_l[8], 2 * c);
+                } else {
+                    wx[c] = (splat2(ct.a0) + bcast2(b0_l, 2 * c)) + splat2(a.p.r[2]);
+                    wy[c] = (splat2(ct.a1) + bcast2(b1_l, 2 * c)) + splat2(a.p.r[5]);
+                    wz[c] = (splat2(ct.a2) + bcast2(b2_l, 2 * c)) + splat2(a.p.r[8]);
                 }
-                f32x2 ax, ay;
-                map_pixel32_x2<BASE == MAP_FISH_TO_RECT>(icx32, icy32, ifx32, ify32, r02, r12, r22, a0, a1, a2, b0, b1, b2, ax, ay);
-                ax += splat2(QMAGIC), ay += splat2(QMAGIC);
-                qxb[j] = __float_as_int(ax.x), qxb[j + 1] = __float_as_int(ax.y);
-                qyb[j] = __float_as_int(ay.x), qyb[j + 1] = __float_as_int(ay.y);
+            }
+            map_pairs_ieee<NP, BASE == MAP_FISH_TO_RECT>(icx32, icy32, ifx32, ify32, wx, wy, wz, ax, ay);
+#pragma unroll
+            for (int c = 0; c < NP; c++) {
+                ax[c] += splat2(QMAGIC), ay[c] += splat2(QMAGIC);
+                qxb[2 * c] = __float_as_int(ax[c].x), qxb[2 * c + 1] = __float_as_int(ax[c].y);
+                qyb[2 * c] = __float_as_int(ay[c].x), qyb[2 * c + 1] = __float_as_int(ay[c].y);
+            }
+        } else if constexpr (BASE == MAP_CREATEMAP_CL_OPENCL) {
+            constexpr int NP = RW / 2;
+            f32x2 wx[NP], wy[NP], wz[NP], ax[NP], ay[NP];
+#pragma unroll
+            for (int c = 0; c < NP; c++) {
+                const f32x2 vy2 = bcast2(vy_l, 2 * c);
+                wz[c] = fma2(splat2(a.p.r[7]), vy2, splat2(ct.a2)) + splat2(a.p.r[8]);
+                wx[c] = fma2(splat2(a.p.r[1]), vy2, splat2(ct.a0)) + splat2(a.p.r[2]);
+                wy[c] = fma2(splat2(a.p.r[4]), vy2, splat2(ct.a1)) + splat2(a.p.r[5]);
+            }
+            const uint32_t irregular = map_pairs_ocl<NP>(icx32, icy32, ifx32, ify32, wx, wy, wz, ax, ay);
+#pragma unroll
+            for (int c = 0; c < NP; c++) {
+                ax[c] += splat2(QMAGIC), ay[c] += splat2(QMAGIC);
+                qxb[2 * c] = __float_as_int(ax[c].x), qxb[2 * c + 1] = __float_as_int(ax[c].y);
+                qyb[2 * c] = __float_as_int(ay[c].x), qyb[2 * c + 1] = __float_as_int(ay[c].y);
+            }
+            if (__builtin_amdgcn_ballot_w64(irregular != 0)) {  // practically never: the code object's literal stream
+#pragma unroll 1
+                for (int j = 0; j < RW; j++) {
+                    float fx, fy;
+                    map_pixel_ocl_literal(icx32, icy32, ifx32, ify32, a.p, ct.a0, ct.a1, ct.a2, bcast(vy_l, j), fx, fy);
+                    const int ix = __float_as_int(fx + QMAGIC), iy = __float_as_int(fy + QMAGIC);
+#pragma unroll
+                    for (int k = 0; k < RW; k++) qxb[k] = j == k ? ix : qxb[k], qyb[k] = j == k ? iy : qyb[k];
+                }
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < R; j++) {
+            for (int j = 0; j < RW; j++) {
                 const float vy = bcast(vy_l, j);
                 const RowTerm rt = {bcast(b0_l, j), bcast(b1_l, j), bcast(b2_l, j)};
-                float ax, ay;
-                map_pixel_ex<BASE>(ta.p32, a.p, ct, rt, vx, vy, ax, ay);
-                qxb[j] = __float_as_int(ax + QMAGIC), qyb[j] = __float_as_int(ay + QMAGIC);
+                float fx, fy;
+                map_pixel_ex<BASE>(ta.p32, a.p, ct, rt, vx, vy, fx, fy);
+                qxb[j] = __float_as_int(fx + QMAGIC), qyb[j] = __float_as_int(fy + QMAGIC);
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < R; j++) asm volatile("" : "+v"(qxb[j]), "+v"(qyb[j]) : : "memory");
+    for (int j = 0; j < RW; j++) asm volatile("" : "+v"(qxb[j]), "+v"(qyb[j]) : : "memory");
 
+    VSTAB_STAMP(3);
     // ---- convert: cvtColor once per source pixel, BGRx dwords to LDS --------------------------------------------
     if (use_lds) {
 #pragma unroll
@@ -352,55 +497,80 @@ __global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
             }
         }
     }
+    VSTAB_STAMP(4);
     __syncthreads();
+    VSTAB_STAMP(5);
 
     // ---- sample + blend -----------------------------------------------------------------------------------------
     const bool col_live = x < a.dw;
-    uint32_t out[R];
-    uint32_t slow = 0;  // bit j: live pixel whose footprint is not inside the staged box
+    uint32_t out[RW];
     {
         const int cx = bx0 + (QB >> 5), cy = by0 + (QB >> 5);
         const uint32_t wlim = use_lds ? (uint32_t)(wb - 1) : 0u, hlim = (uint32_t)(hb - 1);  // both taps of each axis inside the staged box
+        int Xr[RW], Yr[RW];
+        uint32_t mxx = 0, mxy = 0;  // as unsigned: a coordinate left of / above the box is huge
 #pragma unroll
-        for (int j = 0; j < R; j++) {
-            const int Xr = (qxb[j] >> 5) - cx, Yr = (qyb[j] >> 5) - cy;
-            const bool inbox = (uint32_t)Xr < wlim && (uint32_t)Yr < hlim;
-            uint32_t v = 0;
-            if (inbox) {
-                const uint32_t *t = tile + (__mul24(Yr, wb) + Xr);
+        for (int j = 0; j < RW; j++) {
+            Xr[j] = (qxb[j] >> 5) - cx, Yr[j] = (qyb[j] >> 5) - cy;
+            mxx = max(mxx, (uint32_t)Xr[j]), mxy = max(mxy, (uint32_t)Yr[j]);
+        }
+        if (!__builtin_amdgcn_ballot_w64(mxx >= wlim || mxy >= hlim)) {
+            // every footprint of the wave lies in the staged box: all tap reads first, then the blends
+            uint32_t t0[RW], t1[RW], t2[RW], t3[RW];
+#pragma unroll
+            for (int j = 0; j < RW; j++) {
+                const uint32_t *t = tile + (__mul24(Yr[j], wb) + Xr[j]);
+                t0[j] = t[0], t1[j] = t[1], t2[j] = t[wb], t3[j] = t[wb + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < RW; j++) {
 #ifdef VSTAB_DEV
-                if (ta.ablate & 2) v = t[0] ^ t[1] ^ t[wb] ^ t[wb + 1] ^ (qxb[j] & 31) ^ (qyb[j] & 31);
+                if (ta.ablate & 2) out[j] = t0[j] ^ t1[j] ^ t2[j] ^ t3[j] ^ (qxb[j] & 31) ^ (qyb[j] & 31);
                 else
 #endif
-                v = blend_bgrx(t[0], t[1], t[wb], t[wb + 1], qxb[j] & 31, qyb[j] & 31);
+                out[j] = blend_bgrx(t0[j], t1[j], t2[j], t3[j], qxb[j] & 31, qyb[j] & 31);
             }
-            out[j] = v;
-            const bool live = col_live && y0 + wave * R + j < a.dh;
-            slow |= (!inbox && live ? 1u : 0u) << j;
-        }
-    }
-    if (__builtin_amdgcn_ballot_w64(slow != 0)) {  // rare: source border, degenerate rotation, box over the LDS budget
+        } else {
+            // rare (source border with a box that had to be cut, degenerate rotation, box over the LDS budget): pixel by
+            // pixel, from the box where the footprint is inside it and from global memory where it is not
+            uint32_t slow = 0;  // bit j: live pixel whose footprint is not inside the staged box
+#pragma unroll
+            for (int j = 0; j < RW; j++) {
+                const bool inbox = (uint32_t)Xr[j] < wlim && (uint32_t)Yr[j] < hlim;
+                uint32_t v = 0;
+                if (inbox) {
+                    const uint32_t *t = tile + (__mul24(Yr[j], wb) + Xr[j]);
+                    v = blend_bgrx(t[0], t[1], t[wb], t[wb + 1], qxb[j] & 31, qyb[j] & 31);
+                }
+                out[j] = v;
+                const bool live = col_live && y0 + wave * RW + j < a.dh;
+                slow |= (!inbox && live ? 1u : 0u) << j;
+            }
+            if (__builtin_amdgcn_ballot_w64(slow != 0)) {
 #pragma unroll 1
-        for (int j = 0; j < R; j++) {
-            int sx = qxb[0], sy = qyb[0];
+                for (int j = 0; j < RW; j++) {
+                    int sx = qxb[0], sy = qyb[0];
 #pragma unroll
-            for (int k = 1; k < R; k++) sx = j == k ? qxb[k] : sx, sy = j == k ? qyb[k] : sy;
-            if ((slow >> j) & 1u) {
-                const uint32_t v = gather_pixel_far(a, sx - QB, sy - QB);
+                    for (int k = 1; k < RW; k++) sx = j == k ? qxb[k] : sx, sy = j == k ? qyb[k] : sy;
+                    if ((slow >> j) & 1u) {
+                        const uint32_t v = gather_pixel_far(a, sx - QB, sy - QB);
 #pragma unroll
-                for (int k = 0; k < R; k++) out[k] = j == k ? v : out[k];
+                        for (int k = 0; k < RW; k++) out[k] = j == k ? v : out[k];
+                    }
+                }
             }
         }
     }
 
+    VSTAB_STAMP(6);
     // ---- store: a row of 64 BGRx dwords -> 48 dwords of BGR, one per lane (ds_bpermute transposition) ----------
 #ifdef VSTAB_DEV
     if (ta.ablate & 8) {
         uint32_t acc = 0;
 #pragma unroll
-        for (int j = 0; j < R; j++) acc ^= out[j];
+        for (int j = 0; j < RW; j++) acc ^= out[j];
         if (acc == 0x12345678u) a.dst[0] = 1;
-        return;
+        return true;
     }
 #endif
     const int ncols = min(64, a.dw - x0);  // > 0
@@ -408,9 +578,27 @@ __global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
         const int p0 = (4 * lane) / 3, m3 = lane - 3 * (lane / 3);  // pixels p0, p0 + 1 feed dword `lane` (lane < 48)
         const uint32_t sel = m3 == 0 ? 0x04020100u : m3 == 1 ? 0x05040201u : 0x06050402u;
         const int nbytes = 3 * ncols, nfull = nbytes >> 2, rem = nbytes & 3;
+        if (ta.dst_vec_ok && ncols == 64 && y0 + wave * RW + RW <= a.dh) {
+            // the whole strip of this wave is inside the image (all but the last tile column / row): every cross-lane
+            // read of the transposition first, then RW stores with nothing but a scalar address step between them
+            uint32_t lo[RW], hi[RW];
 #pragma unroll
-        for (int j = 0; j < R; j++) {
-            const int y = y0 + wave * R + j;
+            for (int j = 0; j < RW; j++) {
+                lo[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * p0, (int)out[j]);
+                hi[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * p0 + 4, (int)out[j]);
+            }
+            uint8_t *o = a.dst + ((size_t)(uint32_t)(y0 + wave * RW) * a.pitch_dst + (uint32_t)x0 * 3u);  // uniform
+            if (lane < 48) {
+#pragma unroll
+                for (int j = 0; j < RW; j++) {
+                    *reinterpret_cast<uint32_t *>(o + (uint32_t)(4 * lane)) = __builtin_amdgcn_perm(hi[j], lo[j], sel);
+                    o += a.pitch_dst;
+                }
+            }
+        } else
+#pragma unroll
+        for (int j = 0; j < RW; j++) {
+            const int y = y0 + wave * RW + j;
             if (y >= a.dh) break;  // uniform
             uint8_t *o = a.dst + ((size_t)(uint32_t)y * a.pitch_dst + (uint32_t)x0 * 3u);  // uniform
             if (ta.dst_vec_ok) {
@@ -429,8 +617,8 @@ __global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
         // NV12 output: luma for every pixel, chroma from the even-row / even-column pixels; four lanes' bytes are
         // collected in the first lane of each quad (DPP quad_perm) and stored as one dword
 #pragma unroll
-        for (int j = 0; j < R; j++) {
-            const int y = y0 + wave * R + j;
+        for (int j = 0; j < RW; j++) {
+            const int y = y0 + wave * RW + j;
             if (y >= a.dh) break;  // uniform
             const uint32_t yb = bgr_to_y(out[j]);
             const uint32_t y1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0x55, 0xf, 0xf, true);
@@ -460,12 +648,36 @@ __global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
             }
         }
     }
-#ifdef VSTAB_DEV
-    if (ta.timing && tid == 0) {
-        unsigned long long *t = ta.timing + 4 * (size_t)(tile_y * ta.tiles_x + tile_x);
-        t[0] = t_rt0, t[1] = t_ck0, t[2] = __builtin_amdgcn_s_memrealtime(), t[3] = __builtin_amdgcn_s_memtime();
+    VSTAB_STAMP(7);
+    return true;
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), so every XCD gets one contiguous band of
+// output rows [band_y[k], band_y[k + 1]) in raster order: horizontally and vertically adjacent tiles then share an L2 and
+// the 128-B lines their source and output rows straddle move once.  Inside its band an XCD first works through tiles of
+// 4 RWB rows, then -- from row split_y[k] on -- through tiles of half that height (the last, partly filled round of
+// workgroups then lasts half as long).  Placement and tile height only affect speed, never results.
+template <int RWB, int MODE, int FMT, bool CACHED>
+__global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr int TH = 4 * RWB, TS = TH / 2;
+    const int k = (int)(blockIdx.x & 7u), idx = (int)(blockIdx.x >> 3);
+    const int y_lo = ta.band_y[k], y_sp = ta.split_y[k], y_hi = ta.band_y[k + 1];
+    const int n_tall = ((y_sp - y_lo) / TH) * ta.tiles_x;  // y_sp - y_lo is a multiple of TH
+    int x0, ys, n_half;
+    if (idx < n_tall) {
+        const int row = idx / ta.tiles_x;
+        x0 = (idx - row * ta.tiles_x) * 64, ys = y_lo + row * TH;
+        // a tall tile whose box is over the LDS budget (the image centre, where the lens compresses most) is done as two
+        // half-height tiles, one after the other
+        n_half = warp_tile<RWB, RWB, MODE, FMT, CACHED, true>(ta, smem, x0, ys) ? 0 : 2;
+    } else {
+        const int i2 = idx - n_tall, row = i2 / ta.tiles_x;
+        x0 = (i2 - row * ta.tiles_x) * 64, ys = y_sp + row * TS, n_half = 1;
+        if (ys >= y_hi) return;  // uniform for the workgroup (before any barrier)
     }
-#endif
+#pragma unroll 1
+    for (int i = 0; i < n_half; i++) warp_tile<RWB, RWB / 2, MODE, FMT, CACHED, false>(ta, smem, x0, ys + i * TS);
 }
 
 }  // namespace vstab
@@ -486,7 +698,7 @@ vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int ma
     ta.p32 = {params[0] * 32.0f, params[1] * 32.0f, params[2] * 32.0f, params[3] * 32.0f, params[10], params[13], params[16]};
     ta.src_vec_ok = src_vec_ok, ta.dst_vec_ok = dst_vec_ok;
     ta.qmap = static_cast<const int2 *>(qmap), ta.qpitch = qpitch;
-    for (int k = 0; k < 9; k++) ta.rs_d[k] = rot_bottom ? rot_bottom[k] - params[8 + k] : 0.0f;  // fp32, as the oracle forms it
+    for (int k = 0; k < 9; k++) ta.rs_d[k] = rot_bottom ? rot_bottom[k] - params[8 + k] : 0.0f;  // fp32, as the definition forms it
     ta.rs_den = (float)(a.dh > 1 ? a.dh - 1 : 1);
     if (rot_bottom) map_mode += MAP_RS_CREATEMAP_CL;  // modes 0 / 1 only (checked by the caller)
 #ifdef VSTAB_DEV
@@ -495,25 +707,42 @@ vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int ma
     ta.ablate = ablate;
 #endif
     // Tile shape: 64 x 32 output pixels and 40 KB of LDS (4 workgroups per CU) when that gives the 1024 workgroup
-    // slots of the chip a few rounds of tiles; 64 x 16 with 24 KB for small outputs (1080p).
+    // slots of the chip a few rounds of tiles; 64 x 16 with 24 KB (6 per CU) for small outputs (1080p).
     const long tiles32 = (long)div_up(a.dw, 64) * div_up(a.dh, 32);
-    int rows = tiles32 < 1536 ? 4 : 8, lds_kb = rows == 4 ? 24 : 40;
+    int rwb = tiles32 < 1536 ? 4 : 8, lds_kb = rwb == 4 ? 24 : 40;
+    double tail_rounds = 0.5;  // how many rounds of workgroup slots, counted from the end, use the half-height tiles
 #ifdef VSTAB_DEV
-    if (const char *e = getenv("VSTAB_ROWS")) rows = atoi(e) == 4 ? 4 : 8;
+    if (const char *e = getenv("VSTAB_ROWS")) rwb = atoi(e) == 4 ? 4 : 8;
     if (const char *e = getenv("VSTAB_LDS_KB")) lds_kb = atoi(e);
+    if (const char *e = getenv("VSTAB_TAIL_ROUNDS")) tail_rounds = atof(e);
 #endif
     const size_t lds_bytes = (size_t)lds_kb * 1024;
     ta.lds_capacity_px = (int)(lds_bytes / 4) - 8;  // 8 dwords hold the tile header
-    ta.tiles_x = (int)div_up(a.dw, 64), ta.tiles_y = (int)div_up(a.dh, 4 * rows);
-    // every XCD owns one band of tile rows (see the kernel); the grid holds the largest of the eight shares per XCD
+    ta.tiles_x = (int)div_up(a.dw, 64);
+    // Bands: the image's half-height tile rows dealt evenly to the 8 XCDs.  Inside a band the tall tiles come first; the
+    // last `tail_rounds` rounds of the XCD's workgroup slots (32 CUs x workgroups per CU) are made of half-height tiles.
+    const int th = 4 * rwb, ts = th / 2;
+    const int half_rows = (int)div_up(a.dh, ts);
+    const int slots = 32 * std::max(1, std::min(8, (int)(160 / lds_kb)));
     int share = 0;
-    for (int k = 0; k < 8; k++) share = std::max(share, ((((k + 1) * ta.tiles_y) >> 3) - ((k * ta.tiles_y) >> 3)) * ta.tiles_x);
+    for (int k = 0; k <= 8; k++) ta.band_y[k] = std::min(a.dh, (int)((long)k * half_rows / 8) * ts);
+    ta.band_y[8] = a.dh;
+    for (int k = 0; k < 8; k++) {
+        const int rows = ta.band_y[k + 1] - ta.band_y[k];
+        const int tall_rows_max = rows / th;  // whole tall tile rows that fit
+        // half-height tiles for about tail_rounds * slots tall-tile equivalents at the end of the band
+        const int tail_tall_rows = (int)std::min<long>(tall_rows_max, std::lround(tail_rounds * slots / ta.tiles_x));
+        const int tall_rows = tall_rows_max - tail_tall_rows;
+        ta.split_y[k] = ta.band_y[k] + tall_rows * th;
+        const int n = tall_rows * ta.tiles_x + (int)div_up(ta.band_y[k + 1] - ta.split_y[k], ts) * ta.tiles_x;
+        share = std::max(share, n);
+    }
     const dim3 grid(8u * (unsigned)share);
 #define VSTAB_LAUNCH(R, M, F, C) hipLaunchKernelGGL((k_warp_fused<R, M, F, C>), grid, dim3(256), lds_bytes, st, ta)
 #define VSTAB_LAUNCH_RF(M, C)                                  \
     do {                                                       \
-        if (rows == 8 && !nv12_out) VSTAB_LAUNCH(8, M, 0, C);  \
-        else if (rows == 8) VSTAB_LAUNCH(8, M, 1, C);          \
+        if (rwb == 8 && !nv12_out) VSTAB_LAUNCH(8, M, 0, C);   \
+        else if (rwb == 8) VSTAB_LAUNCH(8, M, 1, C);           \
         else if (!nv12_out) VSTAB_LAUNCH(4, M, 0, C);          \
         else VSTAB_LAUNCH(4, M, 1, C);                         \
     } while (0)
