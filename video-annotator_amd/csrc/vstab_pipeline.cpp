@@ -95,6 +95,7 @@ class Tracker {
         for (int b = 0; b < REC_BUFS; b++) {
             VSTAB_TRY(hrec_[b].ensure(256 * 16));
             VSTAB_TRY(drec_[b].ensure(256 * 16));
+            VSTAB_HIP_TRY(hipMemset(drec_[b].p, 0, 256 * 16));  // tag 0 is never a launch's sequence number: a chained slot never mistakes stale bytes for its predecessor
             VSTAB_TRY(hpts_[b].ensure(256 * sizeof(float2)));
         }
         return VSTAB_OK;
@@ -356,7 +357,7 @@ class Tracker {
         std::memcpy(hpts_[L.buf].p, prev_xy.data(), sizeof(float) * prev_xy.size());
         if (timed && !ev_a_) (void)hipEventCreate(&ev_a_), (void)hipEventCreate(&ev_b_);
         if (timed) (void)hipEventRecord(ev_a_, st);
-        VSTAB_TRY(launch_lk(I, J, static_cast<const float2 *>(hpts_[L.buf].dev()), n, nullptr, nullptr, hrec_[L.buf].dev(), L.seq, st, nullptr,
+        VSTAB_TRY(launch_lk(I, J, static_cast<const float2 *>(hpts_[L.buf].dev()), n, nullptr, nullptr, hrec_[L.buf].dev(), L.seq, st, nullptr, 0,
                             drec_[L.buf].p, clock_slot()));
         if (timed) (void)hipEventRecord(ev_b_, st);
         return VSTAB_OK;
@@ -371,7 +372,7 @@ class Tracker {
         VSTAB_TRY(hrec_[L.buf].ensure((size_t)L.n_slots * 16));
         VSTAB_TRY(drec_[L.buf].ensure((size_t)L.n_slots * 16));
         if (!hrec_[L.buf].dev()) return fail(VSTAB_ERR_DEVICE, "hipHostGetDevicePointer failed");
-        return launch_lk(I, J, nullptr, L.n_slots, nullptr, nullptr, hrec_[L.buf].dev(), L.seq, st, drec_[parent.buf].p, drec_[L.buf].p,
+        return launch_lk(I, J, nullptr, L.n_slots, nullptr, nullptr, hrec_[L.buf].dev(), L.seq, st, drec_[parent.buf].p, parent.seq, drec_[L.buf].p,
                          clock_slot());
     }
 
@@ -399,6 +400,7 @@ class Tracker {
                 }
             }
             const uint32_t x = rec[4 * i], y = rec[4 * i + 2], s = rec[4 * i + 3] & 3u;
+            if (s == 3u) return fail(VSTAB_ERR_DEVICE, "LK chain: a slot's predecessor record never arrived");
             if (s == 2u) continue;  // lost in an earlier frame of the chain: not part of this frame's point list
             float fx, fy;
             std::memcpy(&fx, &x, 4), std::memcpy(&fy, &y, 4);
@@ -569,7 +571,7 @@ using namespace vstab;
 struct vstab_handle {
     // every way out of vstab_create after the streams and events exist, and vstab_destroy, ends here
     ~vstab_handle() {
-        for (hipStream_t s : {tstream, pstream, dstream})
+        for (hipStream_t s : {tstream, tstream2, pstream, dstream})
             if (s) (void)hipStreamSynchronize(s);
         for (auto &pe : pending) (void)hipEventDestroy(pe.a), (void)hipEventDestroy(pe.b);
         for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
@@ -577,13 +579,17 @@ struct vstab_handle {
             if (s.ingested) (void)hipEventDestroy(s.ingested);
         for (hipEvent_t e : warp_events)
             if (e) (void)hipEventDestroy(e);
-        for (hipStream_t s : {dstream, pstream, tstream})
+        for (hipStream_t s : {dstream, pstream, tstream2, tstream})
             if (s) (void)hipStreamDestroy(s);
     }
     vstab_config cfg;
     vstab_source src;
     hipStream_t stream = nullptr;   // caller-visible stream: the warp runs here, dst is complete when it drains
     hipStream_t tstream = nullptr;  // internal stream: corner detection + LK (the per-frame critical path)
+    hipStream_t tstream2 = nullptr; // a second one for LK: a launch chained behind the previous frame's goes to the stream its
+                                    // parent is NOT on, so the two run side by side and every slot follows its own predecessor
+    bool lk_on_second = false;      // which of the two the launch in flight sits on
+    hipStream_t lk_stream(bool second) const { return second && tstream2 ? tstream2 : tstream; }
     hipStream_t pstream = nullptr;  // internal stream: ingest + pyramid of the NEXT frame (prefetch, overlaps LK)
     int w = 0, h = 0, ow = 0, oh = 0;
     Mat3 Kin, Kout;
@@ -728,6 +734,7 @@ struct vstab_handle {
         if (dstream) (void)hipStreamSynchronize(dstream);
         (void)hipStreamSynchronize(pstream);
         (void)hipStreamSynchronize(tstream);
+        if (tstream2) (void)hipStreamSynchronize(tstream2);
         (void)hipStreamSynchronize(stream);
         double *sums[ST_COUNT] = {&prof.gpu_ingest_ms, &prof.gpu_pyramid_ms, &prof.gpu_corners_ms, &prof.gpu_lk_ms, &prof.gpu_warp_ms};
         for (auto &p : pending) {
@@ -764,6 +771,9 @@ struct vstab_handle {
     unsigned marker_set = 0;
     hipStream_t dstream = nullptr;  // speculative corner detection (137 us of kernels every 21st frame) beside everything else
     bool chain_lk = true;        // VSTAB_CHAIN_LK=0 disables chained launches
+    bool two_lk_streams = false; // VSTAB_LK_STREAMS=2 (development): chained launches alternate between two streams and every slot waits for
+                                 // its own predecessor in the kernel -- measured slower than the stream-ordered chain
+    bool spec_on_second = false; // the stream of spec_launch
     long chained_adopted = 0, chained_discarded = 0, key_prelaunched = 0;
     // a frame that has been pulled from upstream, copied into the ring and whose pyramid is being built
     std::deque<std::pair<int, int>> prefetched;  // (ring slot, pyramid set), oldest first
@@ -983,8 +993,9 @@ static vstab_status prefetch_next(vstab_handle *H) {
     {
         if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "spec launch for frame %ld (last_key %ld)\n", H->prefetch_count, H->last_key);
         HT t(HostTimers::SPEC_DETECT);
-        VSTAB_HIP_TRY(hipStreamWaitEvent(H->dstream, H->slots[slot].ingested, 0));
-        VSTAB_TRY(H->tracker.spec_launch(H->gray(slot), H->gpitch(slot), 0.01, H->dstream, H->prefetch_count));
+        hipStream_t ds = H->dstream ? H->dstream : H->pstream;  // with two tracker streams the detection shares the prefetch stream
+        if (ds != H->pstream) VSTAB_HIP_TRY(hipStreamWaitEvent(ds, H->slots[slot].ingested, 0));
+        VSTAB_TRY(H->tracker.spec_launch(H->gray(slot), H->gpitch(slot), 0.01, ds, H->prefetch_count));
         H->tracker.spec_select_async(200, 30.0);
     }
     H->prefetched.emplace_back(slot, pyr);
@@ -1051,13 +1062,17 @@ static vstab_status launch_tracking(vstab_handle *H) {
             // the launch chained behind the previous frame's tracker is this frame's tracker: same points (the
             // survivors, read on the device), same images
             H->inflight_launch = H->spec_launch;
+            H->lk_on_second = H->spec_on_second;
             H->chained_adopted++;
         } else {
             if (H->spec_frame == H->frame_index) H->chained_discarded++;  // key frame after all: its results are ignored
             HT t(HostTimers::LK_LAUNCH);
-            VSTAB_TRY(vstab_handle::wait_if_pending(H->tstream, H->slots[slot].ingested));  // pyramid (and ring copy) of this frame
+            // a discarded chained launch may still be running: this one takes the other stream (its parent's, which has drained)
+            H->lk_on_second = H->spec_frame == H->frame_index ? !H->spec_on_second : false;
+            hipStream_t ls = H->lk_stream(H->lk_on_second);
+            VSTAB_TRY(vstab_handle::wait_if_pending(ls, H->slots[slot].ingested));  // pyramid (and ring copy) of this frame
             VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(H->cur_pyr, pg, ppitch), H->tracker.pyramid(pyr, g, pitch), H->corners,
-                                              H->tstream, H->profiling >= 2, H->inflight_launch));
+                                              ls, H->profiling >= 2, H->inflight_launch));
         }
         H->spec_frame = -1, H->spec_is_key = false;
         H->have_inflight = true;
@@ -1068,9 +1083,13 @@ static vstab_status launch_tracking(vstab_handle *H) {
             (H->frame_index + 1) - H->last_key <= 20) {
             HT t(HostTimers::LK_CHAIN);
             const int nslot = H->prefetched.front().first, npyr = H->prefetched.front().second;
-            VSTAB_TRY(vstab_handle::wait_if_pending(H->tstream, H->slots[nslot].ingested));
+            // on the stream the parent is NOT on: the two launches overlap, each slot waits for its own predecessor
+            // in the kernel (k_lk_track).  The launch before the parent (same stream) has been read by the host already.
+            H->spec_on_second = H->two_lk_streams ? !H->lk_on_second : H->lk_on_second;
+            hipStream_t cs = H->lk_stream(H->spec_on_second);
+            VSTAB_TRY(vstab_handle::wait_if_pending(cs, H->slots[nslot].ingested));
             VSTAB_TRY(H->tracker.track_launch_chained(H->tracker.pyramid(pyr, g, pitch), H->tracker.pyramid(npyr, H->gray(nslot), H->gpitch(nslot)),
-                                                      H->inflight_launch, H->tstream, H->spec_launch));
+                                                      H->inflight_launch, cs, H->spec_launch));
             H->spec_frame = H->frame_index + 1;
         } else if (H->chain_lk && H->profiling < 2 && !H->prefetched.empty() && (H->frame_index + 1) - H->last_key > 20 &&
                    H->tracker.spec_tag() == H->frame_index && H->tracker.spec_state() != 2) {
@@ -1082,9 +1101,11 @@ static vstab_status launch_tracking(vstab_handle *H) {
             HT t(HostTimers::LK_CHAIN);
             H->tracker.spec_take(H->pre_corners);
             const int nslot = H->prefetched.front().first, npyr = H->prefetched.front().second;
-            VSTAB_TRY(vstab_handle::wait_if_pending(H->tstream, H->slots[nslot].ingested));
+            H->spec_on_second = H->two_lk_streams ? !H->lk_on_second : H->lk_on_second;  // independent of the launch in flight: beside it
+            hipStream_t cs = H->lk_stream(H->spec_on_second);
+            VSTAB_TRY(vstab_handle::wait_if_pending(cs, H->slots[nslot].ingested));
             VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(pyr, g, pitch), H->tracker.pyramid(npyr, H->gray(nslot), H->gpitch(nslot)), H->pre_corners,
-                                              H->tstream, false, H->spec_launch));
+                                              cs, false, H->spec_launch));
             H->spec_frame = H->frame_index + 1, H->spec_is_key = true;
         }
     }
@@ -1107,7 +1128,8 @@ static vstab_status finish_wait(vstab_handle *H) {
     std::vector<uint8_t> st;
     {
         HostStage hs(&H->prof.host_track_wait_ms);
-        VSTAB_TRY(H->tracker.track_wait(H->inflight_launch, T.prev.size() / 2, nxt, st, H->tstream, H->profiling >= 2 ? &H->prof.gpu_lk_ms : nullptr));
+        VSTAB_TRY(H->tracker.track_wait(H->inflight_launch, T.prev.size() / 2, nxt, st, H->lk_stream(H->lk_on_second),
+                                        H->profiling >= 2 ? &H->prof.gpu_lk_ms : nullptr));
     }
     // :261-268 keep pairs with status != 0
     for (size_t i = 0; i < st.size(); i++)
@@ -1200,6 +1222,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (const char *e = getenv("VSTAB_SPECULATE")) H->speculate = atoi(e) != 0;
     if (const char *e = getenv("VSTAB_THREADED_ESTIMATE")) H->threaded_estimate = atoi(e) != 0;
     if (const char *e = getenv("VSTAB_CHAIN_LK")) H->chain_lk = atoi(e) != 0;
+    if (const char *e = getenv("VSTAB_LK_STREAMS")) H->two_lk_streams = atoi(e) == 2;
     if (const char *e = getenv("VSTAB_MAP_CACHE")) H->map_cache = atoi(e) != 0;
     H->stream = static_cast<hipStream_t>(cfg->stream);  // NULL = the default stream, as for the stateless operators
     {
@@ -1208,11 +1231,15 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->tstream, hipStreamNonBlocking, hi));
+        if (H->two_lk_streams) VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->tstream2, hipStreamNonBlocking, hi));
         // copy + pyramid of the NEXT frame have a whole frame period of slack: lowest priority, so they fill
         // in behind the warp instead of taking its CUs
         VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, lo));
         // (this runtime offers two priority levels; beside a saturating warp the detection takes ~500 us at either)
-        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->dstream, hipStreamNonBlocking, lo));
+        // The runtime multiplexes its streams onto four hardware queues, and two streams that share one serialise (a fifth
+        // stream cost the 4K pipeline 4 k frames/s merely by existing): caller + tracker + prefetch leave ONE more.  It goes
+        // to the second tracker stream when chained launches alternate, else to the speculative detection.
+        if (!H->two_lk_streams) VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->dstream, hipStreamNonBlocking, lo));
         for (auto &e : H->warp_events) VSTAB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // :214-219 peek the first frame for the input size, then derive both cameras

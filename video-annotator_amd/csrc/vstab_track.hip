@@ -617,10 +617,56 @@ __device__ __forceinline__ uint4 make_record(float x, float y, unsigned int stat
 }
 __device__ __forceinline__ unsigned int record_status(const uint4 &r) { return r.w & 3u; }
 
-__global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid J, const float2 *__restrict__ prev_pts,
+// The device copy of a record is what the NEXT frame's tracker starts from, slot by slot, possibly while this launch is
+// still running (chained launches sit on alternating streams): each 8-byte granule goes out as ONE agent-scope store
+// (global_store_dwordx2 ... sc1, written through the XCD's L2) and is polled with agent-scope loads of the same width --
+// the data-tagged granule hand-off of /opt/skills/guides/MI355X_MICROARCH.md ("handoff-1to1"): a granule is valid as soon
+// as its own tag is, no fence on either side.
+__device__ __forceinline__ void publish_device_record(uint4 *slot, const uint4 &rec) {
+#ifdef VSTAB_LK_PLAIN_CHAIN
+    *slot = rec;
+    return;
+#endif
+    unsigned long long *g = reinterpret_cast<unsigned long long *>(slot);
+    __hip_atomic_store(g, (unsigned long long)rec.x | ((unsigned long long)rec.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 1, (unsigned long long)rec.z | ((unsigned long long)rec.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Wait until the parent launch (sequence number parent_seq) has published slot's record; bounded: on a time-out the slot
+// reports status 3 and the host fails the frame instead of hanging.
+__device__ __forceinline__ bool await_device_record(const uint4 *slot, unsigned int parent_seq, uint4 &rec) {
+    const unsigned long long *g = reinterpret_cast<const unsigned long long *>(slot);
+    for (unsigned int spins = 0; spins < (1u << 22); spins++) {
+        const unsigned long long a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned int)(a >> 32) == parent_seq && ((unsigned int)(b >> 32) >> 2) == (parent_seq & 0x3fffffffu)) {
+            rec = make_uint4((unsigned int)a, (unsigned int)(a >> 32), (unsigned int)b, (unsigned int)(b >> 32));
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return false;
+}
+
+#ifdef VSTAB_DEV
+// development builds: sixteen 100 MHz wall-clock stamps per feature and launch (tools/lk_timeline.py):
+// [0] entry, [1] start point known, [2] blocks staged, then per level (3 -> 0): [3 + 3 i] derivatives + patch matrix done,
+// [4 + 3 i] iterations done, [5 + 3 i] iteration count; [15] end
+__device__ unsigned long long *g_lk_timing = nullptr;
+extern "C" __attribute__((visibility("default"))) void vstab_dev_set_lk_timing(void *p) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lk_timing), &p, sizeof(p));
+}
+#define LK_STAMP(k, v) \
+    if (g_lk_timing && tid == 0) g_lk_timing[(((size_t)(seq & 63u) * 256 + (size_t)f) << 4) + (k)] = (v)
+#define LK_NOW() __builtin_amdgcn_s_memrealtime()
+#else
+#define LK_STAMP(k, v)
+#define LK_NOW() 0ull
+#endif
+
+__global__ void __launch_bounds__(LK_THREADS, 8) k_lk_track(LkPyramid I, LkPyramid J, const float2 *__restrict__ prev_pts,
                                                          int n, float2 *__restrict__ next_pts, uint8_t *__restrict__ status,
                                                          uint4 *__restrict__ host_rec, unsigned int seq,
-                                                         const uint4 *__restrict__ chain_in, uint4 *__restrict__ dev_rec,
+                                                         const uint4 *chain_in, unsigned int parent_seq, uint4 *dev_rec,
                                                          unsigned long long *__restrict__ clk) {
     __shared__ int regI[LK_MAX_LEVELS][LKR * LKR];
     __shared__ int derx[LKT * LKT], dery[LKT * LKT];
@@ -628,18 +674,35 @@ __global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid 
     __shared__ LkExchange ex;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (f >= n) return;
+#ifdef VSTAB_LK_PRIO
+    __builtin_amdgcn_s_setprio(VSTAB_LK_PRIO);
+#endif
     // development aid (VSTAB_LK_CLOCK): first workgroup start / last workgroup end on the 100 MHz wall clock
     if (clk && tid == 0) atomicMin(&clk[0], wall_clock64());
+    LK_STAMP(0, LK_NOW());
     float2 pp;
     if (chain_in) {
-        // chained launch: this slot's input is the record the previous launch wrote for it -- the point it
-        // tracked to, if it survived (status 1).  Slots that were lost earlier stay lost (status 2) and are
-        // skipped by the host, which is exactly the status filter of FrameSourceWarp.cpp:261-268.
+        // chained launch: this slot's input is the record the previous frame's launch wrote for it -- the point it
+        // tracked to, if it survived (status 1).  That launch may still be running (it sits on the other tracker
+        // stream): one lane waits for this slot's record, so every slot follows its OWN predecessor and a frame's
+        // slowest feature no longer holds up the other slots of the next frame.  Slots that were lost earlier stay
+        // lost (status 2) and are skipped by the host, which is exactly the status filter of FrameSourceWarp.cpp:261-268.
+#ifdef VSTAB_LK_PLAIN_CHAIN
         const uint4 r = chain_in[f];
-        if (record_status(r) != 1u) {  // uniform for the workgroup, before any barrier
+#else
+        __shared__ uint4 parent;
+        if (tid == 0) {
+            uint4 r = make_uint4(0, 0, 0, 3u);
+            if (!await_device_record(chain_in + f, parent_seq, r)) r.w = 3u;  // time-out: reported as status 3
+            parent = r;
+        }
+        __syncthreads();
+        const uint4 r = parent;
+#endif
+        if (record_status(r) != 1u) {  // uniform for the workgroup
             if (tid == 0) {
-                const uint4 dead = make_record(0.0f, 0.0f, 2u, seq);
-                if (dev_rec) dev_rec[f] = dead;
+                const uint4 dead = make_record(0.0f, 0.0f, record_status(r) == 3u ? 3u : 2u, seq);
+                if (dev_rec) publish_device_record(dev_rec + f, dead);
                 if (host_rec) host_rec[f] = dead;
             }
             return;
@@ -648,6 +711,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid 
     } else {
         pp = prev_pts[f];
     }
+    LK_STAMP(1, LK_NOW());
     float2 np = make_float2(0.f, 0.f);
     int st = 1, parity = 0;
     const float half = (LKW - 1) * 0.5f;
@@ -690,7 +754,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid 
             if (iok[l]) si[l].store(regI[l], tid);
         if (jorg_x != INT_MIN / 2) sj.store(regJ[0], tid);
     }
+    LK_STAMP(2, LK_NOW());
     for (int level = max_level; level >= 0; level--) {
+        int n_iter = 0;
         const uint8_t *jmg = J.img[level];
         const int w = I.w[level], h = I.h[level];
         const uint32_t jpitch = (uint32_t)J.pitch[level];
@@ -772,7 +838,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid 
             D = 1.f / D;
             npx -= half, npy -= half;
             float pdx = 0.f, pdy = 0.f;
+            LK_STAMP(3 + 3 * (max_level - level), LK_NOW());
             for (int j = 0; j < 30; j++) {
+                n_iter++;
                 const int inx = (int)floorf(npx), iny = (int)floorf(npy);
                 if (inx < -LKW || inx >= w || iny < -LKW || iny >= h) {
                     if (level == 0) st = 0;
@@ -826,16 +894,19 @@ __global__ void __launch_bounds__(LK_THREADS) k_lk_track(LkPyramid I, LkPyramid 
         } while (false);
         // the block fetched for the next level goes into the other buffer (its last readers left at the barrier of
         // the level before this one; the next level's first barrier publishes it)
+        LK_STAMP(4 + 3 * (max_level - level), LK_NOW());
+        LK_STAMP(5 + 3 * (max_level - level), (unsigned long long)n_iter);
         jb ^= 1;
         jorg_x = nx0, jorg_y = ny0;
         if (nx0 != INT_MIN / 2) sn.store(regJ[jb], tid);
     }
+    LK_STAMP(15, LK_NOW());
     if (tid == 0) {
         if (host_rec) {
             // one 16-byte record per feature in coherent host memory (make_record); the host polls the tags.  The device
             // copy feeds a chained launch for the next frame.
             const uint4 rec = make_record(np.x, np.y, (unsigned int)st, seq);
-            if (dev_rec) dev_rec[f] = rec;
+            if (dev_rec) publish_device_record(dev_rec + f, rec);
             host_rec[f] = rec;
             if (clk) atomicMax(&clk[1], wall_clock64());
         } else {
@@ -910,11 +981,12 @@ vstab_status launch_corners_fused(const uint8_t *src, size_t pitch, int w, int h
 
 vstab_status launch_lk(const LkPyramid &I, const LkPyramid &J, const float2 *prev_pts, int n, float2 *next_pts,
                        uint8_t *status, void *host_records, unsigned int seq, hipStream_t s, const void *chain_in,
-                       void *dev_records, void *clock_pair) {
+                       unsigned int parent_seq, void *dev_records, void *clock_pair) {
     if (n <= 0) return VSTAB_OK;
     if (!prev_pts && !chain_in) return fail(VSTAB_ERR_INVALID, "launch_lk: no input points");
     hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(LK_THREADS), 0, s, I, J, prev_pts, n, next_pts, status, static_cast<uint4 *>(host_records), seq,
-                       static_cast<const uint4 *>(chain_in), static_cast<uint4 *>(dev_records), static_cast<unsigned long long *>(clock_pair));
+                       static_cast<const uint4 *>(chain_in), parent_seq, static_cast<uint4 *>(dev_records),
+                       static_cast<unsigned long long *>(clock_pair));
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }

@@ -37,11 +37,12 @@ vstab_status launch_corners_fused(const uint8_t *src, size_t pitch, int w, int h
                                   unsigned int cap, unsigned int *small, hipStream_t s);
 // host_records (may be NULL): n 16-byte records {x, seq, y, seq << 2 | status} in mapped host memory, written instead
 // of next_pts / status so the host can poll for completion without a stream synchronisation
-// chain_in (may be NULL): the device records of the previous frame's launch; slot f then starts from the point that
-// launch tracked it to (status 1) or reports status 2 ("lost earlier") without tracking.  dev_records (may be NULL):
-// device copy of the records for the launch chained behind this one.
+// chain_in (may be NULL): the device records of the previous frame's launch, whose sequence number is parent_seq; slot f
+// WAITS for that launch's record f (the two launches may run side by side on different streams), then starts from the
+// point it holds (status 1) or reports status 2 ("lost earlier") without tracking; status 3 = the record never came.
+// dev_records (may be NULL): device copy of the records for the launch chained behind this one.
 vstab_status launch_lk(const LkPyramid &I, const LkPyramid &J, const float2 *prev_pts, int n, float2 *next_pts,
                        uint8_t *status, void *host_records, unsigned int seq, hipStream_t s, const void *chain_in = nullptr,
-                       void *dev_records = nullptr, void *clock_pair = nullptr);
+                       unsigned int parent_seq = 0, void *dev_records = nullptr, void *clock_pair = nullptr);
 
 }  // namespace vstab

@@ -39,6 +39,13 @@ namespace vstab {
 // Every other input (|a| >= 2^22, +-inf, NaN) yields an integer >= 2^22 in magnitude, which lands far outside any
 // source <= 32767 wide -- the same "outside" cv::remap reaches through cvRound -> INT_MIN.  QMAGIC_BITS is a multiple
 // of 32, so (bits >> 5) - (QMAGIC_BITS >> 5) is the tap column and bits & 31 the fraction.
+// Register budget of the kernel as waves per SIMD it must leave room for: 7 -> at most 72 registers.  The kernel itself is
+// held to 4 waves per SIMD by its LDS; what it leaves free is what the tracker and pyramid kernels beside it run in.
+#ifndef VSTAB_WARP_WAVES
+#define VSTAB_WARP_WAVES 7
+#endif
+constexpr int MAP_GROUP = 2;  // row pairs whose exact-map chains advance in lock-step
+constexpr int TAP_GROUP = 4;  // output rows whose LDS tap reads are issued before the first blend
 constexpr float QMAGIC = 12582912.0f;
 constexpr int QMAGIC_BITS = 0x4B400000;
 
@@ -399,43 +406,55 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
         auto bcast = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
         auto bcast2 = [&bcast](float v, int j) { return (f32x2){bcast(v, j), bcast(v, j + 1)}; };
         if constexpr (BASE == MAP_CREATEMAP_CL || BASE == MAP_FISH_TO_RECT) {
-            constexpr int NP = RW / 2;
-            f32x2 wx[NP], wy[NP], wz[NP], ax[NP], ay[NP];
+            // row pairs in lock-step groups of MAP_GROUP (more pairs in flight would push the kernel past 64 registers and
+            // take wave slots away from the tracker and pyramid kernels that run beside it)
+            constexpr int NP = RW / 2 < MAP_GROUP ? RW / 2 : MAP_GROUP;
 #pragma unroll
-            for (int c = 0; c < NP; c++) {
-                if constexpr (RS) {  // every row has its own matrix: column products and third column per row
-                    wx[c] = (bcast2(m_l[0], 2 * c) * splat2(vx) + bcast2(b0_l, 2 * c)) + bcast2(m_l[2], 2 * c);
-                    wy[c] = (bcast2(m_l[3], 2 * c) * splat2(vx) + bcast2(b1_l, 2 * c)) + bcast2(m_l[5], 2 * c);
-                    wz[c] = (bcast2(m_l[6], 2 * c) * splat2(vx) + bcast2(b2_l, 2 * c)) + bcast2(m_l[8], 2 * c);
-                } else {
-                    wx[c] = (splat2(ct.a0) + bcast2(b0_l, 2 * c)) + splat2(a.p.r[2]);
-                    wy[c] = (splat2(ct.a1) + bcast2(b1_l, 2 * c)) + splat2(a.p.r[5]);
-                    wz[c] = (splat2(ct.a2) + bcast2(b2_l, 2 * c)) + splat2(a.p.r[8]);
+            for (int g0 = 0; g0 < RW / 2; g0 += NP) {
+                f32x2 wx[NP], wy[NP], wz[NP], ax[NP], ay[NP];
+#pragma unroll
+                for (int c = 0; c < NP; c++) {
+                    const int j = 2 * (g0 + c);
+                    if constexpr (RS) {  // every row has its own matrix: column products and third column per row
+                        wx[c] = (bcast2(m_l[0], j) * splat2(vx) + bcast2(b0_l, j)) + bcast2(m_l[2], j);
+                        wy[c] = (bcast2(m_l[3], j) * splat2(vx) + bcast2(b1_l, j)) + bcast2(m_l[5], j);
+                        wz[c] = (bcast2(m_l[6], j) * splat2(vx) + bcast2(b2_l, j)) + bcast2(m_l[8], j);
+                    } else {
+                        wx[c] = (splat2(ct.a0) + bcast2(b0_l, j)) + splat2(a.p.r[2]);
+                        wy[c] = (splat2(ct.a1) + bcast2(b1_l, j)) + splat2(a.p.r[5]);
+                        wz[c] = (splat2(ct.a2) + bcast2(b2_l, j)) + splat2(a.p.r[8]);
+                    }
+                }
+                map_pairs_ieee<NP, BASE == MAP_FISH_TO_RECT>(icx32, icy32, ifx32, ify32, wx, wy, wz, ax, ay);
+#pragma unroll
+                for (int c = 0; c < NP; c++) {
+                    const int j = 2 * (g0 + c);
+                    ax[c] += splat2(QMAGIC), ay[c] += splat2(QMAGIC);
+                    qxb[j] = __float_as_int(ax[c].x), qxb[j + 1] = __float_as_int(ax[c].y);
+                    qyb[j] = __float_as_int(ay[c].x), qyb[j + 1] = __float_as_int(ay[c].y);
                 }
             }
-            map_pairs_ieee<NP, BASE == MAP_FISH_TO_RECT>(icx32, icy32, ifx32, ify32, wx, wy, wz, ax, ay);
-#pragma unroll
-            for (int c = 0; c < NP; c++) {
-                ax[c] += splat2(QMAGIC), ay[c] += splat2(QMAGIC);
-                qxb[2 * c] = __float_as_int(ax[c].x), qxb[2 * c + 1] = __float_as_int(ax[c].y);
-                qyb[2 * c] = __float_as_int(ay[c].x), qyb[2 * c + 1] = __float_as_int(ay[c].y);
-            }
         } else if constexpr (BASE == MAP_CREATEMAP_CL_OPENCL) {
-            constexpr int NP = RW / 2;
-            f32x2 wx[NP], wy[NP], wz[NP], ax[NP], ay[NP];
+            constexpr int NP = RW / 2 < MAP_GROUP ? RW / 2 : MAP_GROUP;
+            uint32_t irregular = 0;
 #pragma unroll
-            for (int c = 0; c < NP; c++) {
-                const f32x2 vy2 = bcast2(vy_l, 2 * c);
-                wz[c] = fma2(splat2(a.p.r[7]), vy2, splat2(ct.a2)) + splat2(a.p.r[8]);
-                wx[c] = fma2(splat2(a.p.r[1]), vy2, splat2(ct.a0)) + splat2(a.p.r[2]);
-                wy[c] = fma2(splat2(a.p.r[4]), vy2, splat2(ct.a1)) + splat2(a.p.r[5]);
-            }
-            const uint32_t irregular = map_pairs_ocl<NP>(icx32, icy32, ifx32, ify32, wx, wy, wz, ax, ay);
+            for (int g0 = 0; g0 < RW / 2; g0 += NP) {
+                f32x2 wx[NP], wy[NP], wz[NP], ax[NP], ay[NP];
 #pragma unroll
-            for (int c = 0; c < NP; c++) {
-                ax[c] += splat2(QMAGIC), ay[c] += splat2(QMAGIC);
-                qxb[2 * c] = __float_as_int(ax[c].x), qxb[2 * c + 1] = __float_as_int(ax[c].y);
-                qyb[2 * c] = __float_as_int(ay[c].x), qyb[2 * c + 1] = __float_as_int(ay[c].y);
+                for (int c = 0; c < NP; c++) {
+                    const f32x2 vy2 = bcast2(vy_l, 2 * (g0 + c));
+                    wz[c] = fma2(splat2(a.p.r[7]), vy2, splat2(ct.a2)) + splat2(a.p.r[8]);
+                    wx[c] = fma2(splat2(a.p.r[1]), vy2, splat2(ct.a0)) + splat2(a.p.r[2]);
+                    wy[c] = fma2(splat2(a.p.r[4]), vy2, splat2(ct.a1)) + splat2(a.p.r[5]);
+                }
+                irregular |= map_pairs_ocl<NP>(icx32, icy32, ifx32, ify32, wx, wy, wz, ax, ay);
+#pragma unroll
+                for (int c = 0; c < NP; c++) {
+                    const int j = 2 * (g0 + c);
+                    ax[c] += splat2(QMAGIC), ay[c] += splat2(QMAGIC);
+                    qxb[j] = __float_as_int(ax[c].x), qxb[j + 1] = __float_as_int(ax[c].y);
+                    qyb[j] = __float_as_int(ay[c].x), qyb[j + 1] = __float_as_int(ay[c].y);
+                }
             }
             if (__builtin_amdgcn_ballot_w64(irregular != 0)) {  // practically never: the code object's literal stream
 #pragma unroll 1
@@ -516,19 +535,23 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
         }
         if (!__builtin_amdgcn_ballot_w64(mxx >= wlim || mxy >= hlim)) {
             // every footprint of the wave lies in the staged box: all tap reads first, then the blends
-            uint32_t t0[RW], t1[RW], t2[RW], t3[RW];
+            constexpr int TG = RW < TAP_GROUP ? RW : TAP_GROUP;  // rows whose tap reads are in flight together
 #pragma unroll
-            for (int j = 0; j < RW; j++) {
-                const uint32_t *t = tile + (__mul24(Yr[j], wb) + Xr[j]);
-                t0[j] = t[0], t1[j] = t[1], t2[j] = t[wb], t3[j] = t[wb + 1];
-            }
+            for (int j0 = 0; j0 < RW; j0 += TG) {
+                uint32_t t0[TG], t1[TG], t2[TG], t3[TG];
 #pragma unroll
-            for (int j = 0; j < RW; j++) {
+                for (int j = 0; j < TG; j++) {
+                    const uint32_t *t = tile + (__mul24(Yr[j0 + j], wb) + Xr[j0 + j]);
+                    t0[j] = t[0], t1[j] = t[1], t2[j] = t[wb], t3[j] = t[wb + 1];
+                }
+#pragma unroll
+                for (int j = 0; j < TG; j++) {
 #ifdef VSTAB_DEV
-                if (ta.ablate & 2) out[j] = t0[j] ^ t1[j] ^ t2[j] ^ t3[j] ^ (qxb[j] & 31) ^ (qyb[j] & 31);
-                else
+                    if (ta.ablate & 2) out[j0 + j] = t0[j] ^ t1[j] ^ t2[j] ^ t3[j] ^ (qxb[j0 + j] & 31) ^ (qyb[j0 + j] & 31);
+                    else
 #endif
-                out[j] = blend_bgrx(t0[j], t1[j], t2[j], t3[j], qxb[j] & 31, qyb[j] & 31);
+                    out[j0 + j] = blend_bgrx(t0[j], t1[j], t2[j], t3[j], qxb[j0 + j] & 31, qyb[j0 + j] & 31);
+                }
             }
         } else {
             // rare (source border with a box that had to be cut, degenerate rotation, box over the LDS budget): pixel by
@@ -658,7 +681,7 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
 // 4 RWB rows, then -- from row split_y[k] on -- through tiles of half that height (the last, partly filled round of
 // workgroups then lasts half as long).  Placement and tile height only affect speed, never results.
 template <int RWB, int MODE, int FMT, bool CACHED>
-__global__ void __launch_bounds__(256) k_warp_fused(FusedArgs ta) {
+__global__ void __launch_bounds__(256, VSTAB_WARP_WAVES) k_warp_fused(FusedArgs ta) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int TH = 4 * RWB, TS = TH / 2;
     const int k = (int)(blockIdx.x & 7u), idx = (int)(blockIdx.x >> 3);
