@@ -8,14 +8,25 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "vstab_frame_source.hpp"
 
 class SyntheticSource : public vstab::NV12FrameSource {  // stands in for FrameSourceFfmpegOpenCl
   public:
-    SyntheticSource(int w, int h, int n) : w_(w), h_(h), left_(n) {
+    // gyro: also stand in for the GPMF "GYRO" stream the reference never got to read (gpmf.cpp:5-11): 3.2 kHz samples of a
+    // hand-held shake, integrated per frame into the rotation since the previous frame and the rotation during read-out
+    SyntheticSource(int w, int h, int n, bool gyro = false) : w_(w), h_(h), left_(n), gyro_(gyro) {
+        if (gyro) {
+            const double hz = 3200.0, fps = 30.0;
+            for (int i = 0; i < (int)((n + 2) / fps * hz); i++) {
+                const double t = (i + 0.5) / hz;
+                samples_.push_back({i / hz, (i + 1) / hz, 0.5 * std::sin(23 * t + 1.1), 0.9 * std::sin(40 * t), 0.7 * std::cos(31 * t + 0.3)});
+            }
+        }
         std::vector<unsigned char> host((size_t)w * h * 3 / 2);
         for (int f = 0; f < 4; f++) {
             for (int y = 0; y < h; y++)
@@ -36,6 +47,12 @@ class SyntheticSource : public vstab::NV12FrameSource {  // stands in for FrameS
         // hold: these frames live as long as the source, so the library uses them in place (no copy into its ring)
         vstab::NV12Frame f{p, p + (size_t)w_ * h_, (size_t)w_, (size_t)w_, w_, h_};
         f.hold = 1 << 20;
+        if (gyro_) {
+            // frame k: first row exposed at k / 30 s, last row 8 ms later; a body-rate gyro -> rate_scale -1
+            const double t_first = idx_ / 30.0, t_prev = idx_ ? (idx_ - 1) / 30.0 : t_first;
+            if (vstab_gyro_integrate(samples_.data(), (int)samples_.size(), -1.0, t_prev, t_first, t_first + 0.008, delta_, readout_) != VSTAB_OK) throw -1;
+            f.delta_rotation = delta_, f.readout_rotation = readout_;
+        }
         return f;
     }
     vstab::NV12Frame pull_frame() override {
@@ -46,15 +63,29 @@ class SyntheticSource : public vstab::NV12FrameSource {  // stands in for FrameS
 
   private:
     int w_, h_, left_;
+    bool gyro_;
     size_t idx_ = 0;
     std::vector<void *> frames_;
+    std::vector<vstab_gyro_sample> samples_;
+    double delta_[9], readout_[9];
 };
+
+int run(vstab::FrameSourceWarp &warped, int n);
 
 int main(int argc, char **argv) {
     const int n = argc > 1 ? std::atoi(argv[1]) : 100;
-    auto source = std::make_shared<SyntheticSource>(1920, 1440, n);
+    const bool gyro = argc > 2 && std::string(argv[2]) == "gyro";
+    auto source = std::make_shared<SyntheticSource>(1920, 1440, n, gyro);
+    if (gyro) {  // motion from the (synthetic) gyro stream instead of optical flow
+        vstab::FrameSourceWarp warped(source, VSTAB_GOPRO_H4B_WIDE43_MEASURED, vstab::FrameSourceWarp::SensorMotion{}, 0.5, false, 1.0, 30);
+        return run(warped, n);
+    }
     // DisplayImage.cpp:55: FrameSourceWarp(ffmpeg_source, GOPRO_H4B_WIDE43_MEASURED, 0.5, false, 1.0, 30)
     vstab::FrameSourceWarp warped(source, VSTAB_GOPRO_H4B_WIDE43_MEASURED, 0.5, false, 1.0, 30);
+    return run(warped, n);
+}
+
+int run(vstab::FrameSourceWarp &warped, int n) {
     void *out = nullptr;
     const size_t pitch = (size_t)warped.output_width() * 3;
     if (hipMalloc(&out, pitch * warped.output_height()) != hipSuccess) return 1;

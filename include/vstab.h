@@ -238,6 +238,27 @@ VSTAB_API vstab_status vstab_rotation_filter_add(vstab_rotation_filter *f, const
 VSTAB_API vstab_status vstab_rotation_filter_filter(const vstab_rotation_filter *f, double R_out[9]);
 VSTAB_API void vstab_rotation_filter_destroy(vstab_rotation_filter *f);
 
+/* Gyro samples -> the per-frame rotations the pipeline takes from an external sensor (vstab_frame.delta_rotation,
+ * vstab_frame.readout_rotation): the step the reference stubbed (gpmf.cpp:5-11 declares GyroFrame {start_ts, end_ts, roll,
+ * pitch, yaw} and the commented-out reader fills one per GPMF "GYRO" sample; AvFrameSourceFileVaapi.cpp:121-123 "TODO process
+ * GPMF packet").  vstab_gyro_sample IS that record: an angular rate held from start_ts to end_ts (seconds on the clock the
+ * frame timestamps use), about the camera's z (roll), x (pitch) and y (yaw) axes, x right, y down, z along the optical axis.
+ * Over an interval [a, b] the rotation is the ordered product of exponential maps, later samples on the left (the
+ * accumulation order of FrameSourceWarp.cpp:441):
+ *     R(a, b) = exp([w_n] dt_n) ... exp([w_1] dt_1),   w_i = rate_scale * (pitch_i, yaw_i, roll_i),
+ *     dt_i = length of [start_ts_i, end_ts_i] inside [a, b]   (time not covered by any sample contributes nothing).
+ * rate_scale = -1 for a gyro that reports the rate of the camera BODY in rad/s (points of the scene then move by R in camera
+ * coordinates, which is what guess_camera_rotation returns); it also absorbs unit conversion (-pi/180 for deg/s).
+ * R_delta = R(t_prev_first_row, t_first_row): the camera's rotation since the previous frame; R_readout =
+ * R(t_first_row, t_last_row): its rotation during this frame's read-out (rolling shutter).  Either may be NULL.  Samples
+ * must be ordered by start_ts with end_ts >= start_ts.  fp64, host only.  GPMF container parsing (gpmf-parser) stays upstream. */
+typedef struct vstab_gyro_sample {
+    double start_ts, end_ts, roll, pitch, yaw; /* field order of the reference's GyroFrame */
+} vstab_gyro_sample;
+VSTAB_API vstab_status vstab_gyro_integrate(const vstab_gyro_sample *samples, int n, double rate_scale,
+                                            double t_prev_first_row, double t_first_row, double t_last_row,
+                                            double R_delta[9], double R_readout[9]);
+
 /* A map that does not change between frames (tracking off: undistort only, the CLI's stab=none re-projections) need
  * not be evaluated per frame as the reference does (FrameSourceWarp.cpp:283-304): vstab_quantised_map writes, once,
  * what cv::remap makes of every map entry (32 * map rounded to int; vstab_quantised_map_bytes() bytes, 16-byte aligned

@@ -22,6 +22,7 @@ struct NV12Frame {
     int width = 0, height = 0;
     bool host = false;
     const double *delta_rotation = nullptr;  // optional external (gyro) rotation since the previous frame, 3x3 row-major
+    const double *readout_rotation = nullptr;  // optional: rotation during this frame's read-out (rolling shutter), from the same sensor
     int bit_depth = 8;  // 10 / 12 / 16: P010-style 16-bit samples (device memory), narrowed on ingest
     int hold = 0;  // vstab_frame.hold: further pulls this frame's memory stays valid for (0 = until the next pull)
 };
@@ -78,6 +79,19 @@ class FrameSourceWarp : public FrameSource {
         vstab_config_default(&cfg);
         cfg.preset = input_camera, cfg.scale = scale, cfg.crop_borders = crop_borders, cfg.zoom = zoom;
         cfg.smooth_radius = smooth_radius, cfg.interpolation = interpolation, cfg.stream = hip_stream;
+        init(cfg);
+    }
+    // Motion from an external sensor instead of optical flow -- the gyro path the reference stubs (gpmf.cpp:5-11,
+    // AvFrameSourceFileVaapi.cpp:121-123): every frame of `source` carries delta_rotation (and, for a rolling shutter,
+    // readout_rotation), e.g. from vstab_gyro_integrate; smoothing and warp are the reference's (not a reference constructor).
+    struct SensorMotion {};
+    FrameSourceWarp(std::shared_ptr<NV12FrameSource> source, CameraPreset input_camera, SensorMotion, double scale = 1,
+                    bool crop_borders = false, double zoom = 1, int smooth_radius = 30, void *hip_stream = nullptr)
+        : m_source(std::move(source)) {
+        vstab_config cfg;
+        vstab_config_default(&cfg);
+        cfg.preset = input_camera, cfg.scale = scale, cfg.crop_borders = crop_borders, cfg.zoom = zoom;
+        cfg.smooth_radius = smooth_radius, cfg.stream = hip_stream, cfg.tracking = 0;
         init(cfg);
     }
     // The same object configured the way the CLI configures libdewobble (not a reference constructor).
@@ -156,6 +170,7 @@ class FrameSourceWarp : public FrameSource {
             const NV12Frame f = advance ? self->m_source->pull_frame() : self->m_source->peek_frame();
             out->y = f.y, out->uv = f.uv, out->pitch_y = f.pitch_y, out->pitch_uv = f.pitch_uv;
             out->width = f.width, out->height = f.height, out->mem = f.host ? 1 : 0, out->pts = 0, out->delta_rotation = f.delta_rotation, out->bit_depth = f.bit_depth, out->hold = f.hold;
+            out->readout_rotation = f.readout_rotation;
             return 0;
         } catch (int err) {  // upstream errors are thrown ints (AvFrameSourceFileVaapi.cpp:141)
             if (err != EOF) self->m_pending_error = err;

@@ -155,6 +155,23 @@ def rodrigues(rvec):
     return math.cos(th) * np.eye(3) + (1 - math.cos(th)) * np.outer(k, k) + math.sin(th) * Kx
 
 
+def gyro_integrate(samples, rate_scale, t_prev_first_row, t_first_row, t_last_row):
+    """What the reference's stubbed gyro path has to compute (gpmf.cpp:5-11 GyroFrame {start_ts, end_ts, roll, pitch, yaw};
+    AvFrameSourceFileVaapi.cpp:121-123): per span, the ordered product of exponential maps of rate x overlap, later samples
+    on the left (the accumulation order of FrameSourceWarp.cpp:441).  -> (R_delta over [t_prev_first_row, t_first_row],
+    R_readout over [t_first_row, t_last_row]).  Independent numpy restatement of vstab_gyro_integrate."""
+    s = np.asarray(samples, np.float64).reshape(-1, 5)
+
+    def span(a, b):
+        R = np.eye(3)
+        for start, end, roll, pitch, yaw in s:
+            lo, hi = max(start, a), min(end, b)
+            if hi > lo:
+                R = rodrigues(np.array([pitch, yaw, roll]) * ((hi - lo) * rate_scale)) @ R
+        return R
+    return span(t_prev_first_row, t_first_row), span(t_first_row, t_last_row)
+
+
 def rotation_angle(R):
     return math.acos(max(-1.0, min(1.0, (np.trace(R) - 1) / 2)))
 

@@ -3,6 +3,7 @@ against ground truth, SG filter / weights against the oracle and the golden vect
 import os
 
 import numpy as np
+import pytest
 
 import oracle
 import synth
@@ -124,3 +125,61 @@ def test_sg_filter_startup_reflection_quirk(vs):
     f.add(R), o.add(R)
     assert np.allclose(o.filter(), -R, atol=1e-12)
     assert np.allclose(f.filter(), -R, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# gyro samples -> rotations (the path gpmf.cpp:5-11 stubs)
+# ---------------------------------------------------------------------------------------------
+def _gyro_samples(rate_fn, t0, t1, hz):
+    """GyroFrame records {start_ts, end_ts, roll, pitch, yaw}: the rate at the middle of each sample interval."""
+    edges = np.arange(int(round((t1 - t0) * hz)) + 1) / hz + t0
+    mid = 0.5 * (edges[:-1] + edges[1:])
+    w = np.array([rate_fn(t) for t in mid])  # (x, y, z) = (pitch, yaw, roll)
+    return np.stack([edges[:-1], edges[1:], w[:, 2], w[:, 0], w[:, 1]], 1)
+
+
+def test_gyro_constant_rate_is_one_exponential_map(vs):
+    w = np.array([0.11, -0.23, 0.31])  # rad/s about x, y, z
+    s = _gyro_samples(lambda t: w, 0.0, 0.2, 400.0)
+    tp, tf, tl = 0.0503, 0.0503 + 1 / 30, 0.0503 + 1 / 30 + 0.0081
+    Rd, Rr = vs.gyro_integrate(s, 1.0, tp, tf, tl)
+    assert np.allclose(Rd, oracle.rodrigues(w * (tf - tp)), atol=1e-14)
+    assert np.allclose(Rr, oracle.rodrigues(w * (tl - tf)), atol=1e-14)
+    # a body-rate gyro: rate_scale -1 gives the inverse rotation (what guess_camera_rotation would measure)
+    Rb, _ = vs.gyro_integrate(s, -1.0, tp, tf, tl)
+    assert np.allclose(Rb, Rd.T, atol=1e-14)
+    # restatement agrees; time not covered by samples contributes nothing
+    Od, Or = oracle.gyro_integrate(s, 1.0, tp, tf, tl)
+    assert np.allclose(Rd, Od, atol=1e-15) and np.allclose(Rr, Or, atol=1e-15)
+    Rg, _ = vs.gyro_integrate(s, 1.0, -1.0, 0.05, 0.06)
+    assert np.allclose(Rg, oracle.rodrigues(w * 0.05), atol=1e-14)
+    assert np.allclose(vs.gyro_integrate(s[:0], 1.0, 0.0, 0.1, 0.2)[0], np.eye(3))
+
+
+def test_gyro_sinusoidal_shake_against_the_closed_form_and_a_fine_reference(vs):
+    # one axis: rotations commute, the integral of the rate is the angle -- exact up to the sampling of the rate
+    amp, f = 0.04, 7.0
+    rate = lambda t: np.array([0.0, amp * 2 * np.pi * f * np.cos(2 * np.pi * f * t), 0.0])
+    s = _gyro_samples(rate, 0.0, 0.5, 3200.0)
+    tp, tf = 0.1, 0.1 + 1 / 29.97
+    Rd, _ = vs.gyro_integrate(s, 1.0, tp, tf, tf)
+    ang = amp * (np.sin(2 * np.pi * f * tf) - np.sin(2 * np.pi * f * tp))
+    assert oracle.rotation_angle(Rd @ oracle.rodrigues([0, ang, 0]).T) < 1e-6   # midpoint sampling of a 7 Hz sine at 3.2 kHz
+    # three axes with different phases (non-commuting): against the same product on a 64 x finer sampling, and the restatement
+    rate3 = lambda t: np.array([0.9 * np.sin(40 * t), 0.7 * np.cos(31 * t + 0.3), 0.5 * np.sin(23 * t + 1.1)])
+    coarse, fine = _gyro_samples(rate3, 0.0, 0.3, 800.0), _gyro_samples(rate3, 0.0, 0.3, 51200.0)
+    tp, tf, tl = 0.0712, 0.0712 + 1 / 30, 0.0712 + 1 / 30 + 0.012
+    Rd, Rr = vs.gyro_integrate(coarse, -1.0, tp, tf, tl)
+    Fd, Fr = oracle.gyro_integrate(fine, -1.0, tp, tf, tl)
+    assert oracle.rotation_angle(Rd @ Fd.T) < 1e-5 and oracle.rotation_angle(Rr @ Fr.T) < 5e-6   # 800 Hz piecewise-constant rate: 4e-6 rad
+    Od, Or = oracle.gyro_integrate(coarse, -1.0, tp, tf, tl)
+    assert np.allclose(Rd, Od, atol=1e-14) and np.allclose(Rr, Or, atol=1e-14)
+    assert abs(np.linalg.det(Rd) - 1) < 1e-13 and np.allclose(Rd @ Rd.T, np.eye(3), atol=1e-13)
+
+
+def test_gyro_bad_arguments(vs):
+    s = _gyro_samples(lambda t: np.zeros(3), 0.0, 0.1, 100.0)
+    with pytest.raises(vs.VstabError):
+        vs.gyro_integrate(s[::-1], 1.0, 0.0, 0.01, 0.02)       # unordered
+    with pytest.raises(vs.VstabError):
+        vs.gyro_integrate(s, 1.0, 0.05, 0.01, 0.02)            # t_prev after t_first

@@ -112,6 +112,7 @@ SIGNATURES = {
     "vstab_pyr_lk": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _fp, _u8p, _vp]),
     "vstab_estimate_rotation": (_i, [_fp, _fp, _i, _dp, _dp, _u64, _dp, _ip]),
     "vstab_sg_weights": (_i, [_i, _dp]),
+    "vstab_gyro_integrate": (_i, [_vp, _i, _d, _d, _d, _d, _dp, _dp]),
     "vstab_rotation_filter_create": (_i, [_i, _pp]),
     "vstab_rotation_filter_add": (_i, [_vp, _dp]),
     "vstab_rotation_filter_filter": (_i, [_vp, _dp]),
@@ -452,6 +453,16 @@ def estimate_rotation(prev_xy, cur_xy, K_in, K_out, seed=1):
     _check(_L.vstab_estimate_rotation(_fptr(a), _fptr(b), a.shape[0], _dptr(Ki), _dptr(Ko), seed, _dptr(R), _c.byref(inl)),
            "vstab_estimate_rotation")
     return R.reshape(3, 3), inl.value
+
+
+def gyro_integrate(samples, rate_scale, t_prev_first_row, t_first_row, t_last_row):
+    """vstab_gyro_integrate.  samples: (n, 5) doubles {start_ts, end_ts, roll, pitch, yaw} (the reference's GyroFrame,
+    gpmf.cpp:5-11) -> (R_delta, R_readout) 3x3."""
+    a = np.ascontiguousarray(samples, np.float64).reshape(-1, 5)
+    Rd, Rr = np.zeros(9), np.zeros(9)
+    _check(_L.vstab_gyro_integrate(a.ctypes.data_as(_vp), a.shape[0], float(rate_scale), float(t_prev_first_row), float(t_first_row),
+                                   float(t_last_row), Rd.ctypes.data_as(_dp), Rr.ctypes.data_as(_dp)), "vstab_gyro_integrate")
+    return Rd.reshape(3, 3), Rr.reshape(3, 3)
 
 
 def sg_weights(m):

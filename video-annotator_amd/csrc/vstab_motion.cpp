@@ -3,6 +3,7 @@
 // The data is <= 200 points / one 3x3 matrix per frame, exactly as small as in the reference,
 // which also runs these steps on the host.
 #include "vstab_motion.hpp"
+#include "vstab_internal.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -303,3 +304,42 @@ Mat3 RotationFilterKalman::update(const Mat3 &measured) {
 }
 
 }  // namespace vstab
+
+// ---------------------------------------------------------------------------------------------
+// Gyro samples -> rotations (the step gpmf.cpp:5-11 / AvFrameSourceFileVaapi.cpp:121-123 stub out): ordered product of
+// exponential maps of rate * overlap, later samples on the left (include/vstab.h).
+// ---------------------------------------------------------------------------------------------
+namespace vstab {
+static Mat3 gyro_span(const vstab_gyro_sample *s, int n, double scale, double a, double b) {
+    Mat3 R = Mat3::identity();
+    for (int i = 0; i < n; i++) {
+        const double lo = s[i].start_ts > a ? s[i].start_ts : a, hi = s[i].end_ts < b ? s[i].end_ts : b;
+        if (!(hi > lo)) continue;
+        const double dt = (hi - lo) * scale;
+        const double rv[3] = {s[i].pitch * dt, s[i].yaw * dt, s[i].roll * dt};
+        R = rodrigues(rv) * R;
+    }
+    return R;
+}
+}  // namespace vstab
+
+extern "C" vstab_status vstab_gyro_integrate(const vstab_gyro_sample *samples, int n, double rate_scale, double t_prev_first_row,
+                                             double t_first_row, double t_last_row, double R_delta[9], double R_readout[9]) {
+    using namespace vstab;
+    if (n < 0 || (n > 0 && !samples)) return fail(VSTAB_ERR_INVALID, "vstab_gyro_integrate: null samples");
+    if (!(rate_scale == rate_scale) || !(t_prev_first_row <= t_first_row) || !(t_first_row <= t_last_row))
+        return fail(VSTAB_ERR_INVALID, "vstab_gyro_integrate: need t_prev_first_row <= t_first_row <= t_last_row");
+    for (int i = 0; i < n; i++) {
+        if (!(samples[i].end_ts >= samples[i].start_ts) || (i > 0 && !(samples[i].start_ts >= samples[i - 1].start_ts)))
+            return fail(VSTAB_ERR_INVALID, "vstab_gyro_integrate: samples must be ordered by start_ts with end_ts >= start_ts");
+    }
+    if (R_delta) {
+        const Mat3 R = gyro_span(samples, n, rate_scale, t_prev_first_row, t_first_row);
+        for (int k = 0; k < 9; k++) R_delta[k] = R.m[k];
+    }
+    if (R_readout) {
+        const Mat3 R = gyro_span(samples, n, rate_scale, t_first_row, t_last_row);
+        for (int k = 0; k < 9; k++) R_readout[k] = R.m[k];
+    }
+    return VSTAB_OK;
+}
