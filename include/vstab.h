@@ -291,7 +291,7 @@ typedef struct vstab_frame {
     const void *uv;
     size_t pitch_y, pitch_uv;
     int width, height; /* luma size; both even */
-    int mem;           /* 0 = device memory, 1 = host memory */
+    int mem;           /* 0 = device memory, 1 = host memory, 2 (VSTAB_MEM_DMABUF) = a DMA-BUF: see dmabuf_fd below */
     int64_t pts;
     const double *delta_rotation; /* optional (NULL = none): 3x3 row-major rotation of the camera since the previous
                           frame from an external sensor -- the gyro path the reference stubs (gpmf.cpp:5-11,
@@ -313,7 +313,17 @@ typedef struct vstab_frame {
                           the stabilising rotation W for the first row, readout_rotation * W for the last, matrix entries
                           interpolated in between (vstab_warp_nv12_rs; preset and fisheye -> rectilinear maps only).  Read
                           during the callback only. */
+    int dmabuf_fd;     /* mem == VSTAB_MEM_DMABUF: the frame lives in a DMA-BUF object -- what a VAAPI / AMF decoder surface is
+                          once exported (av_hwframe_map(..., AV_PIX_FMT_DRM_PRIME) -> AVDRMFrameDescriptor: objects[0].fd /
+                          .size, layers[].planes[].offset / .pitch).  `y` and `uv` are then BYTE OFFSETS of the two planes
+                          inside the object (cast to pointers), pitch_y / pitch_uv as usual.  The library imports the object
+                          into the HIP address space (hipImportExternalMemory; cached per object, the fd is not consumed and
+                          may be closed after the callback) and uses the planes as device memory under the `hold` rules above:
+                          the zero-copy replacement of the reference's VAAPI -> host -> OpenCL double copy
+                          (AvFrameSourceMapOpenCl.cpp:17-66).  Ignored for other `mem` values. */
+    size_t dmabuf_size; /* size of the object in bytes (AVDRMObjectDescriptor.size) */
 } vstab_frame;
+enum { VSTAB_MEM_DEVICE = 0, VSTAB_MEM_HOST = 1, VSTAB_MEM_DMABUF = 2 };
 
 /* Upstream FrameSource (FrameSource.hpp:14,20): return 0 and fill *out, VSTAB_EOF (-1) at end of
  * stream, any other value on failure (propagated as VSTAB_ERR_SOURCE, like a rethrown int). */

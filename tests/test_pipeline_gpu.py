@@ -328,6 +328,108 @@ def _run_raw_device_source(vs, cuda, frames, hold, recycle, p010=False, pool=0, 
     return outs
 
 
+def _hip_runtime():
+    """The HIP runtime this process already uses (PyTorch's copy), for the two calls the test needs beside torch."""
+    import ctypes
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            return ctypes.CDLL(line.split()[-1])
+    pytest.fail("no HIP runtime mapped")
+
+
+def test_dmabuf_frames_are_imported_and_read_in_place(vs, cuda, clip):
+    """SURVEY.md 8(f) row 3 without libav: a decoder surface arrives as a DMA-BUF (what av_hwframe_map(..., DRM_PRIME) hands
+    out: fd, size, per-plane offset and pitch).  A pool of device buffers is exported with
+    hipMemGetHandleForAddressRange(DmaBufFd), every frame is handed over as {fd, size, offsets}; the library imports each
+    object once and must produce the stream it produces from plain device pointers -- used in place (hold = forever) and
+    copied (hold = 0).  Replaces the VAAPI -> host -> OpenCL copies of AvFrameSourceMapOpenCl.cpp:17-66."""
+    import ctypes
+    import torch
+    K, frames, _ = clip
+    n = 14
+    hip = _hip_runtime()
+    hip.hipMemGetHandleForAddressRange.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_ulonglong]
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    hip.hipGetErrorString.restype = ctypes.c_char_p
+    hip.hipGetErrorString.argtypes = [ctypes.c_int]
+    size = (frames[0].nbytes + 64 + (1 << 21) - 1) & ~((1 << 21) - 1)        # whole 2 MiB pages, planes at an offset of 64 bytes
+    bufs, fds = [], []
+    try:
+        for f in frames[:n]:
+            p = ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(p), size) == 0
+            bufs.append(p)
+            host = np.ascontiguousarray(f)
+            assert hip.hipMemcpy(ctypes.c_void_p(p.value + 64), host.ctypes.data_as(ctypes.c_void_p), host.nbytes, 1) == 0
+            fd = ctypes.c_int(-1)
+            e = hip.hipMemGetHandleForAddressRange(ctypes.byref(fd), p, size, 1, 0)   # hipMemRangeHandleTypeDmaBufFd
+            if e != 0:
+                pytest.skip("this box cannot export device memory as a DMA-BUF: " + hip.hipGetErrorString(e).decode())
+            fds.append(fd.value)
+        ref_stab, ref = run_product(vs, cuda, frames[:n], smooth_radius=3, seed=9)
+        for hold in (1 << 29, 0):
+            state = {"i": 0}
+
+            def fill(out, advance):
+                i = state["i"]
+                if i >= n:
+                    return vs.EOF
+                o = out.contents
+                o.mem, o.dmabuf_fd, o.dmabuf_size = 2, fds[i], size
+                o.y, o.uv = 64, 64 + W * H                   # byte offsets inside the object
+                o.pitch_y = o.pitch_uv = W
+                o.width, o.height, o.pts, o.hold, o.bit_depth = W, H, i, hold, 8
+                if advance:
+                    state["i"] += 1
+                return 0
+            pull, peek = vs.PULL_FN(lambda u, o: fill(o, True)), vs.PULL_FN(lambda u, o: fill(o, False))
+            src = vs.Source(pull, peek, None)
+            cfg = vs.default_config(smooth_radius=3, seed=9)
+            h = ctypes.c_void_p()
+            assert vs.lib.vstab_create(ctypes.byref(cfg), ctypes.byref(src), ctypes.byref(h)) == vs.OK, vs.lib.vstab_last_error()
+            ow, oh = ctypes.c_int(), ctypes.c_int()
+            assert vs.lib.vstab_get_output_info(h, ctypes.byref(ow), ctypes.byref(oh), None, None) == vs.OK
+            outs = []
+            while True:
+                o = torch.empty((oh.value, ow.value, 3), dtype=torch.uint8, device=cuda)
+                st = vs.lib.vstab_pull_frame(h, o.data_ptr(), o.stride(0))
+                if st == vs.EOF:
+                    break
+                assert st == vs.OK, vs.lib.vstab_last_error()
+                outs.append(o.cpu().numpy())
+            vs.lib.vstab_destroy(h)
+            assert len(outs) == len(ref) == n - 1
+            for i, (a, b) in enumerate(zip(outs, ref)):
+                assert np.array_equal(a, b), (hold, i)
+        # a frame whose planes do not fit in the object is refused, with a message
+        state = {"i": 0}
+
+        def bad(out, advance):
+            o = out.contents
+            o.mem, o.dmabuf_fd, o.dmabuf_size = 2, fds[0], size
+            o.y, o.uv, o.pitch_y, o.pitch_uv = 64, size - 16, W, W
+            o.width, o.height, o.hold, o.bit_depth = W, H, 0, 8
+            return 0
+        pull, peek = vs.PULL_FN(lambda u, o: bad(o, True)), vs.PULL_FN(lambda u, o: bad(o, False))
+        src = vs.Source(pull, peek, None)
+        cfg = vs.default_config(smooth_radius=3, seed=9)
+        h = ctypes.c_void_p()
+        assert vs.lib.vstab_create(ctypes.byref(cfg), ctypes.byref(src), ctypes.byref(h)) == vs.OK
+        ow, oh = ctypes.c_int(), ctypes.c_int()
+        vs.lib.vstab_get_output_info(h, ctypes.byref(ow), ctypes.byref(oh), None, None)
+        o = torch.empty((oh.value, ow.value, 3), dtype=torch.uint8, device=cuda)
+        assert vs.lib.vstab_pull_frame(h, o.data_ptr(), o.stride(0)) == vs.ERR_INVALID and b"DMA-BUF" in vs.lib.vstab_last_error()
+        vs.lib.vstab_destroy(h)
+    finally:
+        torch.cuda.synchronize()
+        for fd in fds:
+            os.close(fd)
+        for p in bufs:
+            hip.hipFree(p)
+
+
 def test_frame_lifetime_promise_hold(vs, cuda, clip):
     """vstab_frame.hold: a source that recycles one surface every pull (hold = 0, the default contract) and a source
     that keeps every frame alive (frames used in place, never copied) must produce the same stream."""

@@ -44,7 +44,7 @@ _u8p, _i64, _u64 = _c.POINTER(_c.c_ubyte), _c.c_int64, _c.c_uint64
 class Frame(_c.Structure):  # vstab_frame
     _fields_ = [("y", _vp), ("uv", _vp), ("pitch_y", _sz), ("pitch_uv", _sz), ("width", _i), ("height", _i),
                 ("mem", _i), ("pts", _i64), ("delta_rotation", _dp), ("bit_depth", _i), ("hold", _i),
-                ("readout_rotation", _dp)]
+                ("readout_rotation", _dp), ("dmabuf_fd", _i), ("dmabuf_size", _sz)]
 
 
 PULL_FN = _c.CFUNCTYPE(_i, _vp, _c.POINTER(Frame))

@@ -14,6 +14,9 @@
 #include <memory>
 #include <vector>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "vstab_geometry.hpp"
 #include "vstab_internal.hpp"
 #include "vstab_motion.hpp"
@@ -581,6 +584,7 @@ struct vstab_handle {
             if (e) (void)hipEventDestroy(e);
         for (hipStream_t s : {dstream, pstream, tstream2, tstream})
             if (s) (void)hipStreamDestroy(s);
+        for (auto &d : dmabufs) (void)hipDestroyExternalMemory(d.ext);
     }
     vstab_config cfg;
     vstab_source src;
@@ -770,6 +774,16 @@ struct vstab_handle {
     PinnedBuf marker_pts;           // vstab_config.debug: rotating sets of marker centres, read by the kernel in place
     unsigned marker_set = 0;
     hipStream_t dstream = nullptr;  // speculative corner detection (137 us of kernels every 21st frame) beside everything else
+    // DMA-BUF objects imported so far (vstab_frame.mem == VSTAB_MEM_DMABUF), keyed by the inode of the object
+    struct DmaBuf {
+        unsigned long long ino;
+        size_t size;
+        hipExternalMemory_t ext;
+        uint8_t *base;
+        long last_use;
+    };
+    std::vector<DmaBuf> dmabufs;
+    long dmabuf_clock = 0, dmabuf_imports = 0;
     bool chain_lk = true;        // VSTAB_CHAIN_LK=0 disables chained launches
     bool two_lk_streams = false; // VSTAB_LK_STREAMS=2 (development): chained launches alternate between two streams and every slot waits for
                                  // its own predecessor in the kernel -- measured slower than the stream-ordered chain
@@ -843,6 +857,59 @@ struct HostStage {
     explicit HostStage(double *s) : sum(s), t0(std::chrono::steady_clock::now()) {}
     ~HostStage() { *sum += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
+
+// mem == VSTAB_MEM_DMABUF: the planes are offsets into a DMA-BUF object (an exported decoder surface).  Import the object
+// once (objects are recognised by the inode of their fd: decoders hand the same pool of surfaces round and round, under
+// fds that may be closed and reused) and rewrite the frame as ordinary device memory.  This is the zero-copy stand-in for
+// AvFrameSourceMapOpenCl.cpp:17-66, which moves every frame VAAPI -> host -> OpenCL.
+static vstab_status resolve_dmabuf(vstab_handle *H, vstab_frame &f) {
+    if (f.mem != VSTAB_MEM_DMABUF) return VSTAB_OK;
+    const size_t off_y = reinterpret_cast<uintptr_t>(f.y), off_uv = reinterpret_cast<uintptr_t>(f.uv);
+    const size_t bps = f.bit_depth > 8 ? 2 : 1;
+    if (f.dmabuf_fd < 0 || f.dmabuf_size == 0 || f.height <= 0 || off_y + f.pitch_y * (size_t)f.height > f.dmabuf_size ||
+        off_uv + f.pitch_uv * (size_t)(f.height / 2) > f.dmabuf_size || f.pitch_y < (size_t)f.width * bps || f.pitch_uv < (size_t)f.width * bps)
+        return fail(VSTAB_ERR_INVALID, "vstab_frame: DMA-BUF planes do not fit in the object (fd, size, offsets, pitches)");
+    struct stat sb;
+    if (fstat(f.dmabuf_fd, &sb) != 0) return fail(VSTAB_ERR_INVALID, "vstab_frame: dmabuf_fd is not an open file descriptor");
+    vstab_handle::DmaBuf *hit = nullptr;
+    for (auto &d : H->dmabufs)
+        if (d.ino == (unsigned long long)sb.st_ino && d.size == f.dmabuf_size) hit = &d;
+    if (!hit) {
+        if (H->dmabufs.size() >= 256) {  // a pool larger than any decoder's: drop the entry used longest ago
+            size_t old = 0;
+            for (size_t i = 1; i < H->dmabufs.size(); i++)
+                if (H->dmabufs[i].last_use < H->dmabufs[old].last_use) old = i;
+            (void)hipDestroyExternalMemory(H->dmabufs[old].ext);
+            H->dmabufs.erase(H->dmabufs.begin() + (long)old);
+        }
+        const int fd = dup(f.dmabuf_fd);  // the import takes the descriptor it is given; the caller keeps its own
+        if (fd < 0) return fail(VSTAB_ERR_INVALID, "vstab_frame: cannot duplicate dmabuf_fd");
+        hipExternalMemoryHandleDesc hd;
+        std::memset(&hd, 0, sizeof(hd));
+        hd.type = hipExternalMemoryHandleTypeOpaqueFd, hd.handle.fd = fd, hd.size = f.dmabuf_size;
+        hipExternalMemory_t ext = nullptr;
+        hipError_t e = hipImportExternalMemory(&ext, &hd);
+        if (e != hipSuccess) {
+            (void)close(fd);
+            return fail(VSTAB_ERR_DEVICE, std::string("hipImportExternalMemory(DMA-BUF): ") + hipGetErrorString(e));
+        }
+        hipExternalMemoryBufferDesc bd;
+        std::memset(&bd, 0, sizeof(bd));
+        bd.offset = 0, bd.size = f.dmabuf_size;
+        void *base = nullptr;
+        e = hipExternalMemoryGetMappedBuffer(&base, ext, &bd);
+        if (e != hipSuccess || !base) {
+            (void)hipDestroyExternalMemory(ext);
+            return fail(VSTAB_ERR_DEVICE, std::string("hipExternalMemoryGetMappedBuffer(DMA-BUF): ") + hipGetErrorString(e));
+        }
+        H->dmabufs.push_back({(unsigned long long)sb.st_ino, f.dmabuf_size, ext, static_cast<uint8_t *>(base), 0});
+        hit = &H->dmabufs.back();
+        H->dmabuf_imports++;
+    }
+    hit->last_use = ++H->dmabuf_clock;
+    f.y = hit->base + off_y, f.uv = hit->base + off_uv, f.mem = VSTAB_MEM_DEVICE;
+    return VSTAB_OK;
+}
 
 static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
     GpuStage gs(H, vstab_handle::ST_INGEST);
@@ -955,6 +1022,7 @@ static vstab_status prefetch_next(vstab_handle *H) {
         H->src_eof = true, H->src_error = rc;
         return VSTAB_EOF;
     }
+    VSTAB_TRY(resolve_dmabuf(H, f));  // a DMA-BUF frame becomes an ordinary device frame here
     const int slot = H->acquire_slot();
     if (slot < 0) return fail(VSTAB_ERR_NOMEM, "look-ahead ring exhausted");
     {
