@@ -15,10 +15,13 @@ starts the N ranks itself (torch.distributed.run as a child process, before any 
 relays rank 0's line; under torch.distributed.run WORLD_SIZE must equal --gpus.
 
 Rank 0 prints ONE JSON line with the driver's contract plus
-  "roofline":     the fused undistort-remap kernel's algorithmic bytes / measured launch time
-                  (HIP events on the launch stream) against the 8 TB/s HBM peak, and
+  "roofline":     the fused undistort-remap kernel's algorithmic bytes / its average duration in the timed region --
+                  the kernel's own start / end stamps (hipExtLaunchKernelGGL events on its launch stream, every 8th
+                  launch; what rocprofv3's kernel trace reports) -- against the 8 TB/s HBM peak, and
   "cpu_baseline": the CPU oracle (a port of the reference's cvtColor -> createMap -> remap path)
-                  timed on a bounded sample on this host's cores, and
+                  timed on a bounded sample on this host's cores (all the box's share; "cpu_baseline_1_thread": one), and
+  "copy_ingest":  the same pipeline with every frame COPIED into the library's ring (vstab_frame.hold = 0, what a decoder
+                  that recycles its surface gives), measured after the timed region, and
   "cpu_baseline_full_pipeline": the oracle's whole consume_frame / pull_frame loop (detector, LK, smoothing, warp), and
   "parity_check": one frame emitted after the timed region compared bit for bit with the oracle's warp of the same input
                   frame under the rotation the pipeline reports for it (the run fails if they differ).
@@ -62,6 +65,12 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: initialise torch.distributed and run the collectives even with one rank (exercises the RCCL path on one GPU)")
+    ap.add_argument("--ingest", default="inplace", choices=["inplace", "copy"],
+                    help="inplace = upstream holds its frames (vstab_frame.hold), planes are read where they are, no pack kernel; "
+                         "copy = hold 0: every frame goes through vstab_pack_nv12 into the library's ring")
+    ap.add_argument("--map-precision", default="ieee", choices=["ieee", "opencl"],
+                    help="ieee = createMap.cl with every operation IEEE-rounded (CPU-reproducible, the default); opencl = the arithmetic of "
+                         "the reference's own kernel as ROCm's OpenCL compiler builds it for gfx950 (bit-identical to that code object)")
     ap.add_argument("--traffic", default=None, help="measured HBM bytes per launch from PMC passes (profiles/)")
     return ap.parse_args()
 
@@ -134,15 +143,19 @@ def shaky_ring(torch, dev, w, h, K, n, seed):
     return frames, rots
 
 
-def cpu_baseline(w, h, K, Ko, cw, ch, budget_s=10.0):
+def box_cpu_share():
+    """Threads the CPU legs may use: this rank's affinity mask, capped at the 16 CPUs a one-GPU box is given."""
+    return max(1, min(len(os.sched_getaffinity(0)), 16))
+
+
+def cpu_baseline(w, h, K, Ko, cw, ch, budget_s=10.0, threads=None):
     """The reference's CPU path (cvtColor -> createMap -> remap, FrameSourceWarp.cpp:401,272-314)
     as restated in oracle/vstab_oracle.c, timed on this host on a bounded sample of frames."""
     import oracle
     import synth
     frame = synth.nv12(0, w, h)
     p = oracle.map_params(K, Ko, np.eye(3))
-    # host share of a 1-GPU box is 16 CPUs: never oversubscribe beyond the affinity mask
-    threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    threads = box_cpu_share() if threads is None else threads
     oracle.lib().vo_set_num_threads(threads)
     oracle.warp_nv12(frame, p, cw, ch)  # warm
     n, t0 = 0, time.perf_counter()
@@ -163,7 +176,7 @@ def cpu_baseline_p010(frame16, w, h, K, Ko, cw, ch, budget_s=10.0):
     p = oracle.map_params(K, Ko, np.eye(3))
     rb = oracle.map_params(K, Ko, oracle.rodrigues((0.002, 0.001, -0.001)))[8:]
     y, uv = frame16[:h], frame16[h:]
-    threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    threads = box_cpu_share()
     oracle.lib().vo_set_num_threads(threads)
     oracle.warp_p010(y, uv, p, cw, ch, rb, 0, 1)
     n, t0 = 0, time.perf_counter()
@@ -180,7 +193,7 @@ def cpu_baseline_full(frames, K, Ko, cw, ch, w, h, budget_s=12.0):
     cvtColor -> createMap -> remap -- consume_frame / pull_frame of FrameSourceWarp.cpp:397-476 on frames copied back
     from the GPU ring.  The rotation estimate itself (a5, microseconds of fp64 work) is left out: identity rotations."""
     import oracle
-    threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    threads = box_cpu_share()
     oracle.lib().vo_set_num_threads(threads)
 
     def track(prev, cur, corners):
@@ -206,12 +219,7 @@ def cpu_baseline_full(frames, K, Ko, cw, ch, w, h, budget_s=12.0):
 def launch_ranks(args):
     """`bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child process (nothing in this process has
     touched the GPU), relay rank 0's JSON line and the exit code.  Model: concat.sh:248 (xargs -P N)."""
-    import torch
-    have = torch.cuda.device_count()  # does not initialise the GPU
-    if not args.share_gpu and have < args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but {have} GPU(s) visible (use --share-gpu --dist-backend gloo to rehearse ranks on one GPU)",
-              file=sys.stderr)
-        return 2
+    # (no device query here: the launcher stays provably free of the GPU runtime; a rank without a GPU exits 2 by itself)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -273,7 +281,8 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report {world} rank(s) as {args.gpus} GPUs", file=sys.stderr)
         return 2
     if not args.share_gpu and local >= torch.cuda.device_count():
-        print(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local}, {torch.cuda.device_count()} visible)", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus}: rank {rank} has no GPU (LOCAL_RANK {local}, {torch.cuda.device_count()} visible; "
+              "use --share-gpu --dist-backend gloo to rehearse ranks on one GPU)", file=sys.stderr)
         return 2
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -340,6 +349,11 @@ def main():
         Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
         return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * Kx
 
+    opencl = args.map_precision == "opencl"
+    if opencl and p010:
+        print("bench.py: --map-precision opencl exists for the 8-bit path", file=sys.stderr)
+        return 2
+    map_mode = vs.MAP_CREATEMAP_CL_OPENCL if opencl else vs.MAP_CREATEMAP_CL
     kernel_events = []
     preroll = 0
     n_warm, n_timed = args.warmup * args.batch, args.steps * args.batch  # frames
@@ -347,14 +361,12 @@ def main():
         params = [vs.map_params(K, Ko, rot(i)) for i in range((args.warmup + args.steps) * args.batch)]
 
         def step(i, timed):
-            if timed:
+            if timed and i % 8 == 0:   # the kernel's own start / end stamps (hipExtLaunchKernelGGL), every 8th launch
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-            vs.warp_nv12(ring[i % args.ring], params[i], cw, ch, vs.MAP_CREATEMAP_CL, vs.OUT_NV12 if nv12_out else vs.OUT_BGR8,
-                         out=outs[i % args.ring])
-            if timed:
-                e1.record(stream)
+                vs.time_next_launch(e0, e1)
                 kernel_events.append((e0, e1))
+            vs.warp_nv12(ring[i % args.ring], params[i], cw, ch, map_mode, vs.OUT_NV12 if nv12_out else vs.OUT_BGR8,
+                         out=outs[i % args.ring])
         workload = f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, fused undistort-remap (createMap+cvtColor+remap), per-frame rotation, tracking/smoothing NOT included"
     else:
         clip, _ = shaky_ring(torch, dev, w, h, K, args.ring, seed=rank)
@@ -370,8 +382,11 @@ def main():
             readouts = [np.eye(3) + 0.1 * (R - np.eye(3)) for R in readouts]
             readouts = [np.linalg.svd(R)[0] @ np.linalg.svd(R)[2] for R in readouts]   # back onto SO(3)
             extra = dict(bit_depth=10, readouts=readouts, pixel_depth=10, blend=vs.BLEND_FP16)
+        if opencl:
+            extra["map_precision"] = 1
+        ring_hold = 0 if args.ingest == "copy" else None
         stab = vs.Stabilizer(clip, total=preroll + (args.warmup + args.steps) * args.batch + 1000, preset=preset, smooth_radius=30, seed=1234 + rank,
-                             tracking=0 if args.no_tracking else 1, **extra)
+                             tracking=0 if args.no_tracking else 1, ring_hold=ring_hold, **extra)
         assert stab.out_size == (cw, ch)
 
         def step(i, timed):
@@ -383,9 +398,14 @@ def main():
         if p010:
             pull = lambda i: stab.pull_bgr16_into(outs[i % args.ring])
         stab.enable_profiling(1)  # timed region: HIP events around the warp launches only
-        workload = f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, full pipeline: NV12 ingest, corner detect, pyramidal LK, rotation estimate, SG smoothing (r=30), fused undistort-remap"
+        ingest_txt = ("frames used in place (upstream holds them: vstab_frame.hold), no pack kernel" if args.ingest == "inplace"
+                      else "every frame copied into the library's ring (vstab_frame.hold = 0: vstab_pack_nv12)")
+        prec_txt = ", map in the OpenCL build's arithmetic (--map-precision opencl)" if opencl else ""
+        workload = (f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, full pipeline: {ingest_txt}; corner detect, pyramidal LK, rotation estimate, "
+                    f"SG smoothing (r=30), fused undistort-remap{prec_txt}")
         if args.no_tracking:
-            workload = f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, undistort only (tracking off, identity rotations): NV12 ingest + fused undistort-remap"
+            workload = (f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, undistort only (tracking off, identity rotations): {ingest_txt}; "
+                        f"fused undistort-remap from the map written once{prec_txt}")
         if p010:
             workload = (f"4k P010 {w}x{h} -> BGR 16-bit (10 significant) {cw}x{ch}, BASELINE config 5: full pipeline on the narrowed luma (corner detect, "
                         "pyramidal LK, rotation estimate, SG r=30), 10-bit undistort-remap with fp16 blend and a rotation per output row")
@@ -426,9 +446,14 @@ def main():
             rb = oracle.map_params(K, Ko, readouts[(n_emit + 1) % len(clip)] @ stab.warp_rotation(n_emit))[8:]
             s16 = src.view(np.uint16)
             same = np.array_equal(got.cpu().numpy().view(np.uint16), oracle.warp_p010(s16[:h], s16[h:], pr, cw, ch, rb, 0, 1))
-        elif nv12_out:
+        elif nv12_out and not opencl:
             exp_y, exp_uv = oracle.warp_nv12_ex(src, pr, cw, ch, 0, 1)
             same = np.array_equal(got[0].cpu().numpy().reshape(-1), exp_y.reshape(-1)) and np.array_equal(got[1].cpu().numpy().reshape(-1), exp_uv.reshape(-1))
+        elif opencl:
+            # the checker of this mode is the reference's own kernel (oracle/_ref/createMap.gfx950.co) run on this GPU, then
+            # the oracle's cvtColor and cv::remap
+            rx, ry = oracle.create_map_ref_gfx950(pr, cw, ch)
+            same = np.array_equal(got.cpu().numpy(), oracle.remap_bilinear(oracle.cvt_nv12_bgr(src), rx, ry))
         else:
             same = np.array_equal(got.cpu().numpy(), oracle.warp_nv12(src, pr, cw, ch))
         parity = "ok" if same else "MISMATCH"
@@ -453,7 +478,7 @@ def main():
         if mode == "pipeline":
             p1, p0 = stab.profile(), stab._prof0
             d = {k: p1[k] - p0[k] for k in p1}
-            avg_ms = d["gpu_warp_ms"] / max(1, d["warp_timed"])  # HIP events around every 8th warp launch, on its stream
+            avg_ms = d["gpu_warp_ms"] / max(1, d["warp_timed"])  # every 8th warp launch: the kernel's own start / end stamps
             stages = {k: round(v / max(1, d["frames_emitted"]) * 1e3, 2) for k, v in d.items() if k.endswith("_ms")}
             stages = {k.replace("_ms", "_us_per_frame"): v for k, v in stages.items()}
             stages["key_frames"] = int(d["key_frames"])
@@ -470,12 +495,12 @@ def main():
             stages = {k.replace("_ms", "_us_per_frame"): round(v / max(1, dq["frames_emitted"]) * 1e3, 2) for k, v in dq.items() if k.endswith("_ms")}
             stages["key_frames_per_120"] = int(dq["key_frames"])
         # the same kernel with nothing beside it (no tracker / pyramid / detection kernels on other streams): back-to-back
-        # launches on this stream bracketed by one event pair -- the figure that isolates kernel quality from co-scheduling
-        alone_us = None
+        # launches on this stream, every launch with its own start / end stamps -- the figure that isolates kernel quality
+        # from co-scheduling
+        alone_us, copy_ingest = None, None
         if mode == "pipeline":
             pa = vs.map_params(K, Ko, rot(7))
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            run_alone = lambda i: vs.warp_nv12(clip[i % len(clip)], pa, cw, ch, vs.MAP_CREATEMAP_CL, vs.OUT_NV12 if nv12_out else vs.OUT_BGR8,
+            run_alone = lambda i: vs.warp_nv12(clip[i % len(clip)], pa, cw, ch, map_mode, vs.OUT_NV12 if nv12_out else vs.OUT_BGR8,
                                                out=outs[i % args.ring])  # cycling inputs and outputs: nothing stays in the caches
             if p010:
                 pb = vs.map_params(K, Ko, rot(8))[8:]
@@ -484,12 +509,29 @@ def main():
             for i in range(10):
                 run_alone(i)
             torch.cuda.synchronize()
-            e0.record(stream)
-            for i in range(100):
+            pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
+            for i, (a, b) in enumerate(pairs):
+                vs.time_next_launch(a, b)
                 run_alone(10 + i)
-            e1.record(stream)
             torch.cuda.synchronize()
-            alone_us = e0.elapsed_time(e1) / 100 * 1e3
+            alone_us = float(np.mean([a.elapsed_time(b) for a, b in pairs])) * 1e3
+            if args.ingest == "inplace" and not p010 and world == 1:
+                # what a decoder that recycles its surface gives: hold = 0, every frame through vstab_pack_nv12 into the ring
+                # (untimed region; a short run of its own: pre-roll 200 frames, 10 batches)
+                cstab = vs.Stabilizer(clip, total=200 + 10 * args.batch + 100, preset=preset, smooth_radius=30, seed=1234 + rank,
+                                      tracking=0 if args.no_tracking else 1, ring_hold=0, **extra)
+                cpull = (lambda i: cstab.pull_nv12_into(*outs[i % args.ring])) if nv12_out else (lambda i: cstab.pull_into(outs[i % args.ring]))
+                for i in range(200):
+                    assert cpull(i)
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+                for i in range(10 * args.batch):
+                    assert cpull(i)
+                torch.cuda.synchronize()
+                copy_ingest = {"value": round(10 * args.batch / (time.perf_counter() - tc), 1), "unit": "frames/s",
+                               "what": "the same pipeline with vstab_frame.hold = 0: every frame copied into the library's ring by vstab_pack_nv12 "
+                                       f"(+{int(w * h * 3)} B of traffic and one kernel per frame); {10 * args.batch} frames after a 200-frame pre-roll, untimed region"}
+                cstab.close()
         alg_bytes = w * h * 1.5 + cw * ch * 3  # NV12 read once + BGR8 written once
         if nv12_out:
             alg_bytes = w * h * 1.5 + cw * ch + 2 * ((cw + 1) // 2) * ((ch + 1) // 2)
@@ -505,15 +547,16 @@ def main():
             kernel_name = "k_warp_fused<CACHED> (reads the quantised map)"
             alg_bytes += ((cw + 3) // 4 * 4) * ch * 8
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms else None
-        traffic, rocprof_us, valu_busy = None, None, None
-        if args.traffic:
-            traffic = float(args.traffic)
-        else:
-            tf = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-            if os.path.exists(tf) and not nv12_out and not cached and not p010:
-                prof = json.load(open(tf))
-                traffic, rocprof_us = prof.get("hbm_bytes_per_launch"), prof.get("rocprof_avg_launch_us")
-                valu_busy = prof.get("valu_busy")  # SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x launch time x shader clock), same PMC passes
+        # HBM traffic needs PMC passes under rocprofv3 (tools/prof_bench.sh); what this line can carry is the COMMITTED figure
+        # of the same command (profiles/), named as such -- "traffic" itself is only set when the caller passes a measurement
+        traffic = float(args.traffic) if args.traffic else None
+        committed = None
+        tf = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+        if os.path.exists(tf) and not nv12_out and not cached and not p010 and not opencl:
+            prof = json.load(open(tf))
+            committed = {"traffic_bytes_per_launch": prof.get("hbm_bytes_per_launch"), "rocprof_avg_launch_us": prof.get("rocprof_avg_launch_us"),
+                         "valu_busy": prof.get("valu_busy"), "source": f"profiles/traffic_{args.workload}.json ({prof.get('round', 'r02')}: separate rocprofv3 "
+                                                                         "--kernel-trace / --pmc passes of this command on another box)"}
         line = {
             "metric": "stabilized frames/sec at 4K NV12, 1/2/4/8 GPU; remap % HBM roofline",
             "value": round(world * n_timed / el, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -522,18 +565,22 @@ def main():
             "config": {"workload": workload, "mode": mode, "clips": len(records), "ring_frames": args.ring, "frames_per_step": args.batch,
                        "preset": "GOPRO_H4B_WIDE169_MEASURED", "parallelism": f"clip-per-gpu x{world}"},
             "preroll": preroll, "parity_check": parity, "rank_cpus": pinned,
+            "collectives": args.dist_backend if use_dist else None,
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
+                         # kernel time in the timed region: the kernel's own start / end stamps (hipExtLaunchKernelGGL events on the
+                         # launch stream), averaged over the launches timed -- the quantity rocprofv3 --kernel-trace reports
                          "avg_launch_us": round(avg_ms * 1e3, 2) if avg_ms else None,
-                         # the committed rocprofv3 --kernel-trace average of the same command (profiles/), for comparison:
-                         # the HIP-event bracket also counts dispatch latency while other streams' kernels hold the CUs
-                         "rocprof_avg_launch_us_committed": rocprof_us, "valu_busy": valu_busy,
+                         "timing": "kernel start/end stamps (hipExtLaunchKernelGGL) of every 8th launch in the timed region",
+                         "committed_profile": committed,
                          "alone": None if alone_us is None else {"avg_launch_us": round(alone_us, 2),
                                                                    "kernel": "k_warp_p010" if p010 else "k_warp_fused",
                                                                    "achieved": round(base_bytes / alone_us / 1e3, 1),
                                                                    "frac": round(base_bytes / alone_us / 1e3 / HBM_PEAK_GBS, 4)}},
         }
+        if copy_ingest:
+            line["copy_ingest"] = copy_ingest
         if stages:
             line["stages"] = stages  # every GPU stage timed (extra pass outside the timed region; chained LK launches off)
             line["stages_timed_region"] = timed_stages  # host waits + warp launches as they were in the timed region
@@ -541,6 +588,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline_p010(clip[0].cpu().numpy().view(np.uint16), w, h, K, Ko, cw, ch)
         elif world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, h, K, Ko, cw, ch)
+            line["cpu_baseline_1_thread"] = cpu_baseline(w, h, K, Ko, cw, ch, budget_s=6.0, threads=1)
             if mode == "pipeline" and not args.no_tracking:
                 host_ring = [f.cpu().numpy() for f in clip]
                 host_frames = [host_ring[i % len(host_ring)] for i in range(400)]  # bounded by the time budget inside

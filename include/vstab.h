@@ -377,7 +377,11 @@ typedef struct vstab_config {
                             the narrowed luma exactly as in the 8-bit path, the frame is warped from the 16-bit planes with
                             vstab_warp_p010 and emitted by vstab_pull_frame_bgr16. */
     int blend;           /* pixel_depth 10: VSTAB_BLEND_EXACT (default) or VSTAB_BLEND_FP16 */
+    int map_precision;   /* lens_mode 0: VSTAB_MAP_PRECISION_IEEE (default; createMap.cl with every operation IEEE-rounded,
+                            reproducible by a CPU) or VSTAB_MAP_PRECISION_OPENCL (VSTAB_MAP_CREATEMAP_CL_OPENCL: the arithmetic the
+                            reference's own kernel has on this GPU; frames with a readout_rotation are refused in this mode) */
 } vstab_config;
+enum { VSTAB_MAP_PRECISION_IEEE = 0, VSTAB_MAP_PRECISION_OPENCL = 1 };
 
 typedef struct vstab_handle vstab_handle;
 
@@ -443,6 +447,12 @@ VSTAB_API vstab_status vstab_enable_profiling(vstab_handle *h, int level);
 /* Synchronises the stream, folds all pending event pairs into the sums and returns them. */
 VSTAB_API vstab_status vstab_get_profile(vstab_handle *h, vstab_profile *out);
 
+/* Profiling aid for the stateless warp operators (vstab_warp_nv12_*, vstab_warp_p010): the NEXT such call on this thread
+ * launches its kernel with hipExtLaunchKernelGGL and the two events (hipEvent_t with timing enabled, owned by the caller),
+ * which then hold the kernel's own start and end -- the duration rocprofv3's kernel trace reports, without launch gaps.
+ * One-shot; a call that launches no such kernel leaves the request pending. */
+VSTAB_API void vstab_time_next_launch(void *start_event, void *stop_event);
+
 /* Utility upstream source for benchmarks and tests: cycles over n_frames caller-owned device
  * frames (packed NV12, same size) for total_frames pulls, then reports EOF.  Plays the role of
  * the decode chain upstream of FrameSourceWarp (DisplayImage.cpp:42-53), which is out of scope. */
@@ -456,6 +466,10 @@ VSTAB_API vstab_status vstab_ring_source_create_ex(const void *const *frames, in
                                                    size_t pitch, long total_frames, int bit_depth,
                                                    const double *readout_rotations, vstab_ring_source **out,
                                                    vstab_source *as_source);
+/* vstab_frame.hold the source reports for every frame.  Default 1 << 30: the frames belong to the caller for the life of the
+ * source and are used in place, nothing is copied.  0 = the contract of a decoder that recycles its output surface: every
+ * frame is copied into the library's ring (vstab_pack_nv12) before the next callback. */
+VSTAB_API void vstab_ring_source_set_hold(vstab_ring_source *s, int hold);
 VSTAB_API void vstab_ring_source_destroy(vstab_ring_source *s);
 
 #ifdef __cplusplus

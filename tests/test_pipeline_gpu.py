@@ -881,3 +881,26 @@ def test_bench_launches_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["preroll"] == 40 and line["parity_check"] == "ok" and line["scaling"] == "weak"
     assert line["roofline"]["kernel"] == "k_warp_fused" and line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_rccl_branch_runs_on_one_rank():
+    """The `nccl` (= RCCL) branch of bench.py and shard.gather_records, executed for real: one rank on this GPU with
+    --force-dist, so the communicator is created, the barriers, the MAX all-reduce of the timing and the all-gather of the
+    per-clip records all run through RCCL.  The 1 -> 8 curve is the driver's to measure (concat.sh:248
+    is the model: independent clips, one per GPU); this only proves the branch executes and leaves stdout clean."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--workload", "1080p",
+                        "--steps", "2", "--batch", "8", "--preroll", "40", "--ring", "16", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout   # RCCL's banner goes to stderr, stdout is the one JSON line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["parity_check"] == "ok" and line["config"]["clips"] == 1 and line["value"] > 0
+    assert line["collectives"] == "nccl"

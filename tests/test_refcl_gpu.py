@@ -189,3 +189,38 @@ def test_x86_cross_check_build_vs_the_gfx950_build_of_the_same_kernel(refcl, cud
                 rel = np.abs(g - r)[ok] / (np.abs(g[ok]) + abs(float(centre)))
                 worst = max(worst, float(rel.max()) * 2 ** 23)
     assert worst <= 6.0, worst
+
+
+def test_pipeline_object_in_opencl_map_precision(refcl, vs, cuda):
+    """vstab_config.map_precision = OPENCL: the pipeline's decisions and rotations are those of the default handle (the
+    tracker does not see the map), and every emitted frame is cvtColor -> the REFERENCE kernel's map (on this GPU) ->
+    cv::remap of the frame it warps, under the rotation the handle reports."""
+    import torch
+    w, h = 640, 360
+    K = oracle.get_preset_camera(oracle.GOPRO_H4B_WIDE169_MEASURED, w, h)
+    Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
+    frames, _ = synth.shaky_clip(2, K, w, h, 14, sigma=0.004)
+    dev_frames = [torch.from_numpy(f).to(cuda) for f in frames]
+    outs = {}
+    for prec in (0, 1):
+        stab = vs.Stabilizer(dev_frames, total=len(frames), smooth_radius=3, seed=3, map_precision=prec)
+        got = []
+        while True:
+            o = stab.pull()
+            if o is None:
+                break
+            got.append(o.cpu().numpy())
+        outs[prec] = (got, [stab.warp_rotation(i) for i in range(len(got))], stab.frame_log())
+        stab.close()
+    (g0, r0, l0), (g1, r1, l1) = outs[0], outs[1]
+    assert len(g0) == len(g1) == len(frames) - 1
+    assert all(np.array_equal(a, b) for a, b in zip(r0, r1)) and [x["inliers"] for x in l0] == [x["inliers"] for x in l1]
+    differ = 0
+    for i, (img, R) in enumerate(zip(g1, r1)):
+        p = oracle.map_params(K, Ko, R)
+        rx, ry = refcl(p, cw, ch)
+        assert np.array_equal(img, oracle.remap_bilinear(oracle.cvt_nv12_bgr(frames[i + 1]), rx, ry)), i
+        differ += int((img != g0[i]).sum())
+    assert differ > 0   # the two precisions are different maps (a few bytes per frame), not the same mode twice
+    with pytest.raises(vs.VstabError):
+        vs.Stabilizer(dev_frames, total=4, smooth_radius=1, map_precision=1, pixel_depth=10)

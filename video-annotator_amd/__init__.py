@@ -59,7 +59,7 @@ class Config(_c.Structure):  # vstab_config
                 ("interpolation", _i), ("smoother", _i), ("tracking", _i), ("seed", _u64), ("stream", _vp),
                 ("lens_mode", _i), ("in_projection", _i), ("out_projection", _i), ("in_dfov", _d), ("out_dfov", _d),
                 ("out_width", _i), ("out_height", _i), ("out_cx", _d), ("out_cy", _d), ("debug", _i), ("pixel_depth", _i),
-                ("blend", _i)]
+                ("blend", _i), ("map_precision", _i)]
 
 
 class FrameLog(_c.Structure):  # vstab_frame_log
@@ -111,6 +111,7 @@ SIGNATURES = {
     "vstab_good_features_ex": (_i, [_vp, _sz, _i, _i, _i, _d, _d, _i, _fp, _ip, _ip, _vp]),
     "vstab_pyr_lk": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _fp, _u8p, _vp]),
     "vstab_estimate_rotation": (_i, [_fp, _fp, _i, _dp, _dp, _u64, _dp, _ip]),
+    "vstab_time_next_launch": (None, [_vp, _vp]),
     "vstab_sg_weights": (_i, [_i, _dp]),
     "vstab_gyro_integrate": (_i, [_vp, _i, _d, _d, _d, _d, _dp, _dp]),
     "vstab_rotation_filter_create": (_i, [_i, _pp]),
@@ -133,6 +134,7 @@ SIGNATURES = {
     "vstab_get_profile": (_i, [_vp, _c.POINTER(Profile)]),
     "vstab_ring_source_create": (_i, [_pp, _i, _i, _i, _sz, _c.c_long, _pp, _c.POINTER(Source)]),
     "vstab_ring_source_create_ex": (_i, [_c.POINTER(_vp), _i, _i, _i, _sz, _c.c_long, _i, _dp, _c.POINTER(_vp), _c.POINTER(Source)]),
+    "vstab_ring_source_set_hold": (None, [_vp, _i]),
     "vstab_ring_source_destroy": (None, [_vp]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
@@ -366,6 +368,15 @@ def warp_p010(y, uv, params, dw, dh, rot_bottom=None, mode=MAP_CREATEMAP_CL, ble
     return out
 
 
+def time_next_launch(start_event, stop_event):
+    """The next stateless warp call stamps its kernel's own start / end into the two torch.cuda.Event(enable_timing=True):
+    kernel-only time, as rocprofv3's kernel trace reports it."""
+    for e in (start_event, stop_event):
+        if not e.cuda_event:   # torch creates the hipEvent_t lazily, at the first record
+            e.record()
+    _L.vstab_time_next_launch(_c.c_void_p(start_event.cuda_event), _c.c_void_p(stop_event.cuda_event))
+
+
 def quantised_map(params, dw, dh, mode=MAP_CREATEMAP_CL, device="cuda"):
     """The per-pixel quantised map for a run of frames with the same warp parameters -> opaque device tensor."""
     import torch
@@ -506,11 +517,12 @@ class Stabilizer:
     """vstab_handle wrapper.  `frames`: list of packed NV12 CUDA tensors (cycled by the C ring
     source for `total` pulls) or a Python iterable of such tensors (python callback source)."""
 
-    def __init__(self, frames, total=None, use_torch_stream=True, hold=12, bit_depth=8, readouts=None, **cfg_kw):
+    def __init__(self, frames, total=None, use_torch_stream=True, hold=12, bit_depth=8, readouts=None, ring_hold=None, **cfg_kw):
         """hold (iterable sources): vstab_frame.hold -- how many further pulls each tensor is kept alive and unchanged
         for; from smooth_radius + 14 on the library uses the tensors in place instead of copying them.
         bit_depth / readouts (list sources): P010 frames as int16 tensors of shape (h * 3 / 2, w); one 3x3 read-out
-        rotation per ring frame (vstab_frame.readout_rotation)."""
+        rotation per ring frame (vstab_frame.readout_rotation).  ring_hold (list sources): the hold the ring source
+        promises (default: forever, frames used in place; 0: every frame is copied into the library's ring)."""
         import torch
         self._keep = []
         self._src = Source()
@@ -527,6 +539,8 @@ class Stabilizer:
             _check(_L.vstab_ring_source_create_ex(ptrs, len(frames), w, h, f0.stride(0) * f0.element_size(), len(frames) if total is None else total,
                                                   int(bit_depth), None if ro is None else _dptr(ro), _c.byref(self._ring), _c.byref(self._src)),
                    "vstab_ring_source_create_ex")
+            if ring_hold is not None:
+                _L.vstab_ring_source_set_hold(self._ring, int(ring_hold))
         else:
             it = iter(frames)
             state = {"next": None, "done": False}

@@ -15,6 +15,15 @@ namespace vstab {
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
 
+static thread_local LaunchEvents g_launch_events;
+void set_launch_events(hipEvent_t start, hipEvent_t stop) { g_launch_events = {start, stop}; }
+LaunchEvents take_launch_events() {
+    const LaunchEvents e = g_launch_events;
+    g_launch_events = LaunchEvents();
+    return e;
+}
+bool launch_events_pending() { return g_launch_events.start != nullptr; }
+
 // FrameSourceWarp.cpp:22-25: the published FOVs are stored in `const int`, dropping the fraction.
 static const int FOV_H_43W = (int)122.6, FOV_V_43W = (int)94.4, FOV_H_169W = (int)118.2, FOV_V_169W = (int)69.5;
 
@@ -192,3 +201,7 @@ void vstab_map_params(const double K_in[9], const double K_out[9], const double 
 }
 
 }  // extern "C"
+
+extern "C" void vstab_time_next_launch(void *start_event, void *stop_event) {
+    vstab::set_launch_events(static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event));
+}

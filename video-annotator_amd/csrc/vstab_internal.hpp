@@ -25,6 +25,16 @@ inline vstab_status fail(vstab_status st, const std::string &msg) {
 
 inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
+// One-shot event pair for the NEXT hot-kernel launch on this thread: the launcher hands it to hipExtLaunchKernelGGL, which
+// stamps the kernel's own start and end (what rocprofv3's kernel trace reports) instead of the stream positions around the
+// launch call, whose interval also holds the dispatch wait behind other streams' kernels.  take_launch_events() clears it.
+struct LaunchEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+void set_launch_events(hipEvent_t start, hipEvent_t stop);
+LaunchEvents take_launch_events();
+bool launch_events_pending();
+
 // vstab_pack_p010 with a choice of planes (vstab_warp.hip): luma_only narrows the luma plane alone -- what the 10-bit
 // pipeline needs for its tracker
 vstab_status pack_p010_planes(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width, int height, void *dst, bool luma_only,

@@ -807,25 +807,37 @@ struct vstab_handle {
 
 struct GpuStage {  // records an event pair around a stage when profiling is on
     vstab_handle *H;
-    hipEvent_t a = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
     int stage;
     hipStream_t s;
     GpuStage(vstab_handle *h, int st)
         : H(h), stage(st), s(st == vstab_handle::ST_WARP ? h->stream : (st == vstab_handle::ST_INGEST || st == vstab_handle::ST_PYRAMID) ? h->pstream : h->tstream) {
         // level 1 times every 8th warp launch: two event records cost more host time than the launch itself
         if (H->profiling >= 2 || (H->profiling == 1 && st == vstab_handle::ST_WARP && (H->prof.warp_launches & 7) == 0)) {
-            if (st == vstab_handle::ST_WARP) H->prof.warp_timed++;
             a = H->get_event();
-            (void)hipEventRecord(a, s);
+            if (st == vstab_handle::ST_WARP) {
+                // the warp launcher stamps the kernel's own start and end into the pair (hipExtLaunchKernelGGL): kernel
+                // time as rocprofv3 reports it, without the dispatch wait behind the other streams' kernels
+                H->prof.warp_timed++;
+                b = H->get_event();
+                set_launch_events(a, b);
+            } else {
+                (void)hipEventRecord(a, s);
+            }
         }
     }
     ~GpuStage() {
-        if (a) {
-            hipEvent_t b = H->get_event();
+        if (!a) return;
+        if (b && launch_events_pending()) {  // a warp path that does not take the pair (10-bit, direct gather): stream positions
+            (void)take_launch_events();
+            (void)hipEventRecord(a, s);  // (late: such a launch is then timed as ~0; only the fused kernel is the metric's)
             (void)hipEventRecord(b, s);
-            H->pending.push_back({a, b, stage});
-            if (H->pending.size() > 4096) H->fold_pending();
+        } else if (!b) {
+            b = H->get_event();
+            (void)hipEventRecord(b, s);
         }
+        H->pending.push_back({a, b, stage});
+        if (H->pending.size() > 4096) H->fold_pending();
     }
 };
 // VSTAB_HOST_TIMING=1: wall time of the host-side steps of the pull loop, printed by vstab_destroy (development aid)
@@ -1272,7 +1284,7 @@ void vstab_config_default(vstab_config *cfg) {
     cfg->interpolation = 1, cfg->smoother = VSTAB_SMOOTHER_SG, cfg->tracking = 1, cfg->seed = 1, cfg->stream = nullptr;
     cfg->lens_mode = 0, cfg->in_projection = VSTAB_PROJ_FISH, cfg->out_projection = VSTAB_PROJ_RECT;
     cfg->in_dfov = 0, cfg->out_dfov = 0, cfg->out_width = 0, cfg->out_height = 0, cfg->out_cx = -1, cfg->out_cy = -1, cfg->debug = 0;
-    cfg->pixel_depth = 8, cfg->blend = VSTAB_BLEND_EXACT;
+    cfg->pixel_depth = 8, cfg->blend = VSTAB_BLEND_EXACT, cfg->map_precision = VSTAB_MAP_PRECISION_IEEE;
 }
 
 vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vstab_handle **out) {
@@ -1284,6 +1296,10 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (cfg->lens_mode != 0 && cfg->lens_mode != 1) return fail(VSTAB_ERR_INVALID, "vstab_create: lens_mode must be 0 or 1");
     if (cfg->pixel_depth != 0 && cfg->pixel_depth != 8 && cfg->pixel_depth != 10) return fail(VSTAB_ERR_INVALID, "vstab_create: pixel_depth must be 8 or 10");
     if (cfg->blend != VSTAB_BLEND_EXACT && cfg->blend != VSTAB_BLEND_FP16) return fail(VSTAB_ERR_INVALID, "vstab_create: unknown blend");
+    if (cfg->map_precision != VSTAB_MAP_PRECISION_IEEE && cfg->map_precision != VSTAB_MAP_PRECISION_OPENCL)
+        return fail(VSTAB_ERR_INVALID, "vstab_create: unknown map_precision");
+    if (cfg->map_precision == VSTAB_MAP_PRECISION_OPENCL && (cfg->lens_mode != 0 || cfg->pixel_depth == 10))
+        return fail(VSTAB_ERR_INVALID, "vstab_create: map_precision OPENCL exists for the reference's own map (lens_mode 0, 8-bit pixels)");
     std::unique_ptr<vstab_handle> H(new vstab_handle);
     H->cfg = *cfg, H->src = *src;
     H->rng = Pcg32(cfg->seed);
@@ -1322,6 +1338,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (cfg->lens_mode == 0) {
         if (!preset_camera(cfg->preset, H->w, H->h, H->Kin)) return fail(VSTAB_ERR_INVALID, "vstab_create: unknown preset");
         output_camera(H->Kin, H->w, H->h, cfg->scale, cfg->crop_borders != 0, cfg->zoom, H->Kout, H->ow, H->oh);
+        if (cfg->map_precision == VSTAB_MAP_PRECISION_OPENCL) H->map_mode = VSTAB_MAP_CREATEMAP_CL_OPENCL;
     } else {
         // the libdewobble filter options as the CLI sets them (render.ts:669-683)
         H->ow = cfg->out_width > 0 ? cfg->out_width : H->w, H->oh = cfg->out_height > 0 ? cfg->out_height : H->h;
@@ -1599,6 +1616,7 @@ struct vstab_ring_source {
     size_t pitch;
     long total, pos;
     int bit_depth = 8;
+    int hold = 1 << 30;  // what the source promises: by default the caller owns the frames for the life of the source and never rewrites them
     std::vector<double> readout;  // optional: 9 doubles per ring frame (vstab_frame.readout_rotation)
 };
 
@@ -1607,7 +1625,7 @@ static int ring_fill(vstab_ring_source *s, vstab_frame *out) {
     const uint8_t *p = static_cast<const uint8_t *>(s->frames[(size_t)(s->pos % (long)s->frames.size())]);
     out->y = p, out->uv = p + s->pitch * s->h, out->pitch_y = out->pitch_uv = s->pitch;
     out->width = s->w, out->height = s->h, out->mem = 0, out->pts = s->pos;
-    out->hold = 1 << 30;  // the caller owns the frames for the life of the source and never rewrites them
+    out->hold = s->hold;
     out->bit_depth = s->bit_depth;
     if (!s->readout.empty()) out->readout_rotation = &s->readout[9 * (size_t)(s->pos % (long)s->frames.size())];
     return 0;
@@ -1619,6 +1637,10 @@ static int ring_pull(void *user, vstab_frame *out) {
     return rc;
 }
 static int ring_peek(void *user, vstab_frame *out) { return ring_fill(static_cast<vstab_ring_source *>(user), out); }
+
+void vstab_ring_source_set_hold(vstab_ring_source *s, int hold) {
+    if (s) s->hold = hold < 0 ? 0 : hold;
+}
 
 vstab_status vstab_ring_source_create(const void *const *frames, int n_frames, int width, int height, size_t pitch,
                                       long total_frames, vstab_ring_source **out, vstab_source *as_source) {

@@ -28,6 +28,8 @@
 #include <cmath>
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "vstab_device.hpp"
 #include "vstab_internal.hpp"
 #include "vstab_warp_args.hpp"
@@ -761,7 +763,13 @@ vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int ma
         share = std::max(share, n);
     }
     const dim3 grid(8u * (unsigned)share);
-#define VSTAB_LAUNCH(R, M, F, C) hipLaunchKernelGGL((k_warp_fused<R, M, F, C>), grid, dim3(256), lds_bytes, st, ta)
+    // a profiling caller may have left an event pair for this launch: the kernel's own start / end stamps
+    const LaunchEvents ev = take_launch_events();
+#define VSTAB_LAUNCH(R, M, F, C)                                                                                            \
+    do {                                                                                                                    \
+        if (ev.start) hipExtLaunchKernelGGL((k_warp_fused<R, M, F, C>), grid, dim3(256), lds_bytes, st, ev.start, ev.stop, 0, ta); \
+        else hipLaunchKernelGGL((k_warp_fused<R, M, F, C>), grid, dim3(256), lds_bytes, st, ta);                              \
+    } while (0)
 #define VSTAB_LAUNCH_RF(M, C)                                  \
     do {                                                       \
         if (rwb == 8 && !nv12_out) VSTAB_LAUNCH(8, M, 0, C);   \

@@ -12,6 +12,8 @@
 //     within 2 levels of the exact one
 //   BGR, three 16-bit samples per pixel, values 0..1023.
 // Direct gather, two output pixels per thread: this path is about the format, the 8-bit kernel carries the rate.
+#include <hip/hip_ext.h>
+
 #include "vstab_device.hpp"
 #include "vstab_internal.hpp"
 
@@ -175,11 +177,15 @@ extern "C" vstab_status vstab_warp_p010(const void *y, size_t pitch_y, const voi
     a.rs_den = (float)(dh > 1 ? dh - 1 : 1);
     const dim3 grid(div_up(dw, 64), div_up(dh, 8));  // 64 columns x 4 pairs of rows per workgroup
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define VSTAB_LAUNCH(M)                                                                  \
-    if (blend == VSTAB_BLEND_FP16)                                                       \
-        hipLaunchKernelGGL((k_warp_p010<M, VSTAB_BLEND_FP16>), grid, dim3(256), 0, s, a); \
-    else                                                                                 \
-        hipLaunchKernelGGL((k_warp_p010<M, VSTAB_BLEND_EXACT>), grid, dim3(256), 0, s, a)
+    const LaunchEvents ev = take_launch_events();  // a profiling caller's pair: the kernel's own start / end stamps
+#define VSTAB_LAUNCH_B(M, B)                                                                                   \
+    do {                                                                                                       \
+        if (ev.start) hipExtLaunchKernelGGL((k_warp_p010<M, B>), grid, dim3(256), 0, s, ev.start, ev.stop, 0, a); \
+        else hipLaunchKernelGGL((k_warp_p010<M, B>), grid, dim3(256), 0, s, a);                                  \
+    } while (0)
+#define VSTAB_LAUNCH(M)                                              \
+    if (blend == VSTAB_BLEND_FP16) VSTAB_LAUNCH_B(M, VSTAB_BLEND_FP16); \
+    else VSTAB_LAUNCH_B(M, VSTAB_BLEND_EXACT)
     switch (map_mode) {
         case VSTAB_MAP_CREATEMAP_CL: VSTAB_LAUNCH(MAP_CREATEMAP_CL); break;
         case VSTAB_MAP_FISH_TO_RECT: VSTAB_LAUNCH(MAP_FISH_TO_RECT); break;
@@ -188,6 +194,7 @@ extern "C" vstab_status vstab_warp_p010(const void *y, size_t pitch_y, const voi
         default: VSTAB_LAUNCH(MAP_RECT_TO_FISH); break;
     }
 #undef VSTAB_LAUNCH
+#undef VSTAB_LAUNCH_B
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }
