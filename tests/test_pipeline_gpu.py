@@ -816,9 +816,19 @@ def test_long_bench_shaped_run_1080p(vs, cuda):
     (frames used in place: `hold`), chained tracker launches and speculative corner detection on -- against the oracle's
     state machine with the oracle's own detector, tracker and rotation estimator: key-frame list (the > 20 frames rule
     fires seven times), corner / track / inlier counts, rotations, every tenth emitted frame bit for bit."""
+    _bench_shaped_run(vs, cuda, 1920, 1080, 30, 160, 7)
+
+
+def test_bench_shaped_run_4k_config_3(vs, cuda):
+    """BASELINE config 3 at its own size through the whole pipeline object: 4K, smooth_radius 30, 52 frames of the bench's
+    clip, frames used in place, chained tracker launches through two counter-triggered key frames and their speculative
+    detections -- every decision, count and rotation against the oracle's state machine, every tenth frame bit for bit."""
+    _bench_shaped_run(vs, cuda, 3840, 2160, 30, 52, 2)
+
+
+def _bench_shaped_run(vs, cuda, w, h, r, n, min_keys):
     import torch
     import bench
-    w, h, r, n = 1920, 1080, 30, 160
     K = oracle.get_preset_camera(4, w, h)
     Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
     dev_frames, _ = bench.shaky_ring(torch, cuda, w, h, K, n, seed=5)
@@ -853,7 +863,7 @@ def test_long_bench_shaped_run_1080p(vs, cuda):
         exp.append(o)
     assert len(exp) == n - 1
     keys = [k for k, l in enumerate(log) if l["key"]]
-    assert keys == [k for k, l in enumerate(sm.log) if l["key"]] and len(keys) >= 7
+    assert keys == [k for k, l in enumerate(sm.log) if l["key"]] and len(keys) >= min_keys
     assert [(l["n_corners"], l["n_tracked"]) for l in log] == counts
     assert [l["inliers"] for l in log] == [l["inliers"] for l in sm.log]
     assert all(np.allclose(a["R"], b["R"], atol=1e-9) for a, b in zip(log, sm.log))
