@@ -3,11 +3,11 @@
 # copies the judged summaries of gpurun_out/prof_<tag>/ (written by tools/prof_bench.sh) into profiles/
 set -e
 TAG=${1:?tag}
-PFX=${2:-r02}
+PFX=${2:-r03}
 SRC=gpurun_out/prof_$TAG
 cp $SRC/summary.txt profiles/${PFX}_bench_pipeline_rocprof_summary.txt
 cp $SRC/traffic.json profiles/traffic_4k.json
-STATS=$(find $SRC/trace gpurun_out/r02 -name "*kernel_stats*.csv" 2>/dev/null | head -1)
+STATS=$(find $SRC/trace -name "*kernel_stats*.csv" 2>/dev/null | head -1)
 (head -1 $STATS; grep vstab:: $STATS) > profiles/${PFX}_bench_pipeline_kernel_stats.csv
 python3 - "$PFX" <<'PY'
 import csv, json, sys

@@ -29,7 +29,7 @@ cal4 = find("cal_fetch", "k_pack_nv12<unsigned int>", "FETCH_SIZE")
 cal8 = find("cal_fetch", ", 2u>", "FETCH_SIZE") or find("cal_fetch", "uint2", "FETCH_SIZE")
 calw16 = find("cal_write", ", 4u>", "WRITE_SIZE") or find("cal_write", "uint4", "WRITE_SIZE")
 wf, ww = find("pmc_fetch", "k_warp_fused", "FETCH_SIZE"), find("pmc_write", "k_warp_fused", "WRITE_SIZE")
-summary = {"known_copy_bytes": known}
+summary = {"known_copy_bytes": known, "round": os.environ.get("ROUND", "r03")}
 if cal16: summary["fetch_factor_16B_per_lane"] = known / (cal16 * 1024)
 if cal4: summary["fetch_factor_4B_per_lane"] = known / (cal4 * 1024)
 if cal8: summary["fetch_factor_8B_per_lane"] = known / (cal8 * 1024)
@@ -49,8 +49,8 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
         if "k_warp_fused" in r["Name"]:
             summary["rocprof_avg_launch_us"] = round(float(r["AverageNs"]) / 1e3, 2)
 if sq["SQ_ACTIVE_INST_VALU"] and "rocprof_avg_launch_us" in summary:
-    clk = 2.1e9
-    summary["shader_clock_ghz_measured"] = 2.1
+    clk = float(os.environ.get("SHADER_CLOCK_GHZ", "2.1")) * 1e9   # ASSUMED unless given: the clock tools/wg_timeline.py measured in-kernel (r02: 2.10 GHz)
+    summary["shader_clock_ghz_assumed"] = clk / 1e9
     summary["valu_busy"] = round(sq["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * summary["rocprof_avg_launch_us"] * 1e-6 * clk), 3)
     summary["sq"] = {k: v for k, v in sq.items() if v is not None}
 lines.append("traffic: " + json.dumps(summary))

@@ -494,15 +494,27 @@ __device__ __forceinline__ uint32_t blend_bgrx(uint32_t t00, uint32_t t01, uint3
     const uint32_t r_l = __builtin_amdgcn_perm(t10, t00, 0x0c0c0602u);   // [top.R, bottom.R, 0, 0]
     const uint32_t bg_r = __builtin_amdgcn_perm(t11, t01, 0x05010400u);
     const uint32_t r_r = __builtin_amdgcn_perm(t11, t01, 0x0c0c0602u);
-    const uint32_t vb_l = __builtin_amdgcn_udot4(bg_l, w_lo, 0u, false), vg_l = __builtin_amdgcn_udot4(bg_l, w_hi, 0u, false);
-    const uint32_t vr_l = __builtin_amdgcn_udot4(r_l, w_lo, 0u, false);
-    const uint32_t vb_r = __builtin_amdgcn_udot4(bg_r, w_lo, 0u, false), vg_r = __builtin_amdgcn_udot4(bg_r, w_hi, 0u, false);
-    const uint32_t vr_r = __builtin_amdgcn_udot4(r_r, w_lo, 0u, false);
-    // horizontal lerp with the weights scaled by 64: (l * gx + r * fx + 512) << 6 has the result byte at bits 16..23
-    const uint32_t fx6 = fx << 6, gx6 = 2048u - fx6;
-    const uint32_t sb = __umul24(vb_l, gx6) + (__umul24(vb_r, fx6) + 32768u);
-    const uint32_t sg = __umul24(vg_l, gx6) + (__umul24(vg_r, fx6) + 32768u);
-    const uint32_t sr = __umul24(vr_l, gx6) + (__umul24(vr_r, fx6) + 32768u);
+    // horizontal lerp with the weights scaled by 64: (l * gx + r * fx + 512) << 6 has the result byte at bits 16..23.
+    // The six dot products and six multiply-adds are ONE hand-ordered block: gfx950 needs three independent
+    // instructions between a v_dot4 and the VALU instruction that reads its result (the compiler pads its own dot4s with
+    // s_nop, cannot see into inline assembly, and left to itself emits two multiplies and a three-operand add per channel
+    // where two multiply-adds do) -- here every dot product is read five instructions after it was issued.
+    const uint32_t fx6 = fx << 6, gx6 = 2048u - fx6, half = 32768u;
+    uint32_t vb_r, vg_r, vr_r, vb_l, vg_l, vr_l, sb, sg, sr;
+    asm("v_dot4_u32_u8 %0, %9, %13, 0\n\t"
+        "v_dot4_u32_u8 %1, %9, %14, 0\n\t"
+        "v_dot4_u32_u8 %2, %10, %13, 0\n\t"
+        "v_dot4_u32_u8 %3, %11, %13, 0\n\t"
+        "v_dot4_u32_u8 %4, %11, %14, 0\n\t"
+        "v_dot4_u32_u8 %5, %12, %13, 0\n\t"
+        "v_mad_u32_u24 %6, %0, %15, %17\n\t"
+        "v_mad_u32_u24 %7, %1, %15, %17\n\t"
+        "v_mad_u32_u24 %8, %2, %15, %17\n\t"
+        "v_mad_u32_u24 %6, %3, %16, %6\n\t"
+        "v_mad_u32_u24 %7, %4, %16, %7\n\t"
+        "v_mad_u32_u24 %8, %5, %16, %8"
+        : "=&v"(vb_r), "=&v"(vg_r), "=&v"(vr_r), "=&v"(vb_l), "=&v"(vg_l), "=&v"(vr_l), "=&v"(sb), "=&v"(sg), "=&v"(sr)
+        : "v"(bg_r), "v"(r_r), "v"(bg_l), "v"(r_l), "v"(w_lo), "v"(w_hi), "v"(fx6), "v"(gx6), "v"(half));
     const uint32_t bg = __builtin_amdgcn_perm(sg, sb, 0x0c0c0602u);  // [B, G, 0, 0]
     return __builtin_amdgcn_perm(sr, bg, 0x0c060100u);               // [B, G, R, 0]
 }
