@@ -663,7 +663,7 @@ extern "C" __attribute__((visibility("default"))) void vstab_dev_set_lk_timing(v
 #define LK_NOW() 0ull
 #endif
 
-__global__ void __launch_bounds__(LK_THREADS, 8) k_lk_track(LkPyramid I, LkPyramid J, const float2 *__restrict__ prev_pts,
+__global__ void __launch_bounds__(LK_THREADS, 7) k_lk_track(LkPyramid I, LkPyramid J, const float2 *__restrict__ prev_pts,
                                                          int n, float2 *__restrict__ next_pts, uint8_t *__restrict__ status,
                                                          uint4 *__restrict__ host_rec, unsigned int seq,
                                                          const uint4 *chain_in, unsigned int parent_seq, uint4 *dev_rec,

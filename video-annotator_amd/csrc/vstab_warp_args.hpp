@@ -70,5 +70,8 @@ __device__ __forceinline__ uint32_t load_u32_bytes(const uint8_t *p, int valid) 
 
 vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int map_mode, bool nv12_out, bool src_vec_ok, bool dst_vec_ok,
                                const void *qmap, int qpitch, const float *rot_bottom, hipStream_t st);
+// the 10-bit pixel path on the LDS-tiled kernel: a.y / a.uv = P010 planes (16-byte aligned, pitches multiples of 16), a.dst = 16-bit
+// BGR with a.pitch_dst bytes per row; map modes 0 / 1 only
+vstab_status launch_warp_fused10(const WarpArgs &a, const float params[17], int map_mode, int blend, const float *rot_bottom, hipStream_t st);
 
 }  // namespace vstab

@@ -31,6 +31,7 @@
 #include <hip/hip_ext.h>
 
 #include "vstab_device.hpp"
+#include "vstab_device10.hpp"
 #include "vstab_internal.hpp"
 #include "vstab_warp_args.hpp"
 
@@ -297,8 +298,13 @@ __device__ __forceinline__ uint32_t map_pairs_ocl(float icx32, float icy32, floa
 
 // Returns false -- right behind the probe, before anything else is done -- when SPLIT is set and the tile's box is over the
 // LDS budget: the caller then covers the tile with two tiles of half the height.
-template <int RWB, int RW, int MODE, int FMT, bool CACHED, bool SPLIT>
+// DEPTH 8: NV12 bytes in, the reference's pixel path.  DEPTH 10 (FMT 2, BASELINE config 5): P010 words in, the box staged as
+// B | G << 10 | R << 20 dwords -- the same 4-byte LDS pixel -- blended by BLEND (vstab_device10.hpp), 16-bit BGR out.
+template <int RWB, int RW, int MODE, int FMT, bool CACHED, bool SPLIT, int DEPTH = 8, int BLEND = 0>
 __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, const int x0, const int y0) {
+    static_assert((DEPTH == 8 && FMT != 2) || (DEPTH == 10 && FMT == 2), "10-bit pixels leave as 16-bit BGR");
+    using SrcVec = typename std::conditional<DEPTH == 10, uint4, uint2>::type;  // 8 source samples of a block row
+    constexpr uint32_t BPS = DEPTH == 10 ? 2 : 1;                              // bytes per sample
     constexpr int TH = 4 * RW;
     constexpr int STAGE_MAX = StageTrips<RWB, RW>::value;
     constexpr int QB = CACHED ? 0 : QMAGIC_BITS;  // offset of the quantised-coordinate representation kept in registers
@@ -329,7 +335,7 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
 
     // ---- load: this thread's 8x2 blocks of the box, all loads in flight at once --------------------------------
     const int ux_n = wb >> 3, units = use_lds ? ux_n * (hb >> 1) : 0;
-    uint2 y0w[STAGE_MAX], y1w[STAGE_MAX], uvw[STAGE_MAX];
+    SrcVec y0w[STAGE_MAX], y1w[STAGE_MAX], uvw[STAGE_MAX];
     int ldsoff[STAGE_MAX];  // dword offset of the block in the LDS tile (| ZERO_BLOCK: outside the source); -1 = no block
     constexpr int ZERO_BLOCK = 1 << 24;
     if (use_lds) {
@@ -351,17 +357,17 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
             const int gx = bx0 + 8 * ux, gy = by0 + 2 * uy;
             const bool inside = (uint32_t)gx < (uint32_t)(a.sw & ~7) && (uint32_t)gy < (uint32_t)a.sh;
             const uint32_t cx = (uint32_t)min(max(gx, 0), (a.sw & ~7) - 8), cy = (uint32_t)min(max(gy, 0), a.sh - 2);
-            const uint32_t oy = __umul24(cy, pitch_y) + cx, ouv = __umul24(cy >> 1, pitch_uv) + cx;
-            y0w[it] = *reinterpret_cast<const uint2 *>(a.y + oy);
-            y1w[it] = *reinterpret_cast<const uint2 *>(a.y + oy + pitch_y);
-            uvw[it] = *reinterpret_cast<const uint2 *>(a.uv + ouv);
+            const uint32_t oy = __umul24(cy, pitch_y) + cx * BPS, ouv = __umul24(cy >> 1, pitch_uv) + cx * BPS;
+            y0w[it] = *reinterpret_cast<const SrcVec *>(a.y + oy);
+            y1w[it] = *reinterpret_cast<const SrcVec *>(a.y + oy + pitch_y);
+            uvw[it] = *reinterpret_cast<const SrcVec *>(a.uv + ouv);
             ldsoff[it] = valid ? (__mul24(2 * uy, wb) + 8 * ux) | (inside ? 0 : ZERO_BLOCK) : -1;
             ux += sx_, uy += sy_;
             if (ux >= ux_n) ux -= ux_n, uy++;
         }
     } else {
 #pragma unroll
-        for (int it = 0; it < STAGE_MAX; it++) y0w[it] = y1w[it] = uvw[it] = make_uint2(0, 0), ldsoff[it] = -1;
+        for (int it = 0; it < STAGE_MAX; it++) y0w[it] = y1w[it] = uvw[it] = SrcVec(), ldsoff[it] = -1;
     }
 
     VSTAB_STAMP(2);
@@ -493,7 +499,7 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
                 *reinterpret_cast<uint4 *>(d) = z, *reinterpret_cast<uint4 *>(d + 4) = z;
                 *reinterpret_cast<uint4 *>(d + wb) = z, *reinterpret_cast<uint4 *>(d + wb + 4) = z;
 #ifdef VSTAB_DEV
-            } else if (ldsoff[it] >= 0 && (ta.ablate & 4)) {
+            } else if (DEPTH == 8 && ldsoff[it] >= 0 && (ta.ablate & 4)) {
                 uint32_t *d = tile + ldsoff[it];
                 *reinterpret_cast<uint4 *>(d) = make_uint4(y0w[it].x, y0w[it].y, uvw[it].x, uvw[it].y);
                 *reinterpret_cast<uint4 *>(d + 4) = make_uint4(y0w[it].y, y0w[it].x, uvw[it].x, uvw[it].y);
@@ -502,6 +508,22 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
 #endif
             } else if (ldsoff[it] >= 0) {
                 uint32_t *d = tile + ldsoff[it];
+                if constexpr (DEPTH == 10) {
+                    // eight P010 luma words per row (two per dword), four (U, V) word pairs; sample = word >> 6
+                    const uint32_t ya[4] = {y0w[it].x, y0w[it].y, y0w[it].z, y0w[it].w}, yb[4] = {y1w[it].x, y1w[it].y, y1w[it].z, y1w[it].w};
+                    const uint32_t cw[4] = {uvw[it].x, uvw[it].y, uvw[it].z, uvw[it].w};
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        const ChromaTerm c0 = chroma_term10(cw[2 * half]), c1 = chroma_term10(cw[2 * half + 1]);
+                        uint4 r0, r1;
+                        r0.x = pack_bgr10((int)((ya[2 * half] & 0xffffu) >> 6), c0), r0.y = pack_bgr10((int)(ya[2 * half] >> 22), c0);
+                        r0.z = pack_bgr10((int)((ya[2 * half + 1] & 0xffffu) >> 6), c1), r0.w = pack_bgr10((int)(ya[2 * half + 1] >> 22), c1);
+                        r1.x = pack_bgr10((int)((yb[2 * half] & 0xffffu) >> 6), c0), r1.y = pack_bgr10((int)(yb[2 * half] >> 22), c0);
+                        r1.z = pack_bgr10((int)((yb[2 * half + 1] & 0xffffu) >> 6), c1), r1.w = pack_bgr10((int)(yb[2 * half + 1] >> 22), c1);
+                        *reinterpret_cast<uint4 *>(d + 4 * half) = r0;
+                        *reinterpret_cast<uint4 *>(d + wb + 4 * half) = r1;
+                    }
+                } else
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     const uint32_t cw = half ? uvw[it].y : uvw[it].x, ya = half ? y0w[it].y : y0w[it].x, yb = half ? y1w[it].y : y1w[it].x;
@@ -556,7 +578,8 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
                     if (ta.ablate & 2) out[j0 + j] = t0[j] ^ t1[j] ^ t2[j] ^ t3[j] ^ (qxb[j0 + j] & 31) ^ (qyb[j0 + j] & 31);
                     else
 #endif
-                    out[j0 + j] = blend_bgrx(t0[j], t1[j], t2[j], t3[j], qxb[j0 + j] & 31, qyb[j0 + j] & 31);
+                    out[j0 + j] = DEPTH == 10 ? blend_bgr10<BLEND>(t0[j], t1[j], t2[j], t3[j], qxb[j0 + j] & 31, qyb[j0 + j] & 31)
+                                              : blend_bgrx(t0[j], t1[j], t2[j], t3[j], qxb[j0 + j] & 31, qyb[j0 + j] & 31);
                 }
             }
         } else {
@@ -569,7 +592,8 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
                 uint32_t v = 0;
                 if (inbox) {
                     const uint32_t *t = tile + (__mul24(Yr[j], wb) + Xr[j]);
-                    v = blend_bgrx(t[0], t[1], t[wb], t[wb + 1], qxb[j] & 31, qyb[j] & 31);
+                    v = DEPTH == 10 ? blend_bgr10<BLEND>(t[0], t[1], t[wb], t[wb + 1], qxb[j] & 31, qyb[j] & 31)
+                                    : blend_bgrx(t[0], t[1], t[wb], t[wb + 1], qxb[j] & 31, qyb[j] & 31);
                 }
                 out[j] = v;
                 const bool live = col_live && y0 + wave * RW + j < a.dh;
@@ -582,7 +606,7 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
 #pragma unroll
                     for (int k = 1; k < RW; k++) sx = j == k ? qxb[k] : sx, sy = j == k ? qyb[k] : sy;
                     if ((slow >> j) & 1u) {
-                        const uint32_t v = gather_pixel_far(a, sx - QB, sy - QB);
+                        const uint32_t v = DEPTH == 10 ? gather_pixel10<BLEND>(a, sx - QB, sy - QB) : gather_pixel_far(a, sx - QB, sy - QB);
 #pragma unroll
                         for (int k = 0; k < RW; k++) out[k] = j == k ? v : out[k];
                     }
@@ -603,7 +627,19 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
     }
 #endif
     const int ncols = min(64, a.dw - x0);  // > 0
-    if constexpr (FMT == 0) {
+    if constexpr (FMT == 2) {
+        // 16-bit BGR: three samples per pixel, lane = column (2-byte stores: a pixel is 6 bytes, rows are 2-byte aligned;
+        // assembling the row into 4-byte stores through ds_bpermute was measured: no faster, 6 more instructions per pixel)
+#pragma unroll
+        for (int j = 0; j < RW; j++) {
+            const int y = y0 + wave * RW + j;
+            if (y >= a.dh) break;  // uniform
+            if (col_live) {
+                uint16_t *o = reinterpret_cast<uint16_t *>(a.dst + ((size_t)(uint32_t)y * a.pitch_dst + (uint32_t)x * 6u));
+                o[0] = (uint16_t)(out[j] & 1023u), o[1] = (uint16_t)((out[j] >> 10) & 1023u), o[2] = (uint16_t)(out[j] >> 20);
+            }
+        }
+    } else if constexpr (FMT == 0) {
         const int p0 = (4 * lane) / 3, m3 = lane - 3 * (lane / 3);  // pixels p0, p0 + 1 feed dword `lane` (lane < 48)
         const uint32_t sel = m3 == 0 ? 0x04020100u : m3 == 1 ? 0x05040201u : 0x06050402u;
         const int nbytes = 3 * ncols, nfull = nbytes >> 2, rem = nbytes & 3;
@@ -686,8 +722,8 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
 // the 128-B lines their source and output rows straddle move once.  Inside its band an XCD first works through tiles of
 // 4 RWB rows, then -- from row split_y[k] on -- through tiles of half that height (the last, partly filled round of
 // workgroups then lasts half as long).  Placement and tile height only affect speed, never results.
-template <int RWB, int MODE, int FMT, bool CACHED>
-__global__ void __launch_bounds__(256, VSTAB_WARP_WAVES) k_warp_fused(FusedArgs ta) {
+template <int RWB, int MODE, int FMT, bool CACHED, int DEPTH = 8, int BLEND = 0>
+__global__ void __launch_bounds__(256, DEPTH == 10 ? 5 : VSTAB_WARP_WAVES) k_warp_fused(FusedArgs ta) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int TH = 4 * RWB, TS = TH / 2;
     const int k = (int)(blockIdx.x & 7u), idx = (int)(blockIdx.x >> 3);
@@ -699,14 +735,14 @@ __global__ void __launch_bounds__(256, VSTAB_WARP_WAVES) k_warp_fused(FusedArgs 
         x0 = (idx - row * ta.tiles_x) * 64, ys = y_lo + row * TH;
         // a tall tile whose box is over the LDS budget (the image centre, where the lens compresses most) is done as two
         // half-height tiles, one after the other
-        n_half = warp_tile<RWB, RWB, MODE, FMT, CACHED, true>(ta, smem, x0, ys) ? 0 : 2;
+        n_half = warp_tile<RWB, RWB, MODE, FMT, CACHED, true, DEPTH, BLEND>(ta, smem, x0, ys) ? 0 : 2;
     } else {
         const int i2 = idx - n_tall, row = i2 / ta.tiles_x;
         x0 = (i2 - row * ta.tiles_x) * 64, ys = y_sp + row * TS, n_half = 1;
         if (ys >= y_hi) return;  // uniform for the workgroup (before any barrier)
     }
 #pragma unroll 1
-    for (int i = 0; i < n_half; i++) warp_tile<RWB, RWB / 2, MODE, FMT, CACHED, false>(ta, smem, x0, ys + i * TS);
+    for (int i = 0; i < n_half; i++) warp_tile<RWB, RWB / 2, MODE, FMT, CACHED, false, DEPTH, BLEND>(ta, smem, x0, ys + i * TS);
 }
 
 }  // namespace vstab
@@ -719,6 +755,73 @@ namespace vstab {
 static unsigned long long *g_dev_timing = nullptr;
 extern "C" __attribute__((visibility("default"))) void vstab_dev_set_timing(void *p) { g_dev_timing = static_cast<unsigned long long *>(p); }
 #endif
+
+// Bands and tile heights of a launch (see k_warp_fused): the image's half-height tile rows dealt evenly to the 8 XCDs; inside
+// a band the tall tiles come first, the last `tail_rounds` rounds of the XCD's workgroup slots (32 CUs x workgroups per CU)
+// are made of half-height tiles.  Returns the grid size.
+static unsigned tile_schedule(FusedArgs &ta, int rwb, int lds_kb, double tail_rounds) {
+    const WarpArgs &a = ta.w;
+    ta.lds_capacity_px = lds_kb * 1024 / 4 - 8;  // 8 dwords hold the tile header
+    ta.tiles_x = (int)div_up(a.dw, 64);
+    const int th = 4 * rwb, ts = th / 2;
+    const int half_rows = (int)div_up(a.dh, ts);
+    const int slots = 32 * std::max(1, std::min(8, (int)(160 / lds_kb)));
+    int share = 0;
+    for (int k = 0; k <= 8; k++) ta.band_y[k] = std::min(a.dh, (int)((long)k * half_rows / 8) * ts);
+    ta.band_y[8] = a.dh;
+    for (int k = 0; k < 8; k++) {
+        const int rows = ta.band_y[k + 1] - ta.band_y[k];
+        const int tall_rows_max = rows / th;  // whole tall tile rows that fit
+        // half-height tiles for about tail_rounds * slots tall-tile equivalents at the end of the band
+        const int tail_tall_rows = (int)std::min<long>(tall_rows_max, std::lround(tail_rounds * slots / ta.tiles_x));
+        const int tall_rows = tall_rows_max - tail_tall_rows;
+        ta.split_y[k] = ta.band_y[k] + tall_rows * th;
+        const int n = tall_rows * ta.tiles_x + (int)div_up(ta.band_y[k + 1] - ta.split_y[k], ts) * ta.tiles_x;
+        share = std::max(share, n);
+    }
+    return 8u * (unsigned)share;
+}
+
+// The 10-bit pixel path on the same kernel (DEPTH 10): fisheye -> pinhole maps (modes 0 / 1, optionally a rotation per
+// output row), both blends; called by vstab_warp_p010 when the planes allow 16-byte staging loads.
+vstab_status launch_warp_fused10(const WarpArgs &a, const float params[17], int map_mode, int blend, const float *rot_bottom, hipStream_t st) {
+    FusedArgs ta;
+    ta.w = a;
+    ta.p32 = {params[0] * 32.0f, params[1] * 32.0f, params[2] * 32.0f, params[3] * 32.0f, params[10], params[13], params[16]};
+    ta.src_vec_ok = 1, ta.dst_vec_ok = 1;
+    ta.qmap = nullptr, ta.qpitch = 0;
+    for (int k = 0; k < 9; k++) ta.rs_d[k] = rot_bottom ? rot_bottom[k] - params[8 + k] : 0.0f;
+    ta.rs_den = (float)(a.dh > 1 ? a.dh - 1 : 1);
+#ifdef VSTAB_DEV
+    ta.timing = nullptr, ta.ablate = 0;
+#endif
+    const int lds_kb = 40;
+    const long tiles = (long)div_up(a.dw, 64) * div_up(a.dh, 32);
+    const dim3 grid(tile_schedule(ta, 8, lds_kb, tiles > 1024 ? 0.5 : 0.0));
+    const size_t lds_bytes = (size_t)lds_kb * 1024;
+    const LaunchEvents ev = take_launch_events();
+#define VSTAB_LAUNCH10(M, B)                                                                                                        \
+    do {                                                                                                                            \
+        if (ev.start) hipExtLaunchKernelGGL((k_warp_fused<8, M, 2, false, 10, B>), grid, dim3(256), lds_bytes, st, ev.start, ev.stop, 0, ta); \
+        else hipLaunchKernelGGL((k_warp_fused<8, M, 2, false, 10, B>), grid, dim3(256), lds_bytes, st, ta);                            \
+    } while (0)
+#define VSTAB_LAUNCH10_M(M)                                        \
+    do {                                                           \
+        if (blend == VSTAB_BLEND_FP16) VSTAB_LAUNCH10(M, VSTAB_BLEND_FP16); \
+        else VSTAB_LAUNCH10(M, VSTAB_BLEND_EXACT);                 \
+    } while (0)
+    if (rot_bottom) {
+        if (map_mode == VSTAB_MAP_CREATEMAP_CL) VSTAB_LAUNCH10_M(MAP_RS_CREATEMAP_CL);
+        else VSTAB_LAUNCH10_M(MAP_RS_FISH_TO_RECT);
+    } else {
+        if (map_mode == VSTAB_MAP_CREATEMAP_CL) VSTAB_LAUNCH10_M(MAP_CREATEMAP_CL);
+        else VSTAB_LAUNCH10_M(MAP_FISH_TO_RECT);
+    }
+#undef VSTAB_LAUNCH10_M
+#undef VSTAB_LAUNCH10
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
 
 vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int map_mode, bool nv12_out, bool src_vec_ok, bool dst_vec_ok,
                                const void *qmap, int qpitch, const float *rot_bottom, hipStream_t st) {
@@ -749,27 +852,7 @@ vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int ma
     if (const char *e = getenv("VSTAB_TAIL_ROUNDS")) tail_rounds = atof(e);
 #endif
     const size_t lds_bytes = (size_t)lds_kb * 1024;
-    ta.lds_capacity_px = (int)(lds_bytes / 4) - 8;  // 8 dwords hold the tile header
-    ta.tiles_x = (int)div_up(a.dw, 64);
-    // Bands: the image's half-height tile rows dealt evenly to the 8 XCDs.  Inside a band the tall tiles come first; the
-    // last `tail_rounds` rounds of the XCD's workgroup slots (32 CUs x workgroups per CU) are made of half-height tiles.
-    const int th = 4 * rwb, ts = th / 2;
-    const int half_rows = (int)div_up(a.dh, ts);
-    const int slots = 32 * std::max(1, std::min(8, (int)(160 / lds_kb)));
-    int share = 0;
-    for (int k = 0; k <= 8; k++) ta.band_y[k] = std::min(a.dh, (int)((long)k * half_rows / 8) * ts);
-    ta.band_y[8] = a.dh;
-    for (int k = 0; k < 8; k++) {
-        const int rows = ta.band_y[k + 1] - ta.band_y[k];
-        const int tall_rows_max = rows / th;  // whole tall tile rows that fit
-        // half-height tiles for about tail_rounds * slots tall-tile equivalents at the end of the band
-        const int tail_tall_rows = (int)std::min<long>(tall_rows_max, std::lround(tail_rounds * slots / ta.tiles_x));
-        const int tall_rows = tall_rows_max - tail_tall_rows;
-        ta.split_y[k] = ta.band_y[k] + tall_rows * th;
-        const int n = tall_rows * ta.tiles_x + (int)div_up(ta.band_y[k + 1] - ta.split_y[k], ts) * ta.tiles_x;
-        share = std::max(share, n);
-    }
-    const dim3 grid(8u * (unsigned)share);
+    const dim3 grid(tile_schedule(ta, rwb, lds_kb, tail_rounds));
     // a profiling caller may have left an event pair for this launch: the kernel's own start / end stamps
     const LaunchEvents ev = take_launch_events();
 #define VSTAB_LAUNCH(R, M, F, C)                                                                                            \

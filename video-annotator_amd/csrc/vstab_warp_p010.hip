@@ -12,10 +12,13 @@
 //     within 2 levels of the exact one
 //   BGR, three 16-bit samples per pixel, values 0..1023.
 // Direct gather, two output pixels per thread: this path is about the format, the 8-bit kernel carries the rate.
+#include <cstdlib>
+
 #include <hip/hip_ext.h>
 
-#include "vstab_device.hpp"
+#include "vstab_device10.hpp"
 #include "vstab_internal.hpp"
+#include "vstab_warp_args.hpp"
 
 namespace vstab {
 
@@ -29,57 +32,6 @@ struct P010Args {
     float rs_den;   // (float)max(dh - 1, 1)
     int rs;
 };
-
-__device__ __forceinline__ int sat10(int v) { return min(max(v, 0), 1023); }
-// luma term + chroma term: the exact sum needs 33 bits (959 * CY + 511 * CUB = 2.25e9), but whenever it exceeds INT_MAX the
-// pixel is saturated anyway ((2^31 - 1) >> 20 = 2047 > 1023), and it never goes below -1.09e9: a saturating 32-bit add
-// (v_add_i32 ... clamp) gives the same channel value as the 64-bit sum of the definition.
-__device__ __forceinline__ int channel10(int yy, int c) { return sat10(__builtin_elementwise_add_sat(yy, c) >> 20); }
-
-// B, G, R in [0, 1023] of one tap from its luma sample and chroma pair (both still P010 words); !valid -> 0 (BORDER_CONSTANT)
-__device__ __forceinline__ void convert_tap10(uint32_t ys, uint32_t c, bool valid, int &b, int &g, int &r) {
-    const int yv = (int)(ys >> 6);
-    const int u = (int)((c & 0xffffu) >> 6) - 512, v = (int)(c >> 22) - 512;
-    const int yy = max(yv - 64, 0) * CY;  // <= 959 * 1220542 < 2^31
-    b = valid ? channel10(yy, (1 << 19) + CUB * u) : 0;
-    g = valid ? channel10(yy, (1 << 19) + CVG * v + CUG * u) : 0;
-    r = valid ? channel10(yy, (1 << 19) + CVR * v) : 0;
-}
-
-struct Dword2 {  // 4-byte aligned pair of dwords / 2-byte aligned dword: the loads below are narrower than their natural alignment
-    uint32_t lo, hi;
-} __attribute__((packed, aligned(4)));
-struct Dword1 {
-    uint32_t v;
-} __attribute__((packed, aligned(2)));
-
-// The two horizontally adjacent taps (X, Yr), (X + 1, Yr) of a pixel's footprint with TWO loads: one dword holding both
-// luma samples and one pair of dwords holding the (at most two) chroma pairs they use; positions are clamped into the
-// row so that every load is in bounds, and taps outside the source come back as 0.  Needs sw >= 4.
-__device__ __forceinline__ void fetch_row10(const P010Args &a, int X, int Yr, int &b0, int &g0, int &r0, int &b1, int &g1, int &r1) {
-    const bool row_ok = (unsigned)Yr < (unsigned)a.sh;
-    const int Yc = min(max(Yr, 0), a.sh - 1);
-    const int col0 = min(max(X, 0), a.sw - 2);          // samples col0, col0 + 1
-    const uint32_t yy = reinterpret_cast<const Dword1 *>(a.y + (size_t)Yc * a.pitch_y + 2 * (size_t)col0)->v;
-    const int np = a.sw >> 1, pX = X >> 1, pX1 = (X + 1) >> 1;
-    const int pc0 = min(max(pX, 0), np - 2);            // chroma pairs pc0, pc0 + 1
-    const Dword2 cc = *reinterpret_cast<const Dword2 *>(a.uv + (size_t)(Yc >> 1) * a.pitch_uv + 4 * (size_t)pc0);
-    const int d = X - col0;                             // 0 inside; -1 at X = -1; 1 at X = sw - 1
-    const uint32_t yl = d == 1 ? yy >> 16 : yy & 0xffffu, yr = d == -1 ? yy & 0xffffu : yy >> 16;
-    const uint32_t cl = pX - pc0 == 1 ? cc.hi : cc.lo, cr = pX1 - pc0 == 1 ? cc.hi : cc.lo;
-    convert_tap10(yl << 0, cl, row_ok && (unsigned)X < (unsigned)a.sw, b0, g0, r0);
-    convert_tap10(yr << 0, cr, row_ok && (unsigned)(X + 1) < (unsigned)a.sw, b1, g1, r1);
-}
-
-__device__ __forceinline__ int blend_fp16(int p00, int p01, int p10, int p11, int w00, int w01, int w10, int w11) {
-    const _Float16 k = (_Float16)(1.0f / 1024.0f);
-    _Float16 acc = (_Float16)0.0f;
-    acc = __builtin_fmaf16((_Float16)p00, (_Float16)w00 * k, acc);  // (w * 2^-10 is exact: w <= 1024 has <= 11 significant bits)
-    acc = __builtin_fmaf16((_Float16)p01, (_Float16)w01 * k, acc);
-    acc = __builtin_fmaf16((_Float16)p10, (_Float16)w10 * k, acc);
-    acc = __builtin_fmaf16((_Float16)p11, (_Float16)w11 * k, acc);
-    return min((int)__builtin_rintf((float)acc), 1023);
-}
 
 // the four taps of one output pixel, converted and blended; sx, sy = cvRound(32 * map)
 template <int BLEND>
@@ -166,6 +118,21 @@ extern "C" vstab_status vstab_warp_p010(const void *y, size_t pitch_y, const voi
         return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: bad pitch or alignment (16-bit samples; chroma pairs 4-byte aligned)");
     if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_RECT_TO_FISH) return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: unknown map mode");
     if (blend != VSTAB_BLEND_EXACT && blend != VSTAB_BLEND_FP16) return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: unknown blend");
+    // The LDS-tiled kernel (the 8-bit hot kernel's structure with a 10:10:10 LDS pixel) serves the fisheye -> pinhole maps when
+    // the planes allow its 16-byte staging loads; everything else takes the direct-gather kernel below.  Same results.
+    const bool tiled_ok = (map_mode == VSTAB_MAP_CREATEMAP_CL || map_mode == VSTAB_MAP_FISH_TO_RECT) && sw >= 8 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+                          reinterpret_cast<uintptr_t>(uv) % 16 == 0 && pitch_y % 16 == 0 && pitch_uv % 16 == 0 && pitch_y < (1u << 24) &&
+                          pitch_uv < (1u << 24) && (uint64_t)pitch_y * sh < (1ull << 32);
+    static const bool force_direct = getenv("VSTAB_P010_DIRECT") != nullptr;  // development: the direct-gather kernel for every call
+    if (tiled_ok && !force_direct) {
+        WarpArgs wa;
+        wa.y = static_cast<const uint8_t *>(y), wa.uv = static_cast<const uint8_t *>(uv), wa.dst = static_cast<uint8_t *>(dst), wa.dst_uv = nullptr;
+        wa.pitch_y = pitch_y, wa.pitch_uv = pitch_uv, wa.pitch_dst = pitch_dst, wa.pitch_dst_uv = 0;
+        wa.sw = sw, wa.sh = sh, wa.dw = dw, wa.dh = dh;
+        wa.p = {params[0], params[1], params[2], params[3], params[4], params[5], params[6], params[7],
+                {params[8], params[9], params[10], params[11], params[12], params[13], params[14], params[15], params[16]}};
+        return launch_warp_fused10(wa, params, map_mode, blend, rot_bottom, static_cast<hipStream_t>(stream));
+    }
     P010Args a;
     a.y = static_cast<const uint8_t *>(y), a.uv = static_cast<const uint8_t *>(uv), a.dst = static_cast<uint16_t *>(dst);
     a.pitch_y = pitch_y, a.pitch_uv = pitch_uv, a.pitch_dst = pitch_dst;
