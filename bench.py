@@ -538,7 +538,7 @@ def main():
         kernel_name = "k_warp_fused"
         if p010:
             alg_bytes = w * h * 3 + cw * ch * 6  # P010 read once + 16-bit BGR written once
-            kernel_name = "k_warp_p010<CREATEMAP_CL, FP16> (direct gather)"
+            kernel_name = "k_warp_fused<8, RS_CREATEMAP_CL, BGR16, DEPTH 10, FP16> (the LDS-tiled kernel with a 10:10:10 LDS pixel)"
         base_bytes = alg_bytes  # of the kernel that evaluates the map (what "alone" runs)
         cached = mode == "pipeline" and args.no_tracking
         if cached:
@@ -575,7 +575,7 @@ def main():
                          "timing": "kernel start/end stamps (hipExtLaunchKernelGGL) of every 8th launch in the timed region",
                          "committed_profile": committed,
                          "alone": None if alone_us is None else {"avg_launch_us": round(alone_us, 2),
-                                                                   "kernel": "k_warp_p010" if p010 else "k_warp_fused",
+                                                                   "kernel": "k_warp_fused (DEPTH 10)" if p010 else "k_warp_fused",
                                                                    "achieved": round(base_bytes / alone_us / 1e3, 1),
                                                                    "frac": round(base_bytes / alone_us / 1e3 / HBM_PEAK_GBS, 4)}},
         }

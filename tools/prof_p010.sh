@@ -14,16 +14,16 @@ out = sys.argv[1]
 lines = []
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_warp_p010" in r["Name"]:
+        if "k_warp" in r["Name"]:
             lines.append(f"stats: {r['Name'][:70]:70s} calls={r['Calls']:>5s} avg_ns={float(r['AverageNs']):10.1f} min={r['MinNs']} max={r['MaxNs']}")
 for d in ("pmc_sq", "pmc_fetch", "pmc_write"):
     pm = collections.defaultdict(list)
     for f in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_warp_p010" in r["Kernel_Name"]:
-                pm[(r["Kernel_Name"].split("(")[0][-34:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+            if "k_warp" in r["Kernel_Name"]:
+                pm[(r["Kernel_Name"].split("(")[0][-44:], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for k, v in sorted(pm.items()):
-        lines.append(f"pmc[{d}]: {k[0]:36s} {k[1]:22s} mean_per_launch={sum(v)/len(v):.5g}")
+        lines.append(f"pmc[{d}]: {k[0]:46s} {k[1]:22s} mean_per_launch={sum(v)/len(v):.5g}")
 open(os.path.join(out, "summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
