@@ -118,6 +118,13 @@ VSTAB_API vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const 
                                            const float params[17], void *dst_bgr, size_t pitch_dst,
                                            int dst_width, int dst_height, void *stream);
 
+/* The same fused warp with cv::remap's INTER_NEAREST: FrameSourceWarp.hpp:90 takes an InterpolationFlags argument and
+ * FrameSourceWarp.cpp:311 hands it to cv::remap; the reference's callers only ever pass INTER_LINEAR.  OpenCV's CPU path:
+ * cvRound (half to even) + saturate_cast<short> of each map entry, one source pixel, 0 outside (BORDER_CONSTANT). */
+VSTAB_API vstab_status vstab_warp_nv12_nearest(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv,
+                                               int src_width, int src_height, const float params[17], void *dst_bgr,
+                                               size_t pitch_dst, int dst_width, int dst_height, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * the camera surface of the CLI's libdewobble filter (render.ts:611-617,
  * 669-683, 711-717: in_p / out_p in {fish, rect}) and NV12 output for the encoder hand-off
@@ -306,7 +313,11 @@ typedef struct vstab_frame {
                           frames can say how deep the pool is and the wait disappears from the frame loop.  From
                           smooth_radius + 14 on, the planes are not copied at all but read in place by the tracker and
                           by the warp (which runs on vstab_config.stream): the callback at which the promise runs out
-                          first waits, on the host, for that warp to finish.  1 << 29 or more: never waited for. */
+                          first waits, on the host, for that warp to finish.  1 << 29 or more: never waited for.
+                          That threshold is the 8-BIT rule.  16-bit (P010) frames are always narrowed into library
+                          memory for the tracker; their own planes are read in place by the 10-bit warp only with
+                          hold >= 1 << 29 (the promise has to cover a warp that runs smooth_radius frames later, and
+                          finite promises are not tracked for them) -- anything less and they are copied on ingest. */
     const double *readout_rotation; /* optional (NULL = global shutter): 3x3 row-major rotation of the camera between the
                           exposure of this frame's first and last row (rolling shutter, from the same sensor as
                           delta_rotation; BASELINE.json config 5).  The frame is then warped with a rotation per output row:
@@ -352,7 +363,8 @@ typedef struct vstab_config {
     int crop_borders;    /* 0 */
     double zoom;         /* 1 */
     int smooth_radius;   /* 30 */
-    int interpolation;   /* 1 = INTER_LINEAR (only mode the reference ever passes) */
+    int interpolation;   /* cv::InterpolationFlags: 1 = INTER_LINEAR (the only mode the reference ever passes), 0 = INTER_NEAREST
+                            (lens_mode 0, 8-bit BGR output, no read-out rotations); others are refused */
     int smoother;        /* VSTAB_SMOOTHER_SG (reference behaviour) */
     int tracking;        /* 1; 0 = no optical flow: rotations are identity (BASELINE config 1: undistort only) or the
                             upstream-supplied vstab_frame.delta_rotation (external gyro), smoothed the same way */

@@ -62,6 +62,7 @@ def lib():
         L.vo_atanf_max_ulp.restype = c.c_double
         L.vo_create_map.argtypes = [f32p, f32p, c.c_int, c.c_int, f32p]
         L.vo_remap_bilinear.argtypes = [u8p, c.c_int, c.c_int, c.c_int, f32p, f32p, u8p, c.c_int, c.c_int]
+        L.vo_remap_nearest.argtypes = [u8p, c.c_int, c.c_int, c.c_int, f32p, f32p, u8p, c.c_int, c.c_int]
         L.vo_warp_nv12_reference_path.argtypes = [u8p, c.c_int, c.c_int, f32p, u8p, c.c_int, c.c_int, u8p]
         L.vo_sincosf_array.argtypes = [f32p, f32p, f32p, c.c_long]
         L.vo_create_map_ex.argtypes = [f32p, f32p, c.c_int, c.c_int, f32p, c.c_int]
@@ -228,6 +229,18 @@ def remap_bilinear(src, mapx, mapy):
     dh, dw = mx.shape
     out = np.empty((dh, dw, cn), np.uint8)
     lib().vo_remap_bilinear(sp, s.shape[1], s.shape[0], cn, mxp, myp, _p(out, ctypes.c_uint8), dw, dh)
+    return out[:, :, 0] if s.ndim == 2 else out
+
+
+def remap_nearest(src, mapx, mapy):
+    """cv::remap(INTER_NEAREST, BORDER_CONSTANT 0): the other interpolation FrameSourceWarp.hpp:90 admits."""
+    s, sp = _u8(src)
+    cn = 1 if s.ndim == 2 else s.shape[2]
+    mx, mxp = _f32(mapx)
+    my, myp = _f32(mapy)
+    dh, dw = mx.shape
+    out = np.empty((dh, dw, cn), np.uint8)
+    lib().vo_remap_nearest(sp, s.shape[1], s.shape[0], cn, mxp, myp, _p(out, ctypes.c_uint8), dw, dh)
     return out[:, :, 0] if s.ndim == 2 else out
 
 

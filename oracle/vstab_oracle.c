@@ -230,6 +230,19 @@ VO_API void vo_remap_bilinear(const uint8_t *src, int sw, int sh, int cn, const 
                            dst + ((size_t)y * dw + x) * cn);
 }
 
+/* cv::remap(INTER_NEAREST, BORDER_CONSTANT 0) -- FrameSourceWarp.hpp:90 lets the caller choose the interpolation and
+ * :311 passes it on; the reference itself only ever passes INTER_LINEAR.  OpenCV 4.5 CPU path: the float maps are
+ * converted with cvRound (round half to even) and saturate_cast<short>, a pixel outside the source is the border value. */
+VO_API void vo_remap_nearest(const uint8_t *src, int sw, int sh, int cn, const float *mapx, const float *mapy, uint8_t *dst, int dw, int dh) {
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            const int sx = vo_sat16(vo_cvround(mapx[(size_t)y * dw + x])), sy = vo_sat16(vo_cvround(mapy[(size_t)y * dw + x]));
+            uint8_t *o = dst + ((size_t)y * dw + x) * cn;
+            for (int c = 0; c < cn; c++) o[c] = (unsigned)sx < (unsigned)sw && (unsigned)sy < (unsigned)sh ? src[((size_t)sy * sw + sx) * cn + c] : 0;
+        }
+}
+
 /* a2+a9+a10 as the reference runs them (FrameSourceWarp.cpp:401 then :272-314): full-frame
  * colour conversion, map planes written to memory, remap reading them back.  `work` must
  * hold w*h*3 + 2*dw*dh*4 bytes.  Used as the CPU baseline in bench.py. */

@@ -107,6 +107,28 @@ def test_undistort_only_mode_is_identity_warp(vs, cuda, clip):
         assert np.array_equal(outs[i], oracle.warp_nv12(frames[i + 1], p, cw, ch))
 
 
+def test_nearest_interpolation_through_the_pipeline(vs, cuda, clip):
+    """vstab_config.interpolation 0 = INTER_NEAREST: same rotations, nearest-neighbour frames; other flags are refused."""
+    K, frames, _ = clip
+    stab, outs = run_product(vs, cuda, frames[:8], smooth_radius=2, tracking=0, interpolation=0)
+    Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
+    p = oracle.map_params(K, Ko, np.eye(3))
+    mx, my = oracle.create_map(p, cw, ch)
+    assert len(outs) == 7
+    for i in (0, 6):
+        assert np.array_equal(outs[i], oracle.remap_nearest(oracle.cvt_nv12_bgr(frames[i + 1]), mx, my))
+    ref, _ = run_product(vs, cuda, frames[:10], smooth_radius=2), None
+    near, nouts = run_product(vs, cuda, frames[:10], smooth_radius=2, interpolation=0)
+    for i in range(len(nouts)):
+        assert np.array_equal(near.warp_rotation(i), ref[0].warp_rotation(i))
+    import torch
+    one = [torch.from_numpy(frames[0]).to(cuda)]
+    with pytest.raises(vs.VstabError):
+        vs.Stabilizer(one, total=1, interpolation=2)
+    with pytest.raises(vs.VstabError):
+        vs.Stabilizer(one, total=1, interpolation=0, lens_mode=1)
+
+
 def test_python_callback_source_eof_and_errors(vs, cuda, clip):
     import torch
     K, frames, _ = clip

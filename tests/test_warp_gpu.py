@@ -125,6 +125,22 @@ def test_fused_warp_bit_exact_vs_oracle(vs, cuda, w, h, preset, scale, crop):
         assert np.array_equal(got, exp), (rv, int((got != exp).sum()))
 
 
+@pytest.mark.parametrize("w,h,preset,scale,crop", [(128, 72, 4, 1.0, False), (130, 74, 1, 0.5, True), (1920, 1080, 4, 1.0, False)])
+def test_nearest_warp_bit_exact_vs_oracle(vs, cuda, w, h, preset, scale, crop):
+    """INTER_NEAREST (FrameSourceWarp.hpp:90 admits it): cvtColor + createMap + cv::remap nearest, operator by operator."""
+    K, Ko, (cw, ch) = cams(w, h, preset, scale, crop)
+    frame = synth.nv12(12, w, h)
+    bgr = oracle.cvt_nv12_bgr(frame)
+    fd = dev(frame, cuda)
+    for rv in ROTS:
+        p = oracle.map_params(K, Ko, oracle.rodrigues(rv))
+        mx, my = oracle.create_map(p, cw, ch)
+        exp = oracle.remap_nearest(bgr, mx, my)
+        got = vs.warp_nv12_nearest(fd, p, cw, ch).cpu().numpy()
+        assert np.array_equal(got, exp), (rv, int((got != exp).sum()))
+        assert (exp != oracle.warp_nv12(frame, p, cw, ch)).any()   # and it is not the bilinear result
+
+
 def test_fused_warp_golden(vs, cuda):
     kat = np.load(os.path.join(GOLD, "oracle_kat.npz"))
     seed, w, h = (int(v) for v in kat["warp_seed"])

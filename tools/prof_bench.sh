@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 TAG=${1:-bench}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="$R/bench.py --steps 8 --warmup 2 --no-cpu-baseline"
+ARGS="$R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --skip-copy-pass"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1

@@ -96,6 +96,7 @@ SIGNATURES = {
     "vstab_create_map": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _vp]),
     "vstab_remap_bilinear": (_i, [_vp, _sz, _i, _i, _i, _vp, _sz, _vp, _sz, _vp, _sz, _i, _i, _vp]),
     "vstab_warp_nv12_bgr": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _vp, _sz, _i, _i, _vp]),
+    "vstab_warp_nv12_nearest": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _vp, _sz, _i, _i, _vp]),
     "vstab_create_map_ex": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _vp]),
     "vstab_warp_nv12_ex": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
     "vstab_warp_nv12_rs": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _fp, _i, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
@@ -302,6 +303,17 @@ def warp_nv12_bgr(nv12, params, dw, dh, out=None):
         out = torch.empty((dh, dw, 3), dtype=torch.uint8, device=nv12.device)
     _check(_L.vstab_warp_nv12_bgr(yp, pitch, uvp, pitch, w, h, _fptr(p), out.data_ptr(), out.stride(0), dw, dh,
                                   _stream()), "vstab_warp_nv12_bgr")
+    return out
+
+
+def warp_nv12_nearest(nv12, params, dw, dh, out=None):
+    """vstab_warp_nv12_nearest: the fused warp with cv::remap's INTER_NEAREST."""
+    import torch
+    yp, uvp, pitch, w, h = _planes(nv12)
+    p = np.ascontiguousarray(params, np.float32)
+    if out is None:
+        out = torch.empty((dh, dw, 3), dtype=torch.uint8, device=nv12.device)
+    _check(_L.vstab_warp_nv12_nearest(yp, pitch, uvp, pitch, w, h, _fptr(p), out.data_ptr(), out.stride(0), dw, dh, _stream()), "vstab_warp_nv12_nearest")
     return out
 
 

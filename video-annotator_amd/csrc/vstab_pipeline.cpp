@@ -1290,7 +1290,10 @@ void vstab_config_default(vstab_config *cfg) {
 vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vstab_handle **out) {
     if (!cfg || !src || !out || !src->pull || !src->peek) return fail(VSTAB_ERR_INVALID, "vstab_create: null argument");
     if (cfg->smooth_radius < 0 || cfg->smooth_radius > 10000) return fail(VSTAB_ERR_INVALID, "vstab_create: bad smooth_radius");
-    if (cfg->interpolation != 1) return fail(VSTAB_ERR_INVALID, "vstab_create: only INTER_LINEAR is implemented (the only mode the reference passes)");
+    if (cfg->interpolation != 1 && cfg->interpolation != 0)
+        return fail(VSTAB_ERR_INVALID, "vstab_create: interpolation must be INTER_LINEAR (1, the only mode the reference passes) or INTER_NEAREST (0)");
+    if (cfg->interpolation == 0 && (cfg->lens_mode != 0 || cfg->pixel_depth == 10 || cfg->map_precision != VSTAB_MAP_PRECISION_IEEE))
+        return fail(VSTAB_ERR_INVALID, "vstab_create: INTER_NEAREST exists for the reference's own map (lens_mode 0, 8-bit pixels, IEEE map)");
     if (!(cfg->scale > 0) || !(cfg->zoom > 0)) return fail(VSTAB_ERR_INVALID, "vstab_create: scale and zoom must be positive");
     if (cfg->smoother < VSTAB_SMOOTHER_SG || cfg->smoother > VSTAB_SMOOTHER_FIXED) return fail(VSTAB_ERR_INVALID, "vstab_create: unknown smoother");
     if (cfg->lens_mode != 0 && cfg->lens_mode != 1) return fail(VSTAB_ERR_INVALID, "vstab_create: lens_mode must be 0 or 1");
@@ -1469,7 +1472,11 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         if (out_format == OUT_BGR16)
             st = vstab_warp_p010(S.y16, S.pitch_y16, S.uv16, S.pitch_uv16, H->w, H->h, p,
                                  S.have_readout ? p_bottom + 8 : nullptr, H->map_mode, H->cfg.blend, dst, pitch_dst, H->ow, H->oh, H->stream);
-        else if (cached)
+        else if (H->cfg.interpolation == 0) {
+            (void)take_launch_events();
+            if (out_format != VSTAB_OUT_BGR8 || S.have_readout) st = fail(VSTAB_ERR_INVALID, "INTER_NEAREST emits 8-bit BGR frames without a read-out rotation");
+            else st = vstab_warp_nv12_nearest(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, p, dst, pitch_dst, H->ow, H->oh, H->stream);
+        } else if (cached)
             st = vstab_warp_nv12_mapped(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, H->qmap.p, out_format, dst, pitch_dst, dst_uv, pitch_dst_uv,
                                         H->ow, H->oh, H->stream);
         else if (S.have_readout)

@@ -270,6 +270,24 @@ __global__ void __launch_bounds__(256) k_warp_nv12_bgr(WarpArgs a, int vec_ok) {
     }
 }
 
+// k_warp_nearest -- the fused warp with cv::remap's INTER_NEAREST (FrameSourceWarp.hpp:90 admits the flag, :311 passes it
+// on; the reference itself only ever passes INTER_LINEAR): createMap.cl's map, cvRound (half to even) + saturate_cast<short>
+// per coordinate, ONE tap converted with the cvtColor arithmetic, 0 outside the source.  Direct gather: this mode is
+// about completeness, the bilinear kernel carries the rate.
+__global__ void __launch_bounds__(256) k_warp_nearest(WarpArgs a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.dw || y >= a.dh) return;
+    float mx, my;
+    map_pixel(a.p, col_term(a.p, x), row_term(a.p, y), mx, my);
+    // cvRound -> int (NaN / out of range: INT_MIN on x86), then saturate_cast<short>
+    const bool far = !(fabsf(mx) < 2147483520.0f) || !(fabsf(my) < 2147483520.0f);
+    const int sx = far ? -32768 : min(max((int)__builtin_rintf(mx), -32768), 32767), sy = far ? -32768 : min(max((int)__builtin_rintf(my), -32768), 32767);
+    int b, g, r;
+    fetch_tap(a, sx, sy, b, g, r);
+    uint8_t *o = a.dst + (size_t)y * a.pitch_dst + (size_t)x * 3;
+    o[0] = (uint8_t)b, o[1] = (uint8_t)g, o[2] = (uint8_t)r;
+}
+
 // k_quantised_map -- the map of every output pixel as cv::remap quantises it (32 * map rounded half to even; a NaN
 // entry gets x = INT_MIN), written once for a run of frames that share their warp parameters (see CACHED above).
 // The map arithmetic of k_warp_fused; its cvRound is the plain formulation (rint, NaN -> INT_MIN).
@@ -570,6 +588,23 @@ vstab_status vstab_warp_nv12_mapped(const void *y, size_t pitch_y, const void *u
     static const float unused[17] = {0};
     return warp_impl(y, pitch_y, uv, pitch_uv, sw, sh, unused, VSTAB_MAP_CREATEMAP_CL, out_format, dst, pitch_dst, dst_uv, pitch_dst_uv, dw, dh, stream,
                      qmap, (dw + 3) & ~3);
+}
+
+vstab_status vstab_warp_nv12_nearest(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh, const float params[17],
+                                     void *dst, size_t pitch_dst, int dw, int dh, void *stream) {
+    if (!y || !uv || !dst || !params) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_nearest: null pointer");
+    if (sw <= 0 || sh <= 0 || (sw & 1) || (sh & 1) || sw > 32767 || sh > 32767 || dw <= 0 || dh <= 0 || dw > 32767 || dh > 32767)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_nearest: sizes must be in [1, 32767], source even");
+    if (pitch_y < (size_t)sw || pitch_uv < (size_t)sw || pitch_dst < (size_t)dw * 3 || !aligned(uv, 2) || pitch_uv % 2)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_nearest: bad pitch or chroma alignment");
+    WarpArgs a;
+    a.y = (const uint8_t *)y, a.uv = (const uint8_t *)uv, a.dst = (uint8_t *)dst, a.dst_uv = nullptr;
+    a.pitch_y = pitch_y, a.pitch_uv = pitch_uv, a.pitch_dst = pitch_dst, a.pitch_dst_uv = 0;
+    a.sw = sw, a.sh = sh, a.dw = dw, a.dh = dh;
+    a.p = to_params(params);
+    hipLaunchKernelGGL(k_warp_nearest, dim3(div_up(dw, 64), div_up(dh, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
 }
 
 vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh,
