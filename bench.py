@@ -521,6 +521,7 @@ def main():
             if args.ingest == "inplace" and not p010 and world == 1 and not args.skip_copy_pass:
                 # what a decoder that recycles its surface gives: hold = 0, every frame through vstab_pack_nv12 into the ring
                 # (untimed region; a short run of its own: pre-roll 200 frames, 10 batches)
+                stab.close()  # two handles alive = eight streams on the runtime's four hardware queues, which slows both
                 cstab = vs.Stabilizer(clip, total=600 + 10 * args.batch + 100, preset=preset, smooth_radius=30, seed=1234 + rank,
                                       tracking=0 if args.no_tracking else 1, ring_hold=0, **extra)
                 cpull = (lambda i: cstab.pull_nv12_into(*outs[i % args.ring])) if nv12_out else (lambda i: cstab.pull_into(outs[i % args.ring]))
