@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if os.environ.get("QDEV"):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import devlib
-    vs = devlib.load()
+    vs = devlib.load(None if os.environ["QDEV"] == "1" else os.environ["QDEV"])   # QDEV=1: the development build; QDEV=<path>: that build
 else:
     vs = importlib.import_module("video-annotator_amd")
 w, h = int(os.environ.get("QW", 3840)), int(os.environ.get("QH", 2160))
