@@ -841,6 +841,43 @@ def test_long_bench_shaped_run_1080p(vs, cuda):
     _bench_shaped_run(vs, cuda, 1920, 1080, 30, 160, 7)
 
 
+def test_record_handoff_stress_three_runs_of_6000_frames_agree(vs, cuda):
+    """The tracker's results reach the host (and the next chained launch) as self-tagged 8-byte granules with no fence
+    (argued, never stress-verified).  Stress: the bench's 1080p pipeline over 6000
+    frames -- 6000 chained launches x 200 records, speculative detections, helper threads -- three times over the same
+    clip.  A torn or stale record anywhere would move a point, hence a rotation; a decision taken on a different schedule
+    would move a key frame.  Every run must report the same key frames, the same track / inlier counts and bit-identical
+    rotations for every frame, and the same output bytes for every 97th frame."""
+    import torch
+    import zlib
+    import bench
+    w, h, n = 1920, 1080, 6000
+    K = oracle.get_preset_camera(4, w, h)
+    dev_frames, _ = bench.shaky_ring(torch, cuda, w, h, K, 64, seed=9)
+    runs = []
+    for _ in range(3):
+        stab = vs.Stabilizer(dev_frames, total=n, smooth_radius=30, seed=321)
+        crcs, rots, i = [], [], 0
+        while True:
+            o = stab.pull()
+            if o is None:
+                break
+            if i % 97 == 0:
+                crcs.append(zlib.crc32(o.cpu().numpy().tobytes()))
+            rots.append(stab.warp_rotation(i).copy())
+            i += 1
+        assert i == n - 1
+        log = stab.frame_log()
+        runs.append((crcs, np.stack(rots), [(e["key"], e["n_corners"], e["n_tracked"], e["inliers"]) for e in log]))
+        stab.close()
+    keys = sum(1 for e in runs[0][2] if e[0])
+    assert keys >= 270, keys   # the > 20 frames rule fires about every 20th pair
+    for r in runs[1:]:
+        assert r[2] == runs[0][2]
+        assert np.array_equal(r[1], runs[0][1])
+        assert r[0] == runs[0][0]
+
+
 def test_bench_shaped_run_4k_config_3(vs, cuda):
     """BASELINE config 3 at its own size through the whole pipeline object: 4K, smooth_radius 30, 52 frames of the bench's
     clip, frames used in place, chained tracker launches through two counter-triggered key frames and their speculative
