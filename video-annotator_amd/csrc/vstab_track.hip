@@ -580,26 +580,35 @@ __device__ __forceinline__ void lk_block_sums(LkExchange &ex, int parity, int wa
 // workgroup per CU: exposed latency is what it is made of (measured: staging was half of a workgroup's time).
 template <int SIDE>
 struct LkStage {
-    static constexpr int N = (SIDE * SIDE + LK_THREADS - 1) / LK_THREADS;
-    int v[N];
+    // SIDE x SIDE bytes as SIDE * SIDE / 4 dwords: a thread fetches FOUR consecutive pixels of a row with one (unaligned)
+    // dword load and writes them to LDS as four ints with one 16-byte store -- a quarter of the loads, index arithmetic and LDS
+    // stores of the byte-by-byte form it replaces (which is kept for blocks that touch the image border: REFLECT_101 per byte).
+    static_assert(SIDE % 4 == 0, "rows are split into dwords");
+    static constexpr int ROWW = SIDE / 4, NW = SIDE * ROWW, N = (NW + LK_THREADS - 1) / LK_THREADS;
+    uint32_t v[N];
     __device__ __forceinline__ void load(const uint8_t *img, uint32_t pitch, int w, int h, int x0, int y0, int tid) {
-        const bool interior = x0 >= 0 && y0 >= 0 && x0 + SIDE <= w && y0 + SIDE <= h;
+        const bool interior = x0 >= 0 && y0 >= 0 && x0 + SIDE <= w && y0 + SIDE <= h;  // uniform
 #pragma unroll
         for (int k = 0; k < N; k++) {
             const int e = tid + LK_THREADS * k;
             v[k] = 0;
-            if (e < SIDE * SIDE) {
-                const int ry = e / SIDE, rx = e - ry * SIDE;
-                v[k] = interior ? img[(uint32_t)(y0 + ry) * pitch + (uint32_t)(x0 + rx)]
-                                : img[(uint32_t)reflect101(y0 + ry, h) * pitch + (uint32_t)reflect101(x0 + rx, w)];
+            if (e < NW) {
+                const int ry = e / ROWW, rx = 4 * (e - ry * ROWW);
+                if (interior) {
+                    __builtin_memcpy(&v[k], img + (uint32_t)(y0 + ry) * pitch + (uint32_t)(x0 + rx), 4);  // one global_load_dword (any alignment)
+                } else {
+                    const uint8_t *row = img + (uint32_t)reflect101(y0 + ry, h) * pitch;
+                    v[k] = (uint32_t)row[reflect101(x0 + rx, w)] | ((uint32_t)row[reflect101(x0 + rx + 1, w)] << 8) |
+                           ((uint32_t)row[reflect101(x0 + rx + 2, w)] << 16) | ((uint32_t)row[reflect101(x0 + rx + 3, w)] << 24);
+                }
             }
         }
     }
-    __device__ __forceinline__ void store(int *dst, int tid) const {
+    __device__ __forceinline__ void store(int *dst, int tid) const {  // dst 16-byte aligned
 #pragma unroll
         for (int k = 0; k < N; k++) {
             const int e = tid + LK_THREADS * k;
-            if (e < SIDE * SIDE) dst[e] = v[k];
+            if (e < NW) *reinterpret_cast<int4 *>(dst + 4 * e) = make_int4((int)(v[k] & 255u), (int)((v[k] >> 8) & 255u), (int)((v[k] >> 16) & 255u), (int)(v[k] >> 24));
         }
     }
 };
