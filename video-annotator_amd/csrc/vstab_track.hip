@@ -946,6 +946,7 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkPyramid I, LkPyram
         // the level before this one; the next level's first barrier publishes it)
         LK_STAMP(4 + 3 * (max_level - level), LK_NOW());
         LK_STAMP(5 + 3 * (max_level - level), (unsigned long long)n_iter);
+        (void)n_iter;  // read by the development build's stamps only
         jb ^= 1;
         jorg_x = nx0, jorg_y = ny0;
         if (nx0 != INT_MIN / 2) sn.store(regJ[jb], tid);
