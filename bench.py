@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--map-precision", default="ieee", choices=["ieee", "opencl"],
                     help="ieee = createMap.cl with every operation IEEE-rounded (CPU-reproducible, the default); opencl = the arithmetic of "
                          "the reference's own kernel as ROCm's OpenCL compiler builds it for gfx950 (bit-identical to that code object)")
+    ap.add_argument("--pull", choices=("batch", "single"), default="single",
+                    help="pipeline mode, BGR output: one vstab_pull_frame call per frame from this Python loop (default), or one "
+                         "vstab_pull_frames call per step (the consumer's loop in C, as the reference's DisplayImage.cpp runs it); "
+                         "measured equal within the run-to-run noise at 4K (DESIGN.md section 6)")
     ap.add_argument("--skip-copy-pass", action="store_true",
                     help="leave out the extra copy-ingest pass behind the timed region (used when the command runs under rocprofv3, so that the "
                          "kernel population of the trace is the timed pipeline's)")
@@ -413,17 +417,30 @@ def main():
             workload = (f"4k P010 {w}x{h} -> BGR 16-bit (10 significant) {cw}x{ch}, BASELINE config 5: full pipeline on the narrowed luma (corner detect, "
                         "pyramidal LK, rotation estimate, SG r=30), 10-bit undistort-remap with fp16 blend and a rotation per output row")
 
+    # pipeline mode, BGR frames: a step is ONE library call that pulls the step's batch of frames into the output ring
+    # (vstab_pull_frames: the consumer's frame loop on the C side of the boundary, where the reference has it)
+    batched = mode == "pipeline" and args.pull == "batch" and not nv12_out and not p010
+    if batched:
+        def run_steps(first_frame, n_steps, timed):
+            for k in range(n_steps):
+                i0 = first_frame + k * args.batch
+                if timed and k == 0:
+                    stab.profile()               # fold + discard the warm-up stages
+                    stab._prof0 = stab.profile()
+                assert stab.pull_frames_into(outs, i0, args.batch) == args.batch
+    else:
+        def run_steps(first_frame, n_steps, timed):
+            for i in range(first_frame, first_frame + n_steps * args.batch):
+                step(i, timed)
     for i in range(preroll):  # pipeline mode: untimed, ahead of the warm-up the driver asks for
         assert pull(i)
-    for i in range(n_warm):
-        step(i, False)
+    run_steps(0, args.warmup, False)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(n_warm, n_warm + n_timed):
-        step(i, True)
+    run_steps(n_warm, args.steps, True)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -567,6 +584,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": ("u10 pixels (fp16 blend)" if p010 else "u8 pixels") + " / f32 map / f64 rotations", "data": "synthetic",
             "config": {"workload": workload, "mode": mode, "clips": len(records), "ring_frames": args.ring, "frames_per_step": args.batch,
+                       "frame_loop": ("vstab_pull_frames: one call per step" if batched else "vstab_pull_frame per frame from Python") if mode == "pipeline" else None,
                        "preset": "GOPRO_H4B_WIDE169_MEASURED", "parallelism": f"clip-per-gpu x{world}"},
             "preroll": preroll, "parity_check": parity, "rank_cpus": pinned,
             "collectives": args.dist_backend if use_dist else None,

@@ -411,6 +411,12 @@ VSTAB_API vstab_status vstab_get_output_info(const vstab_handle *h, int *width, 
  * Read-ahead: to overlap copy, pyramid, corner detection and tracking with the host work, the library pulls
  * upstream up to nine frames earlier than the reference's loop would (same frames, same order, same outputs). */
 VSTAB_API vstab_status vstab_pull_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
+/* The consumer's loop (DisplayImage.cpp:60-70: `while (true) { frame = source.pull_frame(); ... }`) as one call: n consecutive
+ * vstab_pull_frame calls, frame i into dst[(first + i) % n_dst] with pitch[(first + i) % n_dst] -- an encoder's ring of output
+ * surfaces.  Stops at the first call that does not return VSTAB_OK and returns its status (VSTAB_EOF at end of stream);
+ * *n_done (may be NULL) = frames emitted.  Nothing else differs from calling vstab_pull_frame n times. */
+VSTAB_API vstab_status vstab_pull_frames(vstab_handle *h, int n, void *const *dst_bgr, const size_t *pitch_dst, int n_dst, int first,
+                                         int *n_done);
 /* pull_frame with NV12 output for the encoder hand-off (render.ts:275-281): the same frame,
  * converted as vstab_warp_nv12_ex(VSTAB_OUT_NV12) defines.  dst_y: width bytes per row; dst_uv: ceil(height/2) rows
  * of 2*ceil(width/2) bytes.  BGR and NV12 pulls may be mixed freely on one handle. */

@@ -129,6 +129,28 @@ def test_nearest_interpolation_through_the_pipeline(vs, cuda, clip):
         vs.Stabilizer(one, total=1, interpolation=0, lens_mode=1)
 
 
+def test_pull_frames_is_the_frame_loop_in_one_call(vs, cuda, clip):
+    """vstab_pull_frames (the consumer's loop of DisplayImage.cpp:60-70 on the C side) == vstab_pull_frame called n times:
+    same frames in the same ring slots, the count at end of stream, EOF afterwards."""
+    import torch
+    K, frames, _ = clip
+    ref, outs = run_product(vs, cuda, frames[:12], smooth_radius=2)
+    stab = vs.Stabilizer([torch.from_numpy(f).to(cuda) for f in frames[:12]], total=12, smooth_radius=2)
+    cw, ch = stab.out_size
+    ring = [torch.zeros((ch, cw, 3), dtype=torch.uint8, device=cuda) for _ in range(4)]
+    assert stab.pull_frames_into(ring, 0, 3) == 3
+    for i in range(3):
+        assert np.array_equal(ring[i].cpu().numpy(), outs[i])
+    assert stab.pull_frames_into(ring, 3, 4) == 4          # wraps: frames 3..6 into slots 3, 0, 1, 2
+    for i in range(3, 7):
+        assert np.array_equal(ring[i % 4].cpu().numpy(), outs[i])
+    assert stab.pull_frames_into(ring, 7, 100) == len(outs) - 7   # runs into the end of the stream
+    assert np.array_equal(ring[(len(outs) - 1) % 4].cpu().numpy(), outs[-1])
+    assert stab.pull_frames_into(ring, 0, 1) == 0
+    for i in range(len(outs)):
+        assert np.array_equal(stab.warp_rotation(i), ref.warp_rotation(i))
+
+
 def test_python_callback_source_eof_and_errors(vs, cuda, clip):
     import torch
     K, frames, _ = clip

@@ -123,6 +123,7 @@ SIGNATURES = {
     "vstab_create": (_i, [_c.POINTER(Config), _c.POINTER(Source), _pp]),
     "vstab_get_output_info": (_i, [_vp, _ip, _ip, _dp, _dp]),
     "vstab_pull_frame": (_i, [_vp, _vp, _sz]),
+    "vstab_pull_frames": (_i, [_vp, _i, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t), _i, _i, _c.POINTER(_c.c_int)]),
     "vstab_pull_frame_nv12": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "vstab_pull_frame_host": (_i, [_vp, _vp, _sz]),
     "vstab_lens_camera": (_i, [_i, _d, _i, _i, _d, _d, _dp]),
@@ -597,6 +598,20 @@ class Stabilizer:
             return False
         _check(st, "vstab_pull_frame")
         return True
+
+    def pull_frames_into(self, outs, first, n):
+        """vstab_pull_frames: n frames in one call, frame i into outs[(first + i) % len(outs)].  Returns the number emitted
+        (fewer than n at end of stream)."""
+        ring = getattr(self, "_out_ring", None)
+        if ring is None or ring[0] is not outs:
+            ptrs = (_c.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+            pitches = (_c.c_size_t * len(outs))(*[o.stride(0) for o in outs])
+            ring = self._out_ring = (outs, ptrs, pitches)
+        done = _c.c_int(0)
+        st = _L.vstab_pull_frames(self._h, int(n), ring[1], ring[2], len(outs), int(first) % len(outs), _c.byref(done))
+        if st != EOF:
+            _check(st, "vstab_pull_frames")
+        return done.value
 
     def pull(self):
         import torch

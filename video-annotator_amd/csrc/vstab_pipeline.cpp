@@ -1541,6 +1541,18 @@ vstab_status vstab_pull_frame(vstab_handle *h, void *dst, size_t pitch_dst) {
     return pull_frame_impl(h, VSTAB_OUT_BGR8, dst, pitch_dst, nullptr, 0);
 }
 
+vstab_status vstab_pull_frames(vstab_handle *h, int n, void *const *dst, const size_t *pitch_dst, int n_dst, int first, int *n_done) {
+    if (n_done) *n_done = 0;
+    if (!h || !dst || !pitch_dst || n < 0 || n_dst <= 0 || first < 0) return fail(VSTAB_ERR_INVALID, "vstab_pull_frames: bad argument");
+    for (int i = 0; i < n; i++) {
+        const int k = (int)(((long)first + i) % n_dst);
+        const vstab_status st = pull_frame_impl(h, VSTAB_OUT_BGR8, dst[k], pitch_dst[k], nullptr, 0);
+        if (st != VSTAB_OK) return st;
+        if (n_done) *n_done = i + 1;
+    }
+    return VSTAB_OK;
+}
+
 vstab_status vstab_pull_frame_host(vstab_handle *h, void *dst, size_t pitch_dst) {
     if (!h || !dst || pitch_dst < (size_t)h->ow * 3) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame_host: bad argument");
     const size_t dpitch = ((size_t)h->ow * 3 + 255) & ~(size_t)255;

@@ -47,8 +47,14 @@ namespace vstab {
 #ifndef VSTAB_WARP_WAVES
 #define VSTAB_WARP_WAVES 7
 #endif
-constexpr int MAP_GROUP = 2;  // row pairs whose exact-map chains advance in lock-step
-constexpr int TAP_GROUP = 4;  // output rows whose LDS tap reads are issued before the first blend
+#ifndef VSTAB_MAP_GROUP
+#define VSTAB_MAP_GROUP 2
+#endif
+#ifndef VSTAB_TAP_GROUP
+#define VSTAB_TAP_GROUP 4
+#endif
+constexpr int MAP_GROUP = VSTAB_MAP_GROUP;  // row pairs whose exact-map chains advance in lock-step
+constexpr int TAP_GROUP = VSTAB_TAP_GROUP;  // output rows whose LDS tap reads are issued before the first blend
 constexpr float QMAGIC = 12582912.0f;
 constexpr int QMAGIC_BITS = 0x4B400000;
 
