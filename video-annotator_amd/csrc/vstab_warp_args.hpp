@@ -31,6 +31,7 @@ struct FusedArgs {
 #ifdef VSTAB_DEV
     unsigned long long *timing;  // development builds: 4 qwords per workgroup {memrealtime, memtime at entry and exit}
     int ablate;                  // timing-only ablations (wrong pixels): 1 linear map, 2 xor blend, 4 raw conversion, 8 no stores
+    int lds_pad;                 // experiment: dwords added to the LDS row pitch of the staged box (multiple of 4)
 #endif
 };
 

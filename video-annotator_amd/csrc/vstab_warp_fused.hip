@@ -177,7 +177,11 @@ __device__ __forceinline__ void probe_tile(const FusedArgs &ta, int x0, int y0, 
     // staged as whole 8 x 2 blocks with aligned 8-byte loads: unaligned planes, and boxes that reach the last,
     // partial block column of a source whose width is not a multiple of 8, are sampled straight from global memory
     const bool stageable = have && a.sw >= 8 && ta.src_vec_ok && ((a.sw & 7) == 0 || bx0 + wb <= (a.sw & ~7));
+#ifdef VSTAB_DEV
+    const bool fits = (wb + ta.lds_pad) * hb <= ta.lds_capacity_px && (wb >> 3) * (hb >> 1) <= STAGE_MAX * 256;  // experiment: padded LDS rows
+#else
     const bool fits = wb * hb <= ta.lds_capacity_px && (wb >> 3) * (hb >> 1) <= STAGE_MAX * 256;
+#endif
     if (lane == 0) {
         *reinterpret_cast<uint4 *>(hdr) = make_uint4((uint32_t)bx0, (uint32_t)by0, (uint32_t)wb, (uint32_t)hb);
         hdr[4] = stageable ? (fits ? 1u : 2u) : 0u;  // 2: the box is over the LDS budget -- a tall tile is then done as two half-height tiles
@@ -341,6 +345,11 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
 
     // ---- load: this thread's 8x2 blocks of the box, all loads in flight at once --------------------------------
     const int ux_n = wb >> 3, units = use_lds ? ux_n * (hb >> 1) : 0;
+#ifdef VSTAB_DEV
+    const int pw = wb + ta.lds_pad;  // LDS row pitch in dwords (development experiment: pad against bank conflicts)
+#else
+    const int pw = wb;               // LDS row pitch in dwords
+#endif
     SrcVec y0w[STAGE_MAX], y1w[STAGE_MAX], uvw[STAGE_MAX];
     int ldsoff[STAGE_MAX];  // dword offset of the block in the LDS tile (| ZERO_BLOCK: outside the source); -1 = no block
     constexpr int ZERO_BLOCK = 1 << 24;
@@ -373,7 +382,7 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
             y0w[it] = *reinterpret_cast<const SrcVec *>(a.y + oy);
             y1w[it] = *reinterpret_cast<const SrcVec *>(a.y + oy + pitch_y);
             uvw[it] = *reinterpret_cast<const SrcVec *>(a.uv + ouv);
-            ldsoff[it] = valid ? (__mul24(2 * uy, wb) + 8 * ux) | (inside ? 0 : ZERO_BLOCK) : -1;
+            ldsoff[it] = valid ? (__mul24(2 * uy, pw) + 8 * ux) | (inside ? 0 : ZERO_BLOCK) : -1;
             ux += sx_, uy += sy_;
             if (ux >= ux_n) ux -= ux_n, uy++;
         }
@@ -509,14 +518,14 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
                 uint32_t *d = tile + (ldsoff[it] - ZERO_BLOCK);
                 const uint4 z = make_uint4(0, 0, 0, 0);
                 *reinterpret_cast<uint4 *>(d) = z, *reinterpret_cast<uint4 *>(d + 4) = z;
-                *reinterpret_cast<uint4 *>(d + wb) = z, *reinterpret_cast<uint4 *>(d + wb + 4) = z;
+                *reinterpret_cast<uint4 *>(d + pw) = z, *reinterpret_cast<uint4 *>(d + pw + 4) = z;
 #ifdef VSTAB_DEV
             } else if (DEPTH == 8 && ldsoff[it] >= 0 && (ta.ablate & 4)) {
                 uint32_t *d = tile + ldsoff[it];
                 *reinterpret_cast<uint4 *>(d) = make_uint4(y0w[it].x, y0w[it].y, uvw[it].x, uvw[it].y);
                 *reinterpret_cast<uint4 *>(d + 4) = make_uint4(y0w[it].y, y0w[it].x, uvw[it].x, uvw[it].y);
-                *reinterpret_cast<uint4 *>(d + wb) = make_uint4(y1w[it].x, y1w[it].y, uvw[it].x, uvw[it].y);
-                *reinterpret_cast<uint4 *>(d + wb + 4) = make_uint4(y1w[it].y, y1w[it].x, uvw[it].y, uvw[it].x);
+                *reinterpret_cast<uint4 *>(d + pw) = make_uint4(y1w[it].x, y1w[it].y, uvw[it].x, uvw[it].y);
+                *reinterpret_cast<uint4 *>(d + pw + 4) = make_uint4(y1w[it].y, y1w[it].x, uvw[it].y, uvw[it].x);
 #endif
             } else if (ldsoff[it] >= 0) {
                 uint32_t *d = tile + ldsoff[it];
@@ -533,7 +542,7 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
                         r1.x = pack_bgr10((int)((yb[2 * half] & 0xffffu) >> 6), c0), r1.y = pack_bgr10((int)(yb[2 * half] >> 22), c0);
                         r1.z = pack_bgr10((int)((yb[2 * half + 1] & 0xffffu) >> 6), c1), r1.w = pack_bgr10((int)(yb[2 * half + 1] >> 22), c1);
                         *reinterpret_cast<uint4 *>(d + 4 * half) = r0;
-                        *reinterpret_cast<uint4 *>(d + wb + 4 * half) = r1;
+                        *reinterpret_cast<uint4 *>(d + pw + 4 * half) = r1;
                     }
                 } else
 #pragma unroll
@@ -547,7 +556,7 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
                     r1.x = pack_bgrx(yb & 255, c0), r1.y = pack_bgrx((yb >> 8) & 255, c0);
                     r1.z = pack_bgrx((yb >> 16) & 255, c1), r1.w = pack_bgrx(yb >> 24, c1);
                     *reinterpret_cast<uint4 *>(d + 4 * half) = r0;
-                    *reinterpret_cast<uint4 *>(d + wb + 4 * half) = r1;
+                    *reinterpret_cast<uint4 *>(d + pw + 4 * half) = r1;
                 }
             }
         }
@@ -563,7 +572,7 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
         const int cx = bx0 + (QB >> 5), cy = by0 + (QB >> 5);
         const uint32_t wlim = use_lds ? (uint32_t)(wb - 1) : 0u, hlim = (uint32_t)(hb - 1);  // both taps of each axis inside the staged box
         int Xr[RW], Yr[RW];
-        const uint32_t wb4 = (uint32_t)wb << 2;
+        const uint32_t wb4 = (uint32_t)pw << 2;
         uint32_t mxx = 0, mxy = 0;  // as unsigned: a coordinate left of / above the box is huge
 #pragma unroll
         for (int j = 0; j < RW; j++) {
@@ -603,9 +612,9 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
                 const bool inbox = (uint32_t)Xr[j] < wlim && (uint32_t)Yr[j] < hlim;
                 uint32_t v = 0;
                 if (inbox) {
-                    const uint32_t *t = tile + (__mul24(Yr[j], wb) + Xr[j]);
-                    v = DEPTH == 10 ? blend_bgr10<BLEND>(t[0], t[1], t[wb], t[wb + 1], qxb[j] & 31, qyb[j] & 31)
-                                    : blend_bgrx(t[0], t[1], t[wb], t[wb + 1], qxb[j] & 31, qyb[j] & 31);
+                    const uint32_t *t = tile + (__mul24(Yr[j], pw) + Xr[j]);
+                    v = DEPTH == 10 ? blend_bgr10<BLEND>(t[0], t[1], t[pw], t[pw + 1], qxb[j] & 31, qyb[j] & 31)
+                                    : blend_bgrx(t[0], t[1], t[pw], t[pw + 1], qxb[j] & 31, qyb[j] & 31);
                 }
                 out[j] = v;
                 const bool live = col_live && y0 + wave * RW + j < a.dh;
@@ -805,7 +814,7 @@ vstab_status launch_warp_fused10(const WarpArgs &a, const float params[17], int 
     for (int k = 0; k < 9; k++) ta.rs_d[k] = rot_bottom ? rot_bottom[k] - params[8 + k] : 0.0f;
     ta.rs_den = (float)(a.dh > 1 ? a.dh - 1 : 1);
 #ifdef VSTAB_DEV
-    ta.timing = nullptr, ta.ablate = 0;
+    ta.timing = nullptr, ta.ablate = 0, ta.lds_pad = 0;
 #endif
     const int lds_kb = 40;
     const long tiles = (long)div_up(a.dw, 64) * div_up(a.dh, 32);
@@ -849,6 +858,7 @@ vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int ma
     ta.timing = g_dev_timing;
     static const int ablate = getenv("VSTAB_ABLATE") ? atoi(getenv("VSTAB_ABLATE")) : 0;
     ta.ablate = ablate;
+    ta.lds_pad = getenv("VSTAB_LDS_PAD") ? atoi(getenv("VSTAB_LDS_PAD")) & ~3 : 0;
 #endif
     // Tile shape: 64 x 32 output pixels and 40 KB of LDS (4 workgroups per CU) when that gives the 1024 workgroup
     // slots of the chip a few rounds of tiles; 64 x 16 with 20 KB (8 per CU: 2048 slots, a 1080p output in ONE round)
