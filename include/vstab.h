@@ -184,6 +184,12 @@ VSTAB_API vstab_status vstab_warp_p010(const void *y, size_t pitch_y, const void
                                        int map_mode, int blend, void *dst_bgr16, size_t pitch_dst, int dst_width,
                                        int dst_height, void *stream);
 
+/* The 10-bit path's encoder hand-off: BGR as vstab_warp_p010 writes it -> P010 planes (16-bit samples, significant bits at the top;
+ * chroma interleaved U, V, ceil(w/2) x ceil(h/2) pairs, from the top-left pixel of each 2 x 2 block).  The BGR -> YUV arithmetic of the
+ * NV12 output (cvtColor's BT.601 constants) at 10 bits, offsets 64 / 512; defined in the oracle (vo_cvt_bgr10_p010).  Pitches in bytes. */
+VSTAB_API vstab_status vstab_cvt_bgr16_p010(const void *src_bgr16, size_t pitch_src, int width, int height, void *dst_y, size_t pitch_y,
+                                            void *dst_uv, size_t pitch_uv, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Tracking front-end (device images in; small point lists on the host, as in the reference where
  * goodFeaturesToTrack / calcOpticalFlowPyrLK return std::vector<Point2f>).  These calls
@@ -428,6 +434,9 @@ VSTAB_API vstab_status vstab_pull_frame_host(vstab_handle *h, void *dst_bgr_host
 /* pull_frame of a handle created with pixel_depth = 10: device BGR, three 16-bit samples per pixel (values 0..1023),
  * pitch_dst in bytes, >= 6 * width and even.  The 8-bit pull functions refuse such a handle and vice versa. */
 VSTAB_API vstab_status vstab_pull_frame_bgr16(vstab_handle *h, void *dst_bgr16, size_t pitch_dst);
+/* pull_frame of a pixel_depth = 10 handle as P010 planes for a 10-bit encoder (the counterpart of vstab_pull_frame_nv12): the frame is
+ * warped into a 16-bit BGR buffer of the handle and converted by vstab_cvt_bgr16_p010 (not fused yet: 63 MB of extra traffic per 4K frame). */
+VSTAB_API vstab_status vstab_pull_frame_p010(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv);
 /* FrameSourceWarp::peek_frame (:478-480) IS pull_frame in the reference (destructive); kept. */
 VSTAB_API vstab_status vstab_peek_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
 VSTAB_API void vstab_destroy(vstab_handle *h);

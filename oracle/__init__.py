@@ -62,6 +62,7 @@ def lib():
         L.vo_atanf_max_ulp.restype = c.c_double
         L.vo_create_map.argtypes = [f32p, f32p, c.c_int, c.c_int, f32p]
         L.vo_remap_bilinear.argtypes = [u8p, c.c_int, c.c_int, c.c_int, f32p, f32p, u8p, c.c_int, c.c_int]
+        L.vo_cvt_bgr10_p010.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_void_p, c.c_void_p]
         L.vo_remap_nearest.argtypes = [u8p, c.c_int, c.c_int, c.c_int, f32p, f32p, u8p, c.c_int, c.c_int]
         L.vo_warp_nv12_reference_path.argtypes = [u8p, c.c_int, c.c_int, f32p, u8p, c.c_int, c.c_int, u8p]
         L.vo_sincosf_array.argtypes = [f32p, f32p, f32p, c.c_long]
@@ -386,6 +387,16 @@ def warp_p010(y, uv, params, dw, dh, rot_bottom=None, mode=0, blend=0):
                        ctypes.c_size_t(ua.strides[0]), w, h, pp, None if rb is None else _p(rb, ctypes.c_float), int(mode), int(blend),
                        out.ctypes.data_as(ctypes.c_void_p), dw, dh, _p(work, ctypes.c_uint8))
     return out
+
+
+def cvt_bgr10_p010(bgr):
+    """(h, w, 3) uint16 BGR, values 0..1023 -> ((h, w) uint16 P010 luma, (ceil(h/2), 2 * ceil(w/2)) uint16 interleaved chroma)."""
+    b = np.ascontiguousarray(bgr, np.uint16)
+    h, w = b.shape[:2]
+    y = np.empty((h, w), np.uint16)
+    uv = np.empty(((h + 1) // 2, 2 * ((w + 1) // 2)), np.uint16)
+    lib().vo_cvt_bgr10_p010(b.ctypes.data_as(ctypes.c_void_p), w, h, y.ctypes.data_as(ctypes.c_void_p), uv.ctypes.data_as(ctypes.c_void_p))
+    return y, uv
 
 
 def cvt_p010_bgr10(y, uv):

@@ -397,6 +397,29 @@ VO_API void vo_cvt_bgr_nv12(const uint8_t *bgr, int w, int h, uint8_t *yp, uint8
     }
 }
 
+/* 10-bit BGR (values 0..1023 in 16-bit containers) -> P010 (16-bit samples, the 10 significant bits at the top; chroma interleaved
+ * U, V at half resolution from the top-left pixel of each 2 x 2 block): vo_cvt_bgr_nv12's arithmetic at 10 bits -- the same
+ * BT.601 constants and 20-bit shift, offsets 64 / 512, saturation to [0, 1023].  DEFINED here (config 5's encoder hand-off has no
+ * reference counterpart).  All sums fit int32: 1023 * (CRY + CGY + CBY) + (64 << 20) + (1 << 19) < 2^30. */
+static inline int vo_sat10i(int v) { return v < 0 ? 0 : v > 1023 ? 1023 : v; }
+VO_API void vo_cvt_bgr10_p010(const uint16_t *bgr, int w, int h, uint16_t *yp, uint16_t *uvp) {
+    const int half = 1 << 19, s64 = 64 << 20, s512 = 512 << 20;
+    const int cw = (w + 1) / 2;
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < h; r++) {
+        const uint16_t *row = bgr + (size_t)r * w * 3;
+        for (int c = 0; c < w; c++) {
+            const int B = row[3 * c], G = row[3 * c + 1], R = row[3 * c + 2];
+            yp[(size_t)r * w + c] = (uint16_t)(vo_sat10i((VO_CRY * R + VO_CGY * G + VO_CBY * B + half + s64) >> 20) << 6);
+            if (!(r & 1) && !(c & 1)) {
+                uint16_t *o = uvp + ((size_t)(r >> 1) * cw + (c >> 1)) * 2;
+                o[0] = (uint16_t)(vo_sat10i((VO_CRU * R + VO_CGU * G + VO_CBU * B + half + s512) >> 20) << 6);
+                o[1] = (uint16_t)(vo_sat10i((VO_CBU * R + VO_CGV * G + VO_CBV * B + half + s512) >> 20) << 6);
+            }
+        }
+    }
+}
+
 /* the generalised warp as a reference-style chain: cvtColor, map planes (mode), remap,
  * optional BGR -> NV12.  out_format 0: dst = BGR (dw*dh*3); 1: dst = Y plane then the
  * interleaved chroma plane (dw*dh + 2*ceil(dw/2)*ceil(dh/2) bytes).  work as for

@@ -103,3 +103,35 @@ def test_p010_warp_chain_matches_numpy_for_both_blends_and_per_row_rotation():
         mx, my = oracle.create_map_ex(p, 40, 24, mode)
         assert np.array_equal(oracle.warp_p010(y[:28, :48], uv[:14, :48], p, 40, 24, None, mode, 0),
                               np_remap10(np_bgr10(y[:28, :48] >> 6, uv[:14, :48] >> 6), mx, my, 0)), mode
+
+
+def test_bgr10_to_p010_matches_numpy_and_extends_the_8bit_conversion():
+    """vo_cvt_bgr10_p010 (the 10-bit path's encoder hand-off, DEFINED here): an independent numpy restatement in int64; the
+    float BT.601 formula within one level; and for samples that are 4 x an 8-bit frame the result is 4 x the 8-bit
+    BGR -> NV12 conversion within 4 levels.  Round trip P010 -> BGR -> P010 stays within 3 levels where nothing saturates."""
+    rng = np.random.default_rng(5)
+    for (w, h) in ((64, 36), (33, 17)):
+        bgr = rng.integers(0, 1024, (h, w, 3), dtype=np.uint16)
+        y, uv = oracle.cvt_bgr10_p010(bgr)
+        B, G, R = (bgr[..., k].astype(np.int64) for k in range(3))
+        ey = np.clip((269484 * R + 528482 * G + 102760 * B + (1 << 19) + (64 << 20)) >> 20, 0, 1023)
+        eu = np.clip((-155188 * R - 305135 * G + 460324 * B + (1 << 19) + (512 << 20)) >> 20, 0, 1023)[::2, ::2]
+        ev = np.clip((460324 * R - 385875 * G - 74448 * B + (1 << 19) + (512 << 20)) >> 20, 0, 1023)[::2, ::2]
+        assert np.array_equal(y, (ey << 6).astype(np.uint16))
+        assert np.array_equal(uv[:, 0::2], (eu << 6).astype(np.uint16)) and np.array_equal(uv[:, 1::2], (ev << 6).astype(np.uint16))
+        assert (y & 63).max() == 0 and (uv & 63).max() == 0
+        fy = 64 + (0.257 * R + 0.504 * G + 0.098 * B)
+        assert np.abs((y >> 6).astype(np.float64) - fy).max() <= 1.0
+    # 4 x an 8-bit frame
+    b8 = rng.integers(0, 256, (36, 64, 3), dtype=np.uint8)
+    y8, uv8 = oracle.cvt_bgr_nv12(b8)
+    y10, uv10 = oracle.cvt_bgr10_p010(b8.astype(np.uint16) * 4)
+    assert np.abs((y10 >> 6).astype(int) - 4 * y8.astype(int)).max() <= 4
+    assert np.abs((uv10 >> 6).astype(int) - 4 * uv8.reshape(uv10.shape).astype(int)).max() <= 4
+    # round trip through the 10-bit colour conversion on a smooth frame (chroma constant over 2 x 2 blocks)
+    yy, uu, _, _ = p010_frame(11, 64, 36, junk=False)
+    mid = oracle.cvt_p010_bgr10(yy, uu)
+    back_y, back_uv = oracle.cvt_bgr10_p010(mid)
+    inner = ((mid > 0) & (mid < 1023)).all(axis=2) & (yy >> 6 >= 64) & (yy >> 6 <= 940)   # in gamut: nothing clipped on the way
+    assert inner.mean() > 0.2
+    assert np.abs((back_y >> 6).astype(int) - (yy >> 6).astype(int))[inner].max() <= 3

@@ -210,3 +210,47 @@ def test_p010_identity_map_is_the_colour_conversion_at_4k(vs, cuda):
     exp = oracle.cvt_p010_bgr10(y, uv)
     for blend in (vs.BLEND_EXACT, vs.BLEND_FP16):
         assert np.array_equal(host(vs.warp_p010(dev16(y, cuda), dev16(uv, cuda), p, w, h, None, vs.MAP_RECT_TO_RECT, blend)), exp), blend
+
+
+@pytest.mark.parametrize("w,h", [(640, 360), (323, 181), (66, 34), (2, 2), (1, 1)])
+def test_bgr16_to_p010_bit_exact_vs_oracle(vs, cuda, w, h):
+    """vstab_cvt_bgr16_p010 (the 10-bit path's encoder hand-off) against its definition, odd sizes and pitched planes included."""
+    import torch
+    rng = np.random.default_rng(w * 7 + h)
+    bgr = rng.integers(0, 1024, (h, w, 3), dtype=np.uint16)
+    ey, euv = oracle.cvt_bgr10_p010(bgr)
+    y, uv = vs.cvt_bgr16_p010(dev16(bgr, cuda))
+    assert np.array_equal(host(y), ey) and np.array_equal(host(uv), euv)
+    # pitched source and destinations
+    big = torch.zeros((h, w + 5, 3), dtype=torch.int16, device=cuda)
+    big[:, :w] = dev16(bgr, cuda)
+    oy = torch.full((h, w + 6), -1, dtype=torch.int16, device=cuda)
+    ouv = torch.full(((h + 1) // 2, 2 * ((w + 1) // 2) + 4), -1, dtype=torch.int16, device=cuda)
+    vs.cvt_bgr16_p010(big[:, :w], oy[:, :w], ouv[:, :2 * ((w + 1) // 2)])
+    assert np.array_equal(host(oy)[:, :w], ey) and np.array_equal(host(ouv)[:, :2 * ((w + 1) // 2)], euv)
+    assert (host(oy)[:, w:] == 0xffff).all() and (host(ouv)[:, 2 * ((w + 1) // 2):] == 0xffff).all()   # nothing written beyond the planes
+
+
+def test_pipeline_emits_p010_planes(vs, cuda):
+    """vstab_pull_frame_p010: the 10-bit pipeline's frames as P010 planes = the oracle's BGR frame through the oracle's BGR -> P010."""
+    import torch
+    import synth
+    W, H, n, r = 640, 360, 8, 2
+    K = oracle.get_preset_camera(4, W, H)
+    Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
+    frames8, _ = synth.shaky_clip(6, K, W, H, n, sigma=0.004)
+    rng = np.random.default_rng(8)
+    wide = [((f.astype(np.uint16) << 8) | rng.integers(0, 256, f.shape, dtype=np.uint16)) for f in frames8]
+    dev = [torch.from_numpy(x.view(np.int16)).to(cuda) for x in wide]
+    stab = vs.Stabilizer(dev, total=n, bit_depth=10, smooth_radius=r, seed=3, pixel_depth=10, blend=vs.BLEND_EXACT)
+    i = 0
+    while True:
+        oy = torch.empty((ch, cw), dtype=torch.int16, device=cuda)
+        ouv = torch.empty(((ch + 1) // 2, 2 * ((cw + 1) // 2)), dtype=torch.int16, device=cuda)
+        if not stab.pull_p010_into(oy, ouv):
+            break
+        p = oracle.map_params(K, Ko, stab.warp_rotation(i))
+        ey, euv = oracle.cvt_bgr10_p010(oracle.warp_p010(wide[i + 1][:H], wide[i + 1][H:], p, cw, ch, None, 0, 0))
+        assert np.array_equal(host(oy), ey) and np.array_equal(host(ouv), euv), i
+        i += 1
+    assert i == n - 1

@@ -123,6 +123,8 @@ SIGNATURES = {
     "vstab_create": (_i, [_c.POINTER(Config), _c.POINTER(Source), _pp]),
     "vstab_get_output_info": (_i, [_vp, _ip, _ip, _dp, _dp]),
     "vstab_pull_frame": (_i, [_vp, _vp, _sz]),
+    "vstab_cvt_bgr16_p010": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp, _sz, _vp]),
+    "vstab_pull_frame_p010": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "vstab_pull_frames": (_i, [_vp, _i, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t), _i, _i, _c.POINTER(_c.c_int)]),
     "vstab_pull_frame_nv12": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "vstab_pull_frame_host": (_i, [_vp, _vp, _sz]),
@@ -381,6 +383,19 @@ def warp_p010(y, uv, params, dw, dh, rot_bottom=None, mode=MAP_CREATEMAP_CL, ble
     return out
 
 
+def cvt_bgr16_p010(bgr16, out_y=None, out_uv=None):
+    """vstab_cvt_bgr16_p010: (h, w, 3) int16 CUDA tensor of BGR values 0..1023 -> P010 planes (h, w) and (ceil(h/2), 2 * ceil(w/2)), int16 bit patterns."""
+    import torch
+    h, w = bgr16.shape[:2]
+    if out_y is None:
+        out_y = torch.empty((h, w), dtype=torch.int16, device=bgr16.device)
+    if out_uv is None:
+        out_uv = torch.empty(((h + 1) // 2, 2 * ((w + 1) // 2)), dtype=torch.int16, device=bgr16.device)
+    _check(_L.vstab_cvt_bgr16_p010(bgr16.data_ptr(), bgr16.stride(0) * 2, w, h, out_y.data_ptr(), out_y.stride(0) * 2, out_uv.data_ptr(), out_uv.stride(0) * 2,
+                                   _stream()), "vstab_cvt_bgr16_p010")
+    return out_y, out_uv
+
+
 def time_next_launch(start_event, stop_event):
     """The next stateless warp call stamps its kernel's own start / end into the two torch.cuda.Event(enable_timing=True):
     kernel-only time, as rocprofv3's kernel trace reports it."""
@@ -624,6 +639,14 @@ class Stabilizer:
         if st == EOF:
             return False
         _check(st, "vstab_pull_frame_bgr16")
+        return True
+
+    def pull_p010_into(self, out_y, out_uv):
+        """pixel_depth = 10 handles: P010 planes (int16 CUDA tensors, (h, w) and (ceil(h/2), 2 * ceil(w/2)))."""
+        st = _L.vstab_pull_frame_p010(self._h, out_y.data_ptr(), out_y.stride(0) * 2, out_uv.data_ptr(), out_uv.stride(0) * 2)
+        if st == EOF:
+            return False
+        _check(st, "vstab_pull_frame_p010")
         return True
 
     def pull_host(self):

@@ -764,6 +764,7 @@ struct vstab_handle {
     bool spec_is_key = false;    // that launch is a pre-launched key frame (fresh corners from the speculative detection)
     std::vector<float> pre_corners;
     DevBuf host_out;                // staging buffer of vstab_pull_frame_host
+    DevBuf bgr16_out;               // 16-bit BGR frame of vstab_pull_frame_p010 (converted to P010 planes behind the warp)
     // Quantised-map cache: when two consecutive frames are warped with the same 17 parameters (tracking off, or any
     // run of identical rotations) the map is written once (vstab_quantised_map) and the following warps read it
     // instead of evaluating it -- the reference recomputes an identical map per frame (FrameSourceWarp.cpp:283-304).
@@ -1566,6 +1567,15 @@ vstab_status vstab_pull_frame_host(vstab_handle *h, void *dst, size_t pitch_dst)
 
 vstab_status vstab_pull_frame_bgr16(vstab_handle *h, void *dst, size_t pitch_dst) {
     return pull_frame_impl(h, OUT_BGR16, dst, pitch_dst, nullptr, 0);
+}
+
+vstab_status vstab_pull_frame_p010(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv) {
+    if (!h || !dst_y || !dst_uv) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame_p010: null argument");
+    const size_t bpitch = ((size_t)h->ow * 6 + 255) & ~(size_t)255;
+    VSTAB_TRY(h->bgr16_out.ensure(bpitch * h->oh));
+    const vstab_status st = pull_frame_impl(h, OUT_BGR16, h->bgr16_out.p, bpitch, nullptr, 0);
+    if (st != VSTAB_OK) return st;
+    return vstab_cvt_bgr16_p010(h->bgr16_out.p, bpitch, h->ow, h->oh, dst_y, pitch_y, dst_uv, pitch_uv, h->stream);
 }
 
 vstab_status vstab_pull_frame_nv12(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv) {

@@ -104,9 +104,47 @@ __global__ void __launch_bounds__(256) k_warp_p010(P010Args a) {
     }
 }
 
+// k_cvt_bgr10_p010 -- the encoder hand-off of the 10-bit path: BGR (0..1023 in 16-bit containers) -> P010 planes, the BGR -> YUV
+// arithmetic of the NV12 output (cvtColor's BT.601 constants, 20-bit shift) at 10 bits: offsets 64 / 512, saturation to
+// [0, 1023], sample << 6; chroma from the top-left pixel of each 2 x 2 block (definition: include/vstab.h).  One
+// thread converts two adjacent pixels of a row: 12 bytes in, one luma dword out, on even rows one (U, V) dword.
+__global__ void __launch_bounds__(256) k_cvt_bgr10_p010(const uint8_t *__restrict__ src, size_t pitch_src, int w, int h, uint8_t *__restrict__ dy,
+                                                        size_t pitch_y, uint8_t *__restrict__ duv, size_t pitch_uv) {
+    const int px = (blockIdx.x * 64 + (threadIdx.x & 63)) * 2, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= w || y >= h) return;
+    const uint16_t *s = reinterpret_cast<const uint16_t *>(src + (size_t)y * pitch_src) + 3 * (size_t)px;
+    const bool two = px + 1 < w;
+    const int B0 = s[0], G0 = s[1], R0 = s[2], B1 = two ? s[3] : 0, G1 = two ? s[4] : 0, R1 = two ? s[5] : 0;
+    constexpr int half = 1 << 19;
+    const int y0 = sat10((CRY * R0 + CGY * G0 + CBY * B0 + half + (64 << 20)) >> 20), y1 = sat10((CRY * R1 + CGY * G1 + CBY * B1 + half + (64 << 20)) >> 20);
+    uint16_t *oy = reinterpret_cast<uint16_t *>(dy + (size_t)y * pitch_y) + px;
+    if (two && (reinterpret_cast<uintptr_t>(oy) & 3) == 0) *reinterpret_cast<uint32_t *>(oy) = ((uint32_t)y0 << 6) | ((uint32_t)y1 << 22);
+    else {
+        oy[0] = (uint16_t)(y0 << 6);
+        if (two) oy[1] = (uint16_t)(y1 << 6);
+    }
+    if (!(y & 1)) {
+        const int U = sat10((CRU * R0 + CGU * G0 + CBU * B0 + half + (512 << 20)) >> 20), V = sat10((CBU * R0 + CGV * G0 + CBV * B0 + half + (512 << 20)) >> 20);
+        *reinterpret_cast<uint32_t *>(duv + (size_t)(y >> 1) * pitch_uv + (size_t)px * 2) = ((uint32_t)U << 6) | ((uint32_t)V << 22);
+    }
+}
+
 }  // namespace vstab
 
 using namespace vstab;
+
+extern "C" vstab_status vstab_cvt_bgr16_p010(const void *src_bgr16, size_t pitch_src, int width, int height, void *dst_y, size_t pitch_y, void *dst_uv,
+                                             size_t pitch_uv, void *stream) {
+    if (!src_bgr16 || !dst_y || !dst_uv) return fail(VSTAB_ERR_INVALID, "vstab_cvt_bgr16_p010: null pointer");
+    if (width <= 0 || height <= 0 || width > 32767 || height > 32767) return fail(VSTAB_ERR_INVALID, "vstab_cvt_bgr16_p010: sizes must be in [1, 32767]");
+    if (pitch_src < (size_t)width * 6 || pitch_src % 2 || pitch_y < (size_t)width * 2 || pitch_y % 2 || pitch_uv < (size_t)((width + 1) / 2) * 4 || pitch_uv % 4 ||
+        reinterpret_cast<uintptr_t>(src_bgr16) % 2 || reinterpret_cast<uintptr_t>(dst_y) % 2 || reinterpret_cast<uintptr_t>(dst_uv) % 4)
+        return fail(VSTAB_ERR_INVALID, "vstab_cvt_bgr16_p010: bad pitch or alignment (16-bit samples; chroma pairs 4-byte aligned)");
+    hipLaunchKernelGGL(k_cvt_bgr10_p010, dim3(div_up(div_up(width, 2), 64), div_up(height, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint8_t *>(src_bgr16), pitch_src, width, height, static_cast<uint8_t *>(dst_y), pitch_y, static_cast<uint8_t *>(dst_uv), pitch_uv);
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
 
 extern "C" vstab_status vstab_warp_p010(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh, const float params[17],
                                         const float *rot_bottom, int map_mode, int blend, void *dst, size_t pitch_dst, int dw, int dh, void *stream) {
