@@ -64,10 +64,22 @@ __device__ __forceinline__ void pyr_down_group(const uint8_t *__restrict__ src, 
     }
     uint32_t d[5][4];
     if (!EDGE) {
+        if (y >= 1 && 2 * y + 2 < sh) {
+            // wave-uniform (a wave is one output row): the five source rows 2y - 2 .. 2y + 2 are inside the image, so their
+            // addresses are one multiply and four pitch steps -- the reflection of every row (five quarter-rate 32-bit
+            // multiplies, ten 64-bit adds, twenty min / max / sub) was a third of the kernel's vector instructions
+            const uint8_t *r0 = src + (size_t)(uint32_t)(2 * y - 2) * spitch + sx0;
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(row[j] + sx0);
-            d[j][0] = p[0], d[j][1] = p[1], d[j][2] = p[2], d[j][3] = p[3];
+            for (int j = 0; j < 5; j++) {
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(r0 + (size_t)j * spitch);
+                d[j][0] = p[0], d[j][1] = p[1], d[j][2] = p[2], d[j][3] = p[3];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(row[j] + sx0);
+                d[j][0] = p[0], d[j][1] = p[1], d[j][2] = p[2], d[j][3] = p[3];
+            }
         }
     } else {
         // Whether a dword lies inside the row is the same for the five rows: one branch per dword column, the five (or
