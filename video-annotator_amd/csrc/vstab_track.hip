@@ -114,7 +114,7 @@ __device__ __forceinline__ void pyr_down_group(const uint8_t *__restrict__ src, 
         acc[3] = udot4(d[j][3], k, udot4(d[j][2], w_all, acc[3]));
     }
     // result byte c = bits 8..15 of acc[c] (sum + 128 <= 255 * 256 + 128 < 2^16)
-    uint8_t *o = dst + (size_t)y * dpitch + x0;
+    uint8_t *o = dst + (size_t)((uint32_t)y * (uint32_t)dpitch) + x0;  // one 32-bit multiply (images are at most 32767 x 32767 bytes)
     if (!EDGE) {
         const uint32_t p01 = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0501u), p23 = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0501u);
         *reinterpret_cast<uint32_t *>(o) = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
@@ -985,6 +985,9 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkPyramid I, LkPyram
 vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *dst, size_t dpitch,
                              hipStream_t s) {
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    // the kernel forms row offsets as 32-bit products
+    if ((uint64_t)spitch * (uint64_t)sh >= (1ull << 32) || (uint64_t)dpitch * (uint64_t)dh >= (1ull << 32))
+        return fail(VSTAB_ERR_INVALID, "pyr_down: planes of 4 GiB or more are not supported");
     const int vec_ok = reinterpret_cast<uintptr_t>(src) % 4 == 0 && spitch % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && dpitch % 4 == 0;
     // group g = outputs 4g .. 4g+3 reads source bytes [8g - 4, 8g + 12): interior iff g >= 1, 8g + 12 <= sw and 4g + 4 <= dw
     const int n_groups = div_up(dw, 4);
