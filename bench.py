@@ -57,8 +57,9 @@ def parse():
     ap.add_argument("--ring", type=int, default=64, help="distinct input frames / output buffers")
     ap.add_argument("--no-tracking", action="store_true",
                     help="BASELINE config 1: undistort only (identity rotations) through the pipeline object")
-    ap.add_argument("--out-format", default="bgr", choices=["bgr", "nv12"],
-                    help="bgr = what FrameSourceWarp emits (the BASELINE metric); nv12 = encoder hand-off mode (SURVEY.md 8(f) row 2)")
+    ap.add_argument("--out-format", default="bgr", choices=["bgr", "nv12", "p010"],
+                    help="bgr = what FrameSourceWarp emits (the BASELINE metric); nv12 = encoder hand-off mode (SURVEY.md 8(f) row 2); "
+                         "p010 = the same for --workload 4k-p010 (P010 planes written by the warp kernel itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo only for rehearsing ranks on one GPU")
@@ -325,9 +326,13 @@ def main():
 
     w, h = (1920, 1080) if args.workload == "1080p" else (3840, 2160)
     p010 = args.workload == "4k-p010"
-    if p010 and (args.mode == "warp" or args.out_format != "bgr" or args.no_tracking):
-        print("bench.py: --workload 4k-p010 runs the full pipeline with 16-bit BGR output", file=sys.stderr)
+    if p010 and (args.mode == "warp" or args.out_format == "nv12" or args.no_tracking):
+        print("bench.py: --workload 4k-p010 runs the full pipeline with 16-bit BGR or P010 output", file=sys.stderr)
         return 2
+    if args.out_format == "p010" and not p010:
+        print("bench.py: --out-format p010 belongs to --workload 4k-p010", file=sys.stderr)
+        return 2
+    p010_out = p010 and args.out_format == "p010"
     preset = vs.GOPRO_H4B_WIDE169_MEASURED
     K = vs.get_preset_camera(preset, w, h)
     Ko, (cw, ch) = vs.get_output_camera(K, w, h, 1.0, False, 1.0)
@@ -341,6 +346,9 @@ def main():
     nv12_out = args.out_format == "nv12"
     if nv12_out:
         outs = [vs.nv12_out_planes(cw, ch, dev) for _ in range(args.ring)]
+    elif p010_out:
+        outs = [(torch.empty((ch, cw), dtype=torch.int16, device=dev), torch.empty(((ch + 1) // 2, 2 * ((cw + 1) // 2)), dtype=torch.int16, device=dev))
+                for _ in range(args.ring)]
     elif p010:
         outs = [torch.empty((ch, cw, 3), dtype=torch.int16, device=dev) for _ in range(args.ring)]
     else:
@@ -403,7 +411,7 @@ def main():
             assert pull(i)
         pull = (lambda i: stab.pull_nv12_into(*outs[i % args.ring])) if nv12_out else (lambda i: stab.pull_into(outs[i % args.ring]))
         if p010:
-            pull = lambda i: stab.pull_bgr16_into(outs[i % args.ring])
+            pull = (lambda i: stab.pull_p010_into(*outs[i % args.ring])) if p010_out else (lambda i: stab.pull_bgr16_into(outs[i % args.ring]))
         stab.enable_profiling(1)  # timed region: HIP events around the warp launches only
         ingest_txt = ("frames used in place (upstream holds them: vstab_frame.hold), no pack kernel" if args.ingest == "inplace"
                       else "every frame copied into the library's ring (vstab_frame.hold = 0: vstab_pack_nv12)")
@@ -414,7 +422,7 @@ def main():
             workload = (f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, undistort only (tracking off, identity rotations): {ingest_txt}; "
                         f"fused undistort-remap from the map written once{prec_txt}")
         if p010:
-            workload = (f"4k P010 {w}x{h} -> BGR 16-bit (10 significant) {cw}x{ch}, BASELINE config 5: full pipeline on the narrowed luma (corner detect, "
+            workload = (f"4k P010 {w}x{h} -> {'P010 planes' if p010_out else 'BGR 16-bit (10 significant)'} {cw}x{ch}, BASELINE config 5: full pipeline on the narrowed luma (corner detect, "
                         "pyramidal LK, rotation estimate, SG r=30), 10-bit undistort-remap with fp16 blend and a rotation per output row")
 
     # pipeline mode, BGR frames: a step is ONE library call that pulls the step's batch of frames into the output ring
@@ -465,7 +473,12 @@ def main():
         if p010:
             rb = oracle.map_params(K, Ko, readouts[(n_emit + 1) % len(clip)] @ stab.warp_rotation(n_emit))[8:]
             s16 = src.view(np.uint16)
-            same = np.array_equal(got.cpu().numpy().view(np.uint16), oracle.warp_p010(s16[:h], s16[h:], pr, cw, ch, rb, 0, 1))
+            exp16 = oracle.warp_p010(s16[:h], s16[h:], pr, cw, ch, rb, 0, 1)
+            if p010_out:
+                ey, euv = oracle.cvt_bgr10_p010(exp16)
+                same = np.array_equal(got[0].cpu().numpy().view(np.uint16), ey) and np.array_equal(got[1].cpu().numpy().view(np.uint16), euv)
+            else:
+                same = np.array_equal(got.cpu().numpy().view(np.uint16), exp16)
         elif nv12_out and not opencl:
             exp_y, exp_uv = oracle.warp_nv12_ex(src, pr, cw, ch, 0, 1)
             same = np.array_equal(got[0].cpu().numpy().reshape(-1), exp_y.reshape(-1)) and np.array_equal(got[1].cpu().numpy().reshape(-1), exp_uv.reshape(-1))
@@ -482,7 +495,7 @@ def main():
     # then rank 0 writes the stitch list (concat.sh / join.ts format)
     shard = importlib.import_module("video-annotator_amd.shard")
     last = outs[(n_warm + n_timed - 1) % args.ring]
-    if nv12_out:
+    if nv12_out or p010_out:
         last = last[0]
     rec = dict(rank=rank, clip=rank, frames=n_timed, elapsed_ns=int(el * 1e9), crc=shard.crc_of(last[:64].cpu().numpy()))
     records = shard.gather_records([rec], device=cdev)
@@ -526,6 +539,9 @@ def main():
                 pb = vs.map_params(K, Ko, rot(8))[8:]
                 run_alone = lambda i: vs.warp_p010(clip[i % len(clip)][:h], clip[i % len(clip)][h:], pa, cw, ch, pb, vs.MAP_CREATEMAP_CL, vs.BLEND_FP16,
                                                    out=outs[i % args.ring])
+                if p010_out:
+                    run_alone = lambda i: vs.warp_p010_planes(clip[i % len(clip)][:h], clip[i % len(clip)][h:], pa, cw, ch, pb, vs.MAP_CREATEMAP_CL, vs.BLEND_FP16,
+                                                              out_y=outs[i % args.ring][0], out_uv=outs[i % args.ring][1])
             for i in range(10):
                 run_alone(i)
             torch.cuda.synchronize()
@@ -560,6 +576,9 @@ def main():
         if p010:
             alg_bytes = w * h * 3 + cw * ch * 6  # P010 read once + 16-bit BGR written once
             kernel_name = "k_warp_fused<8, RS_CREATEMAP_CL, BGR16, DEPTH 10, FP16> (the LDS-tiled kernel with a 10:10:10 LDS pixel)"
+            if p010_out:
+                alg_bytes = w * h * 3 + cw * ch * 2 + 4 * ((cw + 1) // 2) * ((ch + 1) // 2)  # P010 read once + P010 planes written once
+                kernel_name = "k_warp_fused<8, RS_CREATEMAP_CL, P010, DEPTH 10, FP16> (P010 planes written by the warp kernel)"
         base_bytes = alg_bytes  # of the kernel that evaluates the map (what "alone" runs)
         cached = mode == "pipeline" and args.no_tracking
         if cached:

@@ -32,7 +32,8 @@ typedef enum vstab_status {
     VSTAB_ERR_INVALID = -2,  /* bad argument / unsupported geometry */
     VSTAB_ERR_DEVICE = -3,   /* HIP runtime error (details in vstab_last_error) */
     VSTAB_ERR_NOMEM = -4,
-    VSTAB_ERR_SOURCE = -5    /* upstream callback failed with a code other than EOF */
+    VSTAB_ERR_SOURCE = -5,   /* upstream callback failed with a code other than EOF */
+    VSTAB_ERR_UNSUPPORTED = -6 /* a valid request this entry point does not serve (the text says which one does) */
 } vstab_status;
 
 /* CameraPreset, FrameSourceWarp.hpp:14-21 (same order, same values) */
@@ -183,6 +184,13 @@ VSTAB_API vstab_status vstab_warp_p010(const void *y, size_t pitch_y, const void
                                        int src_width, int src_height, const float params[17], const float *rot_bottom,
                                        int map_mode, int blend, void *dst_bgr16, size_t pitch_dst, int dst_width,
                                        int dst_height, void *stream);
+
+/* vstab_warp_p010 with P010 planes out in the same kernel (no 16-bit BGR frame in memory): the blended 10-bit BGR pixel is converted
+ * in registers by vstab_cvt_bgr16_p010's arithmetic (below).  Served by the LDS-tiled kernel only: VSTAB_ERR_UNSUPPORTED unless the
+ * source planes and pitches are 16-byte aligned and the map is VSTAB_MAP_CREATEMAP_CL or VSTAB_MAP_FISH_TO_RECT -- then warp to BGR and convert. */
+VSTAB_API vstab_status vstab_warp_p010_planes(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int src_width, int src_height,
+                                              const float params[17], const float *rot_bottom, int map_mode, int blend, void *dst_y,
+                                              size_t pitch_dst_y, void *dst_uv, size_t pitch_dst_uv, int dst_width, int dst_height, void *stream);
 
 /* The 10-bit path's encoder hand-off: BGR as vstab_warp_p010 writes it -> P010 planes (16-bit samples, significant bits at the top;
  * chroma interleaved U, V, ceil(w/2) x ceil(h/2) pairs, from the top-left pixel of each 2 x 2 block).  The BGR -> YUV arithmetic of the
@@ -435,7 +443,8 @@ VSTAB_API vstab_status vstab_pull_frame_host(vstab_handle *h, void *dst_bgr_host
  * pitch_dst in bytes, >= 6 * width and even.  The 8-bit pull functions refuse such a handle and vice versa. */
 VSTAB_API vstab_status vstab_pull_frame_bgr16(vstab_handle *h, void *dst_bgr16, size_t pitch_dst);
 /* pull_frame of a pixel_depth = 10 handle as P010 planes for a 10-bit encoder (the counterpart of vstab_pull_frame_nv12): the frame is
- * warped into a 16-bit BGR buffer of the handle and converted by vstab_cvt_bgr16_p010 (not fused yet: 63 MB of extra traffic per 4K frame). */
+ * warped and converted in one kernel (vstab_warp_p010_planes) when the frame's planes allow it, else warped into a 16-bit BGR buffer of the
+ * handle and converted by vstab_cvt_bgr16_p010. */
 VSTAB_API vstab_status vstab_pull_frame_p010(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv);
 /* FrameSourceWarp::peek_frame (:478-480) IS pull_frame in the reference (destructive); kept. */
 VSTAB_API vstab_status vstab_peek_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);

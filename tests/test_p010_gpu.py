@@ -254,3 +254,37 @@ def test_pipeline_emits_p010_planes(vs, cuda):
         assert np.array_equal(host(oy), ey) and np.array_equal(host(ouv), euv), i
         i += 1
     assert i == n - 1
+
+
+@pytest.mark.parametrize("w,h", [(640, 360), (328, 182), (72, 34)])
+def test_p010_warp_with_planes_out_equals_warp_then_conversion(vs, cuda, w, h):
+    """vstab_warp_p010_planes (P010 out of the warp kernel itself) == the oracle's warp followed by the oracle's BGR -> P010,
+    both blends, per-row rotation, odd output sizes, pitched output planes; planes the tiled kernel cannot take are refused
+    with ERR_UNSUPPORTED (vstab_pull_frame_p010 then converts a 16-bit BGR frame)."""
+    import torch
+    y, uv, _, _ = p010_frame(33, w, h)
+    yd, ud = dev16(y, cuda), dev16(uv, cuda)
+    K = oracle.get_preset_camera(4, w, h)
+    Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
+    rb = oracle.map_params(K, Ko, oracle.rodrigues((0.03, -0.01, -0.01)))[8:]
+    for rot in [(0.0, 0.0, 0.0), (0.02, -0.03, 0.01), (-0.15, 0.1, 0.3)]:
+        p = oracle.map_params(K, Ko, oracle.rodrigues(rot))
+        for blend in (vs.BLEND_EXACT, vs.BLEND_FP16):
+            for rot_bottom in (None, rb):
+                ey, euv = oracle.cvt_bgr10_p010(oracle.warp_p010(y, uv, p, cw, ch, rot_bottom, 0, blend))
+                gy, guv = vs.warp_p010_planes(yd, ud, p, cw, ch, rot_bottom, 0, blend)
+                assert np.array_equal(host(gy), ey) and np.array_equal(host(guv), euv), (rot, blend, rot_bottom is not None)
+    # pitched, only 2-byte / 4-byte aligned output planes (the scalar store path)
+    p = oracle.map_params(K, Ko, oracle.rodrigues((0.02, -0.03, 0.01)))
+    ey, euv = oracle.cvt_bgr10_p010(oracle.warp_p010(y, uv, p, cw, ch, None, 0, 0))
+    oy = torch.full((ch, cw + 7), -1, dtype=torch.int16, device=cuda)
+    ouv = torch.full(((ch + 1) // 2, 2 * ((cw + 1) // 2) + 6), -1, dtype=torch.int16, device=cuda)
+    vs.warp_p010_planes(yd, ud, p, cw, ch, None, 0, 0, out_y=oy[:, 1:cw + 1], out_uv=ouv[:, 2:2 * ((cw + 1) // 2) + 2])
+    assert np.array_equal(host(oy)[:, 1:cw + 1], ey) and np.array_equal(host(ouv)[:, 2:2 * ((cw + 1) // 2) + 2], euv)
+    assert (host(oy)[:, 0] == 0xffff).all() and (host(oy)[:, cw + 1:] == 0xffff).all() and (host(ouv)[:, :2] == 0xffff).all()
+    # unaligned source planes: not this entry point's job
+    big = torch.zeros((h, w + 8), dtype=torch.int16, device=cuda)
+    big[:, 1:w + 1] = yd
+    with pytest.raises(vs.VstabError) as e:
+        vs.warp_p010_planes(big[:, 1:w + 1], ud, p, cw, ch)
+    assert e.value.status == vs.ERR_UNSUPPORTED

@@ -29,7 +29,7 @@ import torch  # noqa: E402,F401  (plumbing: device memory + streams)
 
 _L = ctypes.CDLL(LIB_PATH)
 
-OK, EOF, ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_SOURCE = 0, -1, -2, -3, -4, -5
+OK, EOF, ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_SOURCE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 
 (GOPRO_H4B_WIDE43_PUBLISHED, GOPRO_H4B_WIDE43_MEASURED, GOPRO_H4B_WIDE43_MEASURED_STABILISATION,
  GOPRO_H4B_WIDE169_PUBLISHED, GOPRO_H4B_WIDE169_MEASURED, GOPRO_H4B_WIDE169_MEASURED_STABILISATION) = range(6)
@@ -123,6 +123,7 @@ SIGNATURES = {
     "vstab_create": (_i, [_c.POINTER(Config), _c.POINTER(Source), _pp]),
     "vstab_get_output_info": (_i, [_vp, _ip, _ip, _dp, _dp]),
     "vstab_pull_frame": (_i, [_vp, _vp, _sz]),
+    "vstab_warp_p010_planes": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _fp, _i, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
     "vstab_cvt_bgr16_p010": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp, _sz, _vp]),
     "vstab_pull_frame_p010": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "vstab_pull_frames": (_i, [_vp, _i, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t), _i, _i, _c.POINTER(_c.c_int)]),
@@ -381,6 +382,23 @@ def warp_p010(y, uv, params, dw, dh, rot_bottom=None, mode=MAP_CREATEMAP_CL, ble
     _check(_L.vstab_warp_p010(y.data_ptr(), y.stride(0) * 2, uv.data_ptr(), uv.stride(0) * 2, w, h, _fptr(p), None if rb is None else _fptr(rb),
                               int(mode), int(blend), out.data_ptr(), out.stride(0) * 2, dw, dh, _stream()), "vstab_warp_p010")
     return out
+
+
+def warp_p010_planes(y, uv, params, dw, dh, rot_bottom=None, mode=MAP_CREATEMAP_CL, blend=BLEND_EXACT, out_y=None, out_uv=None):
+    """vstab_warp_p010_planes: the 10-bit warp with P010 planes out, one kernel.  Raises VstabError (ERR_UNSUPPORTED) for planes the
+    tiled kernel cannot take."""
+    import torch
+    h, w = y.shape
+    p = np.ascontiguousarray(params, np.float32)
+    rb = None if rot_bottom is None else np.ascontiguousarray(rot_bottom, np.float32).reshape(9)
+    if out_y is None:
+        out_y = torch.empty((dh, dw), dtype=torch.int16, device=y.device)
+    if out_uv is None:
+        out_uv = torch.empty(((dh + 1) // 2, 2 * ((dw + 1) // 2)), dtype=torch.int16, device=y.device)
+    _check(_L.vstab_warp_p010_planes(y.data_ptr(), y.stride(0) * 2, uv.data_ptr(), uv.stride(0) * 2, w, h, _fptr(p), None if rb is None else _fptr(rb),
+                                     int(mode), int(blend), out_y.data_ptr(), out_y.stride(0) * 2, out_uv.data_ptr(), out_uv.stride(0) * 2, dw, dh, _stream()),
+           "vstab_warp_p010_planes")
+    return out_y, out_uv
 
 
 def cvt_bgr16_p010(bgr16, out_y=None, out_uv=None):

@@ -1381,11 +1381,12 @@ vstab_status vstab_get_output_info(const vstab_handle *h, int *width, int *heigh
 }  // extern "C"
 
 constexpr int OUT_BGR16 = 2;  // internal: the 10-bit path's output (vstab_pull_frame_bgr16)
+constexpr int OUT_P010 = 3;   // internal: the 10-bit path's frame as P010 planes (vstab_pull_frame_p010)
 
 // FrameSourceWarp::pull_frame, :452-476
 static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, size_t pitch_dst, void *dst_uv, size_t pitch_dst_uv) {
-    if (!H || !dst || (out_format == VSTAB_OUT_NV12 && !dst_uv)) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: null argument");
-    if ((H->cfg.pixel_depth == 10) != (out_format == OUT_BGR16))
+    if (!H || !dst || ((out_format == VSTAB_OUT_NV12 || out_format == OUT_P010) && !dst_uv)) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: null argument");
+    if ((H->cfg.pixel_depth == 10) != (out_format == OUT_BGR16 || out_format == OUT_P010))
         return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: a pixel_depth 10 handle emits through vstab_pull_frame_bgr16, an 8-bit handle through the others");
     HT t_total(HostTimers::TOTAL);
     while (H->queue.size() <= (size_t)H->cfg.smooth_radius) {  // :453
@@ -1449,7 +1450,7 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
     float p_bottom[17];
     if (S.have_readout) map_params(H->Kin, H->Kout, S.readout * warp_R, p_bottom);
     bool cached = false;
-    if (H->map_cache && !S.have_readout && out_format != OUT_BGR16) {
+    if (H->map_cache && !S.have_readout && out_format != OUT_BGR16 && out_format != OUT_P010) {
         if (H->qmap_valid && std::memcmp(p, H->qmap_params, sizeof(p)) == 0) {
             cached = true;
         } else if (H->have_last_params && std::memcmp(p, H->last_params, sizeof(p)) == 0) {
@@ -1473,6 +1474,18 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         if (out_format == OUT_BGR16)
             st = vstab_warp_p010(S.y16, S.pitch_y16, S.uv16, S.pitch_uv16, H->w, H->h, p,
                                  S.have_readout ? p_bottom + 8 : nullptr, H->map_mode, H->cfg.blend, dst, pitch_dst, H->ow, H->oh, H->stream);
+        else if (out_format == OUT_P010) {
+            st = vstab_warp_p010_planes(S.y16, S.pitch_y16, S.uv16, S.pitch_uv16, H->w, H->h, p, S.have_readout ? p_bottom + 8 : nullptr, H->map_mode,
+                                        H->cfg.blend, dst, pitch_dst, dst_uv, pitch_dst_uv, H->ow, H->oh, H->stream);
+            if (st == VSTAB_ERR_UNSUPPORTED) {
+                const size_t bpitch = ((size_t)H->ow * 6 + 255) & ~(size_t)255;
+                st = H->bgr16_out.ensure(bpitch * H->oh);
+                if (st == VSTAB_OK)
+                    st = vstab_warp_p010(S.y16, S.pitch_y16, S.uv16, S.pitch_uv16, H->w, H->h, p, S.have_readout ? p_bottom + 8 : nullptr, H->map_mode,
+                                         H->cfg.blend, H->bgr16_out.p, bpitch, H->ow, H->oh, H->stream);
+                if (st == VSTAB_OK) st = vstab_cvt_bgr16_p010(H->bgr16_out.p, bpitch, H->ow, H->oh, dst, pitch_dst, dst_uv, pitch_dst_uv, H->stream);
+            }
+        }
         else if (H->cfg.interpolation == 0) {
             (void)take_launch_events();
             if (out_format != VSTAB_OUT_BGR8 || S.have_readout) st = fail(VSTAB_ERR_INVALID, "INTER_NEAREST emits 8-bit BGR frames without a read-out rotation");
@@ -1487,7 +1500,7 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
             st = vstab_warp_nv12_ex(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, p, H->map_mode, out_format, dst,
                                     pitch_dst, dst_uv, pitch_dst_uv, H->ow, H->oh, H->stream);
     }
-    if (st == VSTAB_OK && H->cfg.debug && !S.feats.empty() && out_format != OUT_BGR16) {  // (markers are drawn into 8-bit outputs)
+    if (st == VSTAB_OK && H->cfg.debug && !S.feats.empty() && out_format != OUT_BGR16 && out_format != OUT_P010) {  // (markers are drawn into 8-bit outputs)
         // where the warp sends each tracked feature: input pixel -> ray -> R^T -> output projection (the inverse of the map)
         constexpr int SETS = 16, CAP = 256;
         VSTAB_TRY(H->marker_pts.ensure(sizeof(int) * 2 * CAP * SETS));
@@ -1571,11 +1584,9 @@ vstab_status vstab_pull_frame_bgr16(vstab_handle *h, void *dst, size_t pitch_dst
 
 vstab_status vstab_pull_frame_p010(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv) {
     if (!h || !dst_y || !dst_uv) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame_p010: null argument");
-    const size_t bpitch = ((size_t)h->ow * 6 + 255) & ~(size_t)255;
-    VSTAB_TRY(h->bgr16_out.ensure(bpitch * h->oh));
-    const vstab_status st = pull_frame_impl(h, OUT_BGR16, h->bgr16_out.p, bpitch, nullptr, 0);
-    if (st != VSTAB_OK) return st;
-    return vstab_cvt_bgr16_p010(h->bgr16_out.p, bpitch, h->ow, h->oh, dst_y, pitch_y, dst_uv, pitch_uv, h->stream);
+    // the warp writes the planes itself (OUT_P010) where the frame's planes allow the tiled kernel; pull_frame_impl falls back
+    // to a 16-bit BGR buffer of the handle + vstab_cvt_bgr16_p010 otherwise
+    return pull_frame_impl(h, OUT_P010, dst_y, pitch_y, dst_uv, pitch_uv);
 }
 
 vstab_status vstab_pull_frame_nv12(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv) {

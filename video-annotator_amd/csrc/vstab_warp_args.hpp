@@ -73,6 +73,7 @@ vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int ma
                                const void *qmap, int qpitch, const float *rot_bottom, hipStream_t st);
 // the 10-bit pixel path on the LDS-tiled kernel: a.y / a.uv = P010 planes (16-byte aligned, pitches multiples of 16), a.dst = 16-bit
 // BGR with a.pitch_dst bytes per row; map modes 0 / 1 only
-vstab_status launch_warp_fused10(const WarpArgs &a, const float params[17], int map_mode, int blend, const float *rot_bottom, hipStream_t st);
+vstab_status launch_warp_fused10(const WarpArgs &a, const float params[17], int map_mode, int blend, const float *rot_bottom, bool p010_out, bool dst_vec_ok,
+                                 hipStream_t st);
 
 }  // namespace vstab

@@ -312,7 +312,7 @@ __device__ __forceinline__ uint32_t map_pairs_ocl(float icx32, float icy32, floa
 // B | G << 10 | R << 20 dwords -- the same 4-byte LDS pixel -- blended by BLEND (vstab_device10.hpp), 16-bit BGR out.
 template <int RWB, int RW, int MODE, int FMT, bool CACHED, bool SPLIT, int DEPTH = 8, int BLEND = 0>
 __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, const int x0, const int y0) {
-    static_assert((DEPTH == 8 && FMT != 2) || (DEPTH == 10 && FMT == 2), "10-bit pixels leave as 16-bit BGR");
+    static_assert((DEPTH == 8 && FMT < 2) || (DEPTH == 10 && FMT >= 2), "10-bit pixels leave as 16-bit BGR (FMT 2) or P010 planes (FMT 3)");
     using SrcVec = typename std::conditional<DEPTH == 10, uint4, uint2>::type;  // 8 source samples of a block row
     constexpr uint32_t BPS = DEPTH == 10 ? 2 : 1;                              // bytes per sample
     constexpr int TH = 4 * RW;
@@ -660,6 +660,44 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
                 o[0] = (uint16_t)(out[j] & 1023u), o[1] = (uint16_t)((out[j] >> 10) & 1023u), o[2] = (uint16_t)(out[j] >> 20);
             }
         }
+    } else if constexpr (FMT == 3) {
+        // P010 planes (the 10-bit path's encoder hand-off; definition: include/vstab.h, vstab_cvt_bgr16_p010): luma word for every
+        // pixel, (U, V) words from the even-row / even-column pixels; four lanes' words are collected in the first lane of each
+        // quad (DPP quad_perm) and stored as 8 bytes
+#pragma unroll
+        for (int j = 0; j < RW; j++) {
+            const int y = y0 + wave * RW + j;
+            if (y >= a.dh) break;  // uniform
+            const int B = (int)(out[j] & 1023u), G = (int)((out[j] >> 10) & 1023u), R = (int)(out[j] >> 20);
+            const uint32_t yb = (uint32_t)sat10((CRY * R + CGY * G + CBY * B + (1 << 19) + (64 << 20)) >> 20) << 6;
+            const uint32_t y1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0x55, 0xf, 0xf, true);
+            const uint32_t y2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0xaa, 0xf, 0xf, true);
+            const uint32_t y3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0xff, 0xf, 0xf, true);
+            uint16_t *o = reinterpret_cast<uint16_t *>(a.dst + (size_t)(uint32_t)y * a.pitch_dst) + x;
+            if (!(lane & 3) && col_live) {
+                if (ta.dst_vec_ok && x + 4 <= a.dw) {
+                    *reinterpret_cast<uint2 *>(o) = make_uint2(yb | (y1 << 16), y2 | (y3 << 16));
+                } else {
+                    const uint32_t w[4] = {yb, y1, y2, y3};
+                    for (int i = 0; i < 4 && x + i < a.dw; i++) o[i] = (uint16_t)w[i];
+                }
+            }
+            if (!(y & 1)) {
+                const uint32_t U = (uint32_t)sat10((CRU * R + CGU * G + CBU * B + (1 << 19) + (512 << 20)) >> 20) << 6;
+                const uint32_t V = (uint32_t)sat10((CBU * R + CGV * G + CBV * B + (1 << 19) + (512 << 20)) >> 20) << 6;
+                const uint32_t cb = U | (V << 16);
+                const uint32_t c2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)cb, 0xaa, 0xf, 0xf, true);
+                uint16_t *c = reinterpret_cast<uint16_t *>(a.dst_uv + (size_t)(uint32_t)(y >> 1) * a.pitch_dst_uv) + x;
+                if (!(lane & 3) && col_live) {
+                    if (ta.dst_vec_ok && x + 2 < a.dw) {
+                        *reinterpret_cast<uint2 *>(c) = make_uint2(cb, c2);
+                    } else {
+                        *reinterpret_cast<uint32_t *>(c) = cb;  // (U, V) pairs are 4-byte aligned (checked by the caller)
+                        if (x + 2 < a.dw) *reinterpret_cast<uint32_t *>(c + 2) = c2;
+                    }
+                }
+            }
+        }
     } else if constexpr (FMT == 0) {
         const int p0 = (4 * lane) / 3, m3 = lane - 3 * (lane / 3);  // pixels p0, p0 + 1 feed dword `lane` (lane < 48)
         const uint32_t sel = m3 == 0 ? 0x04020100u : m3 == 1 ? 0x05040201u : 0x06050402u;
@@ -805,11 +843,12 @@ static unsigned tile_schedule(FusedArgs &ta, int rwb, int lds_kb, double tail_ro
 
 // The 10-bit pixel path on the same kernel (DEPTH 10): fisheye -> pinhole maps (modes 0 / 1, optionally a rotation per
 // output row), both blends; called by vstab_warp_p010 when the planes allow 16-byte staging loads.
-vstab_status launch_warp_fused10(const WarpArgs &a, const float params[17], int map_mode, int blend, const float *rot_bottom, hipStream_t st) {
+vstab_status launch_warp_fused10(const WarpArgs &a, const float params[17], int map_mode, int blend, const float *rot_bottom, bool p010_out, bool dst_vec_ok,
+                                 hipStream_t st) {
     FusedArgs ta;
     ta.w = a;
     ta.p32 = {params[0] * 32.0f, params[1] * 32.0f, params[2] * 32.0f, params[3] * 32.0f, params[10], params[13], params[16]};
-    ta.src_vec_ok = 1, ta.dst_vec_ok = 1;
+    ta.src_vec_ok = 1, ta.dst_vec_ok = dst_vec_ok;
     ta.qmap = nullptr, ta.qpitch = 0;
     for (int k = 0; k < 9; k++) ta.rs_d[k] = rot_bottom ? rot_bottom[k] - params[8 + k] : 0.0f;
     ta.rs_den = (float)(a.dh > 1 ? a.dh - 1 : 1);
@@ -821,15 +860,18 @@ vstab_status launch_warp_fused10(const WarpArgs &a, const float params[17], int 
     const dim3 grid(tile_schedule(ta, 8, lds_kb, tiles > 1024 ? 0.5 : 0.0));
     const size_t lds_bytes = (size_t)lds_kb * 1024;
     const LaunchEvents ev = take_launch_events();
-#define VSTAB_LAUNCH10(M, B)                                                                                                        \
+#define VSTAB_LAUNCH10(M, B, F)                                                                                                     \
     do {                                                                                                                            \
-        if (ev.start) hipExtLaunchKernelGGL((k_warp_fused<8, M, 2, false, 10, B>), grid, dim3(256), lds_bytes, st, ev.start, ev.stop, 0, ta); \
-        else hipLaunchKernelGGL((k_warp_fused<8, M, 2, false, 10, B>), grid, dim3(256), lds_bytes, st, ta);                            \
+        if (ev.start) hipExtLaunchKernelGGL((k_warp_fused<8, M, F, false, 10, B>), grid, dim3(256), lds_bytes, st, ev.start, ev.stop, 0, ta); \
+        else hipLaunchKernelGGL((k_warp_fused<8, M, F, false, 10, B>), grid, dim3(256), lds_bytes, st, ta);                            \
     } while (0)
-#define VSTAB_LAUNCH10_M(M)                                        \
-    do {                                                           \
-        if (blend == VSTAB_BLEND_FP16) VSTAB_LAUNCH10(M, VSTAB_BLEND_FP16); \
-        else VSTAB_LAUNCH10(M, VSTAB_BLEND_EXACT);                 \
+#define VSTAB_LAUNCH10_M(M)                                                      \
+    do {                                                                         \
+        if (p010_out) {                                                          \
+            if (blend == VSTAB_BLEND_FP16) VSTAB_LAUNCH10(M, VSTAB_BLEND_FP16, 3); \
+            else VSTAB_LAUNCH10(M, VSTAB_BLEND_EXACT, 3);                        \
+        } else if (blend == VSTAB_BLEND_FP16) VSTAB_LAUNCH10(M, VSTAB_BLEND_FP16, 2); \
+        else VSTAB_LAUNCH10(M, VSTAB_BLEND_EXACT, 2);                            \
     } while (0)
     if (rot_bottom) {
         if (map_mode == VSTAB_MAP_CREATEMAP_CL) VSTAB_LAUNCH10_M(MAP_RS_CREATEMAP_CL);
