@@ -69,9 +69,12 @@ def parse():
     ap.add_argument("--ingest", default="inplace", choices=["inplace", "copy"],
                     help="inplace = upstream holds its frames (vstab_frame.hold), planes are read where they are, no pack kernel; "
                          "copy = hold 0: every frame goes through vstab_pack_nv12 into the library's ring")
-    ap.add_argument("--map-precision", default="ieee", choices=["ieee", "opencl"],
-                    help="ieee = createMap.cl with every operation IEEE-rounded (CPU-reproducible, the default); opencl = the arithmetic of "
-                         "the reference's own kernel as ROCm's OpenCL compiler builds it for gfx950 (bit-identical to that code object)")
+    ap.add_argument("--map-precision", default="opencl", choices=["ieee", "opencl"],
+                    help="opencl (default, as in vstab_config_default) = the arithmetic of the reference's own kernel, createMap.cl as ROCm's OpenCL "
+                         "compiler builds it for gfx950 (bit-identical to that code object, which is also the parity checker of the run); "
+                         "ieee = createMap.cl with every operation IEEE-rounded (CPU-reproducible; checked against the CPU oracle)")
+    ap.add_argument("--skip-ieee-pass", action="store_true",
+                    help="leave out the short extra pass that reports the IEEE-map rate beside the default run's (key `ieee_map`)")
     ap.add_argument("--pull", choices=("batch", "single"), default="single",
                     help="pipeline mode, BGR output: one vstab_pull_frame call per frame from this Python loop (default), or one "
                          "vstab_pull_frames call per step (the consumer's loop in C, as the reference's DisplayImage.cpp runs it); "
@@ -151,9 +154,18 @@ def shaky_ring(torch, dev, w, h, K, n, seed):
     return frames, rots
 
 
+GPUS_PER_NODE = 8  # an MI355X node carries eight GPUs: one GPU's fair share of the host is an eighth of its CPUs
+
+
 def box_cpu_share():
-    """Threads the CPU legs may use: this rank's affinity mask, capped at the 16 CPUs a one-GPU box is given."""
-    return max(1, min(len(os.sched_getaffinity(0)), 16))
+    """Threads the CPU legs may use: one GPU's share of the host -- its CPUs / 8 (SURVEY.md 8d: "the same box's host cores";
+    a 256-CPU node gives 32) -- and never more than this process is allowed to run on."""
+    return max(1, min(len(os.sched_getaffinity(0)), max(1, (os.cpu_count() or 1) // GPUS_PER_NODE)))
+
+
+def share_txt():
+    return (f"{box_cpu_share()} threads = min(CPUs this process may use: {len(os.sched_getaffinity(0))}, host CPUs / {GPUS_PER_NODE} GPUs per node: "
+            f"{(os.cpu_count() or 1) // GPUS_PER_NODE})")
 
 
 def cpu_baseline(w, h, K, Ko, cw, ch, budget_s=10.0, threads=None):
@@ -173,7 +185,7 @@ def cpu_baseline(w, h, K, Ko, cw, ch, budget_s=10.0, threads=None):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 2000:
             break
-    return {"value": round(n / el, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+    return {"value": round(n / el, 3), "unit": "frames/s", "cores": threads, "kind": "port", "share": share_txt() if threads > 1 else "1 thread",
             "sample": f"{n} frames of {w}x{h} NV12 -> {cw}x{ch} BGR, undistort-remap only "
                       f"(cvtColor+createMap+remap, identity rotation), OpenMP over rows, {el:.1f} s"}
 
@@ -365,9 +377,6 @@ def main():
         return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * Kx
 
     opencl = args.map_precision == "opencl"
-    if opencl and p010:
-        print("bench.py: --map-precision opencl exists for the 8-bit path", file=sys.stderr)
-        return 2
     map_mode = vs.MAP_CREATEMAP_CL_OPENCL if opencl else vs.MAP_CREATEMAP_CL
     kernel_events = []
     preroll = 0
@@ -397,8 +406,7 @@ def main():
             readouts = [np.eye(3) + 0.1 * (R - np.eye(3)) for R in readouts]
             readouts = [np.linalg.svd(R)[0] @ np.linalg.svd(R)[2] for R in readouts]   # back onto SO(3)
             extra = dict(bit_depth=10, readouts=readouts, pixel_depth=10, blend=vs.BLEND_FP16)
-        if opencl:
-            extra["map_precision"] = 1
+        extra["map_precision"] = vs.MAP_PRECISION_OPENCL if opencl else vs.MAP_PRECISION_IEEE
         ring_hold = 0 if args.ingest == "copy" else None
         stab = vs.Stabilizer(clip, total=preroll + (args.warmup + args.steps) * args.batch + 1000, preset=preset, smooth_radius=30, seed=1234 + rank,
                              tracking=0 if args.no_tracking else 1, ring_hold=ring_hold, **extra)
@@ -415,7 +423,8 @@ def main():
         stab.enable_profiling(1)  # timed region: HIP events around the warp launches only
         ingest_txt = ("frames used in place (upstream holds them: vstab_frame.hold), no pack kernel" if args.ingest == "inplace"
                       else "every frame copied into the library's ring (vstab_frame.hold = 0: vstab_pack_nv12)")
-        prec_txt = ", map in the OpenCL build's arithmetic (--map-precision opencl)" if opencl else ""
+        prec_txt = (", map in the arithmetic of the reference's own createMap kernel (createMap.cl built for gfx950 by ROCm's OpenCL compiler; bit-identical)"
+                    if opencl else ", map with every operation IEEE-rounded (--map-precision ieee: CPU-reproducible, not the reference's GPU arithmetic)")
         workload = (f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, full pipeline: {ingest_txt}; corner detect, pyramidal LK, rotation estimate, "
                     f"SG smoothing (r=30), fused undistort-remap{prec_txt}")
         if args.no_tracking:
@@ -423,7 +432,7 @@ def main():
                         f"fused undistort-remap from the map written once{prec_txt}")
         if p010:
             workload = (f"4k P010 {w}x{h} -> {'P010 planes' if p010_out else 'BGR 16-bit (10 significant)'} {cw}x{ch}, BASELINE config 5: full pipeline on the narrowed luma (corner detect, "
-                        "pyramidal LK, rotation estimate, SG r=30), 10-bit undistort-remap with fp16 blend and a rotation per output row")
+                        f"pyramidal LK, rotation estimate, SG r=30), 10-bit undistort-remap with fp16 blend and a rotation per output row{prec_txt}")
 
     # pipeline mode, BGR frames: a step is ONE library call that pulls the step's batch of frames into the output ring
     # (vstab_pull_frames: the consumer's frame loop on the C side of the boundary, where the reference has it)
@@ -461,7 +470,7 @@ def main():
 
     # correctness tie-in (outside the timed region): the next frame the pipeline emits, against the oracle's warp of the
     # same input frame under the rotation the pipeline reports for it (FrameSourceWarp.cpp:471-475); bit for bit
-    parity = None
+    parity, parity_against = None, None
     if mode == "pipeline" and rank == 0:
         import oracle
         n_emit = preroll + n_warm + n_timed  # index of the frame pulled now; frame 0 of the clip is never emitted
@@ -473,7 +482,8 @@ def main():
         if p010:
             rb = oracle.map_params(K, Ko, readouts[(n_emit + 1) % len(clip)] @ stab.warp_rotation(n_emit))[8:]
             s16 = src.view(np.uint16)
-            exp16 = oracle.warp_p010(s16[:h], s16[h:], pr, cw, ch, rb, 0, 1)
+            # opencl: the reference kernel's map row by row (one launch per output row with that row's matrix), oracle conversion and remap
+            exp16 = oracle.warp_p010_ref_gfx950(s16[:h], s16[h:], pr, cw, ch, rb, 1) if opencl else oracle.warp_p010(s16[:h], s16[h:], pr, cw, ch, rb, 0, 1)
             if p010_out:
                 ey, euv = oracle.cvt_bgr10_p010(exp16)
                 same = np.array_equal(got[0].cpu().numpy().view(np.uint16), ey) and np.array_equal(got[1].cpu().numpy().view(np.uint16), euv)
@@ -484,12 +494,18 @@ def main():
             same = np.array_equal(got[0].cpu().numpy().reshape(-1), exp_y.reshape(-1)) and np.array_equal(got[1].cpu().numpy().reshape(-1), exp_uv.reshape(-1))
         elif opencl:
             # the checker of this mode is the reference's own kernel (oracle/_ref/createMap.gfx950.co) run on this GPU, then
-            # the oracle's cvtColor and cv::remap
-            rx, ry = oracle.create_map_ref_gfx950(pr, cw, ch)
-            same = np.array_equal(got.cpu().numpy(), oracle.remap_bilinear(oracle.cvt_nv12_bgr(src), rx, ry))
+            # the oracle's cvtColor and cv::remap (and its BGR -> NV12 for the encoder hand-off format)
+            exp = oracle.warp_nv12_ref_gfx950(src, pr, cw, ch)
+            if nv12_out:
+                exp_y, exp_uv = oracle.cvt_bgr_nv12(exp)
+                same = np.array_equal(got[0].cpu().numpy().reshape(-1), exp_y.reshape(-1)) and np.array_equal(got[1].cpu().numpy().reshape(-1), exp_uv.reshape(-1))
+            else:
+                same = np.array_equal(got.cpu().numpy(), exp)
         else:
             same = np.array_equal(got.cpu().numpy(), oracle.warp_nv12(src, pr, cw, ch))
         parity = "ok" if same else "MISMATCH"
+        parity_against = ("the reference's createMap kernel (oracle/_ref/createMap.gfx950.co, run on this GPU) -> oracle cvtColor / remap" if opencl
+                          else "the CPU oracle's IEEE chain")
 
     # end-of-run record exchange: the run's only collective (RCCL all-gather over xGMI when N > 1),
     # then rank 0 writes the stitch list (concat.sh / join.ts format)
@@ -530,7 +546,7 @@ def main():
         # the same kernel with nothing beside it (no tracker / pyramid / detection kernels on other streams): back-to-back
         # launches on this stream, every launch with its own start / end stamps -- the figure that isolates kernel quality
         # from co-scheduling
-        alone_us, copy_ingest = None, None
+        alone_us, copy_ingest, ieee_map = None, None, None
         if mode == "pipeline":
             pa = vs.map_params(K, Ko, rot(7))
             run_alone = lambda i: vs.warp_nv12(clip[i % len(clip)], pa, cw, ch, map_mode, vs.OUT_NV12 if nv12_out else vs.OUT_BGR8,
@@ -569,6 +585,24 @@ def main():
                                "what": "the same pipeline with vstab_frame.hold = 0: every frame copied into the library's ring by vstab_pack_nv12 "
                                        f"(+{int(w * h * 3)} B of traffic and one kernel per frame); {10 * args.batch} frames after a 600-frame pre-roll, untimed region"}
                 cstab.close()
+            if opencl and not p010 and world == 1 and not args.skip_ieee_pass and not args.skip_copy_pass:
+                # the same pipeline with the CPU-reproducible map (every operation IEEE-rounded; vstab_config.map_precision = IEEE): the
+                # rate beside the default's, from a short run of its own in the untimed region
+                stab.close()
+                istab = vs.Stabilizer(clip, total=600 + 10 * args.batch + 100, preset=preset, smooth_radius=30, seed=1234 + rank,
+                                      tracking=0 if args.no_tracking else 1, ring_hold=ring_hold, **dict(extra, map_precision=vs.MAP_PRECISION_IEEE))
+                ipull = (lambda i: istab.pull_nv12_into(*outs[i % args.ring])) if nv12_out else (lambda i: istab.pull_into(outs[i % args.ring]))
+                for i in range(600):
+                    assert ipull(i)
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+                for i in range(10 * args.batch):
+                    assert ipull(i)
+                torch.cuda.synchronize()
+                ieee_map = {"value": round(10 * args.batch / (time.perf_counter() - tc), 1), "unit": "frames/s",
+                            "what": "the same pipeline with vstab_config.map_precision = IEEE (createMap.cl with every operation IEEE-rounded, reproducible by a "
+                                    f"CPU; not the reference's GPU arithmetic); {10 * args.batch} frames after a 600-frame pre-roll, untimed region"}
+                istab.close()
         alg_bytes = w * h * 1.5 + cw * ch * 3  # NV12 read once + BGR8 written once
         if nv12_out:
             alg_bytes = w * h * 1.5 + cw * ch + 2 * ((cw + 1) // 2) * ((ch + 1) // 2)
@@ -592,10 +626,10 @@ def main():
         traffic = float(args.traffic) if args.traffic else None
         committed = None
         tf = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-        if os.path.exists(tf) and not nv12_out and not cached and not p010 and not opencl:
-            prof = json.load(open(tf))
+        prof = json.load(open(tf)) if os.path.exists(tf) else None
+        if prof and not nv12_out and not cached and not p010 and prof.get("map_precision", "ieee") == args.map_precision:
             committed = {"traffic_bytes_per_launch": prof.get("hbm_bytes_per_launch"), "rocprof_avg_launch_us": prof.get("rocprof_avg_launch_us"),
-                         "valu_busy": prof.get("valu_busy"), "source": f"profiles/traffic_{args.workload}.json ({prof.get('round', 'r02')}: separate rocprofv3 "
+                         "valu_busy": prof.get("valu_busy"), "source": f"profiles/traffic_{args.workload}.json ({prof.get('round', 'r02')}, --map-precision {prof.get('map_precision', 'ieee')}: separate rocprofv3 "
                                                                          "--kernel-trace / --pmc passes of this command on another box)"}
         line = {
             "metric": "stabilized frames/sec at 4K NV12, 1/2/4/8 GPU; remap % HBM roofline",
@@ -605,7 +639,7 @@ def main():
             "config": {"workload": workload, "mode": mode, "clips": len(records), "ring_frames": args.ring, "frames_per_step": args.batch,
                        "frame_loop": ("vstab_pull_frames: one call per step" if batched else "vstab_pull_frame per frame from Python") if mode == "pipeline" else None,
                        "preset": "GOPRO_H4B_WIDE169_MEASURED", "parallelism": f"clip-per-gpu x{world}"},
-            "preroll": preroll, "parity_check": parity, "rank_cpus": pinned,
+            "preroll": preroll, "parity_check": parity, "parity_check_against": parity_against if parity else None, "rank_cpus": pinned,
             "collectives": args.dist_backend if use_dist else None,
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
@@ -622,6 +656,8 @@ def main():
         }
         if copy_ingest:
             line["copy_ingest"] = copy_ingest
+        if ieee_map:
+            line["ieee_map"] = ieee_map
         if stages:
             line["stages"] = stages  # every GPU stage timed (extra pass outside the timed region; chained LK launches off)
             line["stages_timed_region"] = timed_stages  # host waits + warp launches as they were in the timed region

@@ -55,6 +55,14 @@ VSTAB_API int vstab_device_count(void);
 /* sizeof() of the ABI structs as this library was compiled, for bindings to check their mirrors against:
  * 0 vstab_frame, 1 vstab_source, 2 vstab_config, 3 vstab_frame_log, 4 vstab_profile; -1 for any other index. */
 VSTAB_API int vstab_struct_size(int which);
+/* Layout version of the structs above.  It changes whenever one of them gains, loses or re-orders a member; a caller built against
+ * another version of this header must not share a vstab_config / vstab_frame with this library.  vstab_config carries it
+ * (vstab_config.abi_version, written by vstab_config_default) and vstab_create refuses any other value -- so a vstab_config MUST be
+ * initialised with vstab_config_default() and then modified, never zero-filled or assembled by hand.  vstab_frame is always
+ * allocated and zeroed by the library before a source callback fills it in.  Version 4: abi_version, vstab_frame.dmabuf_modifier;
+ * map_precision defaults to VSTAB_MAP_PRECISION_OPENCL. */
+#define VSTAB_ABI_VERSION 4
+VSTAB_API int vstab_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
  * Cameras (host, fp64).  Replaces get_preset_camera / get_output_camera,
@@ -125,6 +133,10 @@ VSTAB_API vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const 
 VSTAB_API vstab_status vstab_warp_nv12_nearest(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv,
                                                int src_width, int src_height, const float params[17], void *dst_bgr,
                                                size_t pitch_dst, int dst_width, int dst_height, void *stream);
+/* The same with the map arithmetic chosen: VSTAB_MAP_CREATEMAP_CL (0, what the call above uses) or VSTAB_MAP_CREATEMAP_CL_OPENCL (5). */
+VSTAB_API vstab_status vstab_warp_nv12_nearest_ex(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv,
+                                                  int src_width, int src_height, const float params[17], int map_mode, void *dst_bgr,
+                                                  size_t pitch_dst, int dst_width, int dst_height, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * the camera surface of the CLI's libdewobble filter (render.ts:611-617,
@@ -141,8 +153,10 @@ typedef enum vstab_map_mode {
     /* createMap.cl with the arithmetic the reference's OWN kernel has when ROCm's OpenCL compiler builds it for this GPU
      * (oracle/_ref/createMap.gfx950.co: contracted multiply-adds, reciprocal-based division, v_sqrt_f32, ocml's atan --
      * all inside OpenCL 1.2's error bounds, none IEEE-rounded).  Bit-identical to that code object run on the same
-     * device (tests/test_refcl_gpu.py); mode 0 is the same kernel with every operation IEEE-rounded, reproducible on a
-     * CPU.  The two differ in the last bits of the map. */
+     * device (tests/test_refcl_gpu.py) and the arithmetic the pipeline object uses by default
+     * (vstab_config.map_precision); mode 0 is the same kernel with every operation IEEE-rounded, reproducible on a
+     * CPU.  The two differ in the last bits of the map.  Served wherever mode 0 is: map planes,
+     * quantised map, fused warp, per-row (rolling-shutter) warp, nearest-neighbour warp, 10-bit warp. */
     VSTAB_MAP_CREATEMAP_CL_OPENCL = 5
 } vstab_map_mode;
 typedef enum vstab_out_format {
@@ -162,9 +176,11 @@ VSTAB_API vstab_status vstab_warp_nv12_ex(const void *y, size_t pitch_y, const v
                                           size_t pitch_dst_uv, int dst_width, int dst_height, void *stream);
 
 /* Rolling-shutter warp (BASELINE.json config 5: "rolling-shutter per-row warp"; no counterpart in the reference, whose gyro
- * path is a stub: gpmf.cpp:5-11): vstab_warp_nv12_ex for map modes 0 / 1 with a rotation per OUTPUT ROW.  Row y is mapped
+ * path is a stub: gpmf.cpp:5-11): vstab_warp_nv12_ex for map modes 0 / 1 / 5 with a rotation per OUTPUT ROW.  Row y is mapped
  * with the matrix whose nine entries are interpolated in fp32 between params[8..16] (first row) and rot_bottom (last row):
- * t = (float)y / (float)max(dst_height - 1, 1), m_k = fmaf(t, rot_bottom[k] - params[8 + k], params[8 + k]). */
+ * t = (float)y / (float)max(dst_height - 1, 1) (IEEE division), m_k = fmaf(t, rot_bottom[k] - params[8 + k], params[8 + k]);
+ * the row is then what the mode's createMap arithmetic makes of m -- in mode 5, what the reference's kernel returns for that
+ * row when it is handed m as its rotation. */
 VSTAB_API vstab_status vstab_warp_nv12_rs(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv,
                                           int src_width, int src_height, const float params[17], const float rot_bottom[9],
                                           int map_mode, int out_format, void *dst, size_t pitch_dst, void *dst_uv,
@@ -347,7 +363,14 @@ typedef struct vstab_frame {
                           the zero-copy replacement of the reference's VAAPI -> host -> OpenCL double copy
                           (AvFrameSourceMapOpenCl.cpp:17-66).  Ignored for other `mem` values. */
     size_t dmabuf_size; /* size of the object in bytes (AVDRMObjectDescriptor.size) */
+    uint64_t dmabuf_modifier; /* AVDRMObjectDescriptor.format_modifier of the object: how its bytes are arranged.  The kernels read
+                          rows of `pitch` bytes, so only DRM_FORMAT_MOD_LINEAR (0) is accepted -- and DRM_FORMAT_MOD_INVALID
+                          (0x00ffffffffffffff: "no modifier given", which libav reports for implicit-layout exports; such a surface
+                          is the exporter's to keep linear).  Any other value (a tiled / compressed surface) is refused with
+                          VSTAB_ERR_UNSUPPORTED instead of being read as garbage: map the surface linear (hwmap) first. */
 } vstab_frame;
+#define VSTAB_DRM_FORMAT_MOD_LINEAR 0ull
+#define VSTAB_DRM_FORMAT_MOD_INVALID 0x00ffffffffffffffull
 enum { VSTAB_MEM_DEVICE = 0, VSTAB_MEM_HOST = 1, VSTAB_MEM_DMABUF = 2 };
 
 /* Upstream FrameSource (FrameSource.hpp:14,20): return 0 and fill *out, VSTAB_EOF (-1) at end of
@@ -372,6 +395,7 @@ VSTAB_API vstab_status vstab_lens_camera(int projection, double dfov_deg, int wi
 /* Constructor arguments of FrameSourceWarp (FrameSourceWarp.hpp:83-91) plus what the reference
  * hard-codes.  vstab_config_default fills the reference's defaults. */
 typedef struct vstab_config {
+    int abi_version;     /* VSTAB_ABI_VERSION, written by vstab_config_default; vstab_create refuses anything else */
     int preset;          /* vstab_camera_preset */
     double scale;        /* 1 */
     int crop_borders;    /* 0 */
@@ -403,9 +427,12 @@ typedef struct vstab_config {
                             the narrowed luma exactly as in the 8-bit path, the frame is warped from the 16-bit planes with
                             vstab_warp_p010 and emitted by vstab_pull_frame_bgr16. */
     int blend;           /* pixel_depth 10: VSTAB_BLEND_EXACT (default) or VSTAB_BLEND_FP16 */
-    int map_precision;   /* lens_mode 0: VSTAB_MAP_PRECISION_IEEE (default; createMap.cl with every operation IEEE-rounded,
-                            reproducible by a CPU) or VSTAB_MAP_PRECISION_OPENCL (VSTAB_MAP_CREATEMAP_CL_OPENCL: the arithmetic the
-                            reference's own kernel has on this GPU; frames with a readout_rotation are refused in this mode) */
+    int map_precision;   /* lens_mode 0: VSTAB_MAP_PRECISION_OPENCL (default; VSTAB_MAP_CREATEMAP_CL_OPENCL: the arithmetic the reference's
+                            own kernel -- createMap.cl through ROCm's OpenCL compiler -- has on this GPU, bit-identical to it) or
+                            VSTAB_MAP_PRECISION_IEEE (createMap.cl with every operation IEEE-rounded: reproducible by a CPU, a few
+                            output bytes per frame away from the reference's GPU result).  Every path of the
+                            handle honours it: cached map (tracking off), read-out rotations, INTER_NEAREST, pixel_depth 10.
+                            lens_mode 1 ignores it (those maps are this library's own definitions, IEEE throughout). */
 } vstab_config;
 enum { VSTAB_MAP_PRECISION_IEEE = 0, VSTAB_MAP_PRECISION_OPENCL = 1 };
 
@@ -477,6 +504,8 @@ typedef struct vstab_profile {
     double host_corners_ms, host_track_wait_ms, host_estimate_ms, host_smooth_ms;  /* sums of wall time */
     long warp_launches;
     long warp_timed;     /* warp launches that gpu_warp_ms sums over (level 1 samples every 8th) */
+    long dmabuf_imports, dmabuf_evictions, dmabuf_cached; /* VSTAB_MEM_DMABUF: objects imported so far, unmapped again (least recently
+                            used, once more than 256 are cached and none of the window's frames can still refer to them), mapped now */
 } vstab_profile;
 /* level 0 = off, 1 = time every 8th warp launch only (event records are expensive host calls), 2 = every GPU stage */
 VSTAB_API vstab_status vstab_enable_profiling(vstab_handle *h, int level);

@@ -72,6 +72,7 @@ def lib():
         L.vo_create_map_rs.argtypes = [f32p, f32p, c.c_int, c.c_int, f32p, f32p, c.c_int]
         L.vo_warp_p010.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.c_int, c.c_int, f32p, f32p, c.c_int, c.c_int, c.c_void_p, c.c_int,
                                    c.c_int, u8p]
+        L.vo_remap_bilinear10.argtypes = [c.c_void_p, c.c_int, c.c_int, f32p, f32p, c.c_int, c.c_void_p, c.c_int, c.c_int]
         L.vo_cvt_p010_bgr10.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.c_void_p]
         L.vo_warp_nv12_rs.argtypes = [u8p, c.c_int, c.c_int, f32p, f32p, c.c_int, c.c_int, u8p, c.c_int, c.c_int, u8p]
         L.vo_min_eig.argtypes = [u8p, c.c_size_t, c.c_int, c.c_int, f32p]
@@ -120,17 +121,7 @@ def create_map_ref_gfx950(params, cols, rows, block=(64, 4)):
     """The reference's own createMap.cl, compiled unmodified by ROCm's OpenCL front end for gfx950
     (oracle/_ref/createMap.gfx950.co), launched on the current GPU exactly as FrameSourceWarp.cpp:272-304 does
     (global size {cols, rows}; arguments of :275-300).  -> (map_x, map_y) float32 (rows, cols)."""
-    global _RUNNER
-    if _RUNNER is None:
-        build()
-        R = ctypes.CDLL(os.path.join(_HERE, "_build", "libref_cl_runner.so"))
-        f32p = ctypes.POINTER(ctypes.c_float)
-        R.refcl_create_map.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, f32p, f32p, f32p, ctypes.c_int, ctypes.c_int,
-                                       ctypes.c_char_p, ctypes.c_int]
-        R.refcl_create_map.restype = ctypes.c_int
-        _RUNNER = R
-    if not os.path.exists(REF_GFX950_CO):
-        raise RuntimeError("oracle/_ref/createMap.gfx950.co not built")
+    _runner()
     p, pp = _f32(np.asarray(params, np.float32).reshape(17))
     mx = np.empty((rows, cols), np.float32)
     my = np.empty((rows, cols), np.float32)
@@ -140,6 +131,64 @@ def create_map_ref_gfx950(params, cols, rows, block=(64, 4)):
     if rc:
         raise RuntimeError("reference createMap (gfx950 code object): " + err.value.decode())
     return mx, my
+
+
+def _runner():
+    global _RUNNER
+    if _RUNNER is None:
+        build()
+        R = ctypes.CDLL(os.path.join(_HERE, "_build", "libref_cl_runner.so"))
+        f32p = ctypes.POINTER(ctypes.c_float)
+        R.refcl_create_map.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, f32p, f32p, f32p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_char_p, ctypes.c_int]
+        R.refcl_create_map.restype = ctypes.c_int
+        R.refcl_create_map_rs.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, f32p, f32p, f32p, f32p, ctypes.c_char_p, ctypes.c_int]
+        R.refcl_create_map_rs.restype = ctypes.c_int
+        _RUNNER = R
+    if not os.path.exists(REF_GFX950_CO):
+        raise RuntimeError("oracle/_ref/createMap.gfx950.co not built")
+    return _RUNNER
+
+
+def create_map_ref_gfx950_rs(params, rot_bottom, cols, rows):
+    """The rolling-shutter map in the reference kernel's arithmetic: row y = row y of the reference kernel's output when it is handed
+    the definition's matrix m(y) (include/vstab.h: vstab_warp_nv12_rs) as its rotation -- one launch of the code object per row."""
+    R = _runner()
+    p, pp = _f32(np.asarray(params, np.float32).reshape(17))
+    rb, rbp = _f32(np.asarray(rot_bottom, np.float32).reshape(9))
+    mx = np.empty((rows, cols), np.float32)
+    my = np.empty((rows, cols), np.float32)
+    err = ctypes.create_string_buffer(512)
+    if R.refcl_create_map_rs(REF_GFX950_CO.encode(), cols, rows, pp, rbp, _p(mx, ctypes.c_float), _p(my, ctypes.c_float), err, 512):
+        raise RuntimeError("reference createMap per row (gfx950 code object): " + err.value.decode())
+    return mx, my
+
+
+def warp_nv12_ref_gfx950(nv12, params, dw, dh, rot_bottom=None, nearest=False):
+    """cvtColor (oracle) -> createMap (the REFERENCE's kernel, on this GPU) -> cv::remap (oracle): the checker of the
+    OpenCL-precision map (the pipeline object's default).  rot_bottom: the rolling-shutter variant (a launch per row)."""
+    mx, my = create_map_ref_gfx950(params, dw, dh) if rot_bottom is None else create_map_ref_gfx950_rs(params, rot_bottom, dw, dh)
+    bgr = cvt_nv12_bgr(nv12)
+    return remap_nearest(bgr, mx, my) if nearest else remap_bilinear(bgr, mx, my)
+
+
+def remap_bilinear10(bgr10, mapx, mapy, blend=0):
+    """The 10-bit remap (vo_remap_pixel10: both blends) with map planes from anywhere.  bgr10: (h, w, 3) uint16, 0..1023."""
+    b = np.ascontiguousarray(bgr10, np.uint16)
+    h, w = b.shape[:2]
+    mx, mxp = _f32(mapx)
+    my, myp = _f32(mapy)
+    dh, dw = mx.shape
+    out = np.empty((dh, dw, 3), np.uint16)
+    lib().vo_remap_bilinear10(b.ctypes.data_as(ctypes.c_void_p), w, h, mxp, myp, int(blend), out.ctypes.data_as(ctypes.c_void_p), dw, dh)
+    return out
+
+
+def warp_p010_ref_gfx950(y, uv, params, dw, dh, rot_bottom=None, blend=0):
+    """The config-5 chain with the map from the reference's kernel on this GPU: 10-bit conversion (oracle) -> createMap (reference,
+    per row when rot_bottom is given) -> 10-bit remap (oracle)."""
+    mx, my = create_map_ref_gfx950(params, dw, dh) if rot_bottom is None else create_map_ref_gfx950_rs(params, rot_bottom, dw, dh)
+    return remap_bilinear10(cvt_p010_bgr10(y, uv), mx, my, blend)
 
 
 def _p(a, t):

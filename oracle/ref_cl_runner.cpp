@@ -77,3 +77,65 @@ extern "C" __attribute__((visibility("default"))) int refcl_create_map(const cha
     (void)hipModuleUnload(mod);
     return 0;
 }
+
+// The rolling-shutter variant's checker (config 5 has no reference counterpart; the definition -- include/vstab.h, vstab_warp_nv12_rs
+// -- gives every output row its own matrix m(y) and says the row is "what the reference's kernel returns for that row when it is
+// handed m(y) as its rotation").  Literally that: for every row y the reference kernel is launched over the whole frame with
+// m(y) in its nine rotation arguments and row y of its output is kept.  m_k(y) = fmaf((float)y / (float)max(rows - 1, 1),
+// rot_bottom[k] - params[8 + k], params[8 + k]) in IEEE binary32 (compiled with -ffp-contract=off; SSE division and glibc fmaf).
+#include <cmath>
+extern "C" __attribute__((visibility("default"))) int refcl_create_map_rs(const char *co_path, int cols, int rows, const float params[17],
+                                                                          const float rot_bottom[9], float *out_x, float *out_y, char *err,
+                                                                          int errlen) {
+    hipModule_t mod = nullptr;
+    void *dx = nullptr, *dy = nullptr;  // scratch planes of one launch
+    void *rx = nullptr, *ry = nullptr;  // the assembled result
+#undef RC_TRY
+#define RC_TRY(expr)                                          \
+    do {                                                      \
+        hipError_t e_ = (expr);                               \
+        if (e_ != hipSuccess) {                               \
+            if (mod) (void)hipModuleUnload(mod);              \
+            for (void *p_ : {dx, dy, rx, ry})                 \
+                if (p_) (void)hipFree(p_);                    \
+            return fail(err, errlen, #expr, e_);              \
+        }                                                     \
+    } while (0)
+    if (cols <= 0 || rows <= 0 || cols > 32767 || rows > 32767) {
+        if (err && errlen > 0) snprintf(err, (size_t)errlen, "bad size");
+        return -1;
+    }
+    RC_TRY(hipModuleLoad(&mod, co_path));
+    hipFunction_t fn = nullptr;
+    RC_TRY(hipModuleGetFunction(&fn, mod, "createMap"));
+    const size_t row_bytes = (size_t)cols * sizeof(float), bytes = row_bytes * rows;
+    RC_TRY(hipMalloc(&dx, bytes));
+    RC_TRY(hipMalloc(&dy, bytes));
+    RC_TRY(hipMalloc(&rx, bytes));
+    RC_TRY(hipMalloc(&ry, bytes));
+    RC_TRY(hipMemset(rx, 0xff, bytes));
+    RC_TRY(hipMemset(ry, 0xff, bytes));
+    float d[9];
+    for (int k = 0; k < 9; k++) d[k] = rot_bottom[k] - params[8 + k];
+    const float den = (float)(rows > 1 ? rows - 1 : 1);
+    const unsigned gx = (unsigned)((cols + 63) / 64), gy = (unsigned)((rows + 3) / 4);
+    for (int y = 0; y < rows; y++) {
+        CreateMapArgs a;
+        a.map_x = dx, a.step_x = cols * 4, a.offset_x = 0, a.rows = rows, a.cols = cols;
+        a.map_y = dy, a.step_y = cols * 4, a.offset_y = 0;
+        memcpy(a.f, params, sizeof(a.f));
+        const float t = (float)y / den;
+        for (int k = 0; k < 9; k++) a.f[8 + k] = std::fmaf(t, d[k], params[8 + k]);
+        size_t size = sizeof(a);
+        void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+        RC_TRY(hipModuleLaunchKernel(fn, gx, gy, 1, 64, 4, 1, 0, nullptr, nullptr, extra));  // (the kernarg buffer is copied at launch)
+        RC_TRY(hipMemcpyAsync(static_cast<char *>(rx) + (size_t)y * row_bytes, static_cast<char *>(dx) + (size_t)y * row_bytes, row_bytes, hipMemcpyDeviceToDevice, nullptr));
+        RC_TRY(hipMemcpyAsync(static_cast<char *>(ry) + (size_t)y * row_bytes, static_cast<char *>(dy) + (size_t)y * row_bytes, row_bytes, hipMemcpyDeviceToDevice, nullptr));
+    }
+    RC_TRY(hipDeviceSynchronize());
+    RC_TRY(hipMemcpy(out_x, rx, bytes, hipMemcpyDeviceToHost));
+    RC_TRY(hipMemcpy(out_y, ry, bytes, hipMemcpyDeviceToHost));
+    for (void *p_ : {dx, dy, rx, ry}) (void)hipFree(p_);
+    (void)hipModuleUnload(mod);
+    return 0;
+}

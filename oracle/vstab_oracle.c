@@ -535,6 +535,15 @@ static inline void vo_remap_pixel10(const uint16_t *src, int sw, int sh, float m
     }
 }
 
+/* The 10-bit remap on its own: 10-bit BGR frame (vo_cvt_p010_bgr10) + map planes -> 10-bit BGR.  Lets a test feed map planes
+ * that did not come from this file -- the reference's own createMap kernel run on the GPU (oracle/_ref/createMap.gfx950.co). */
+VO_API void vo_remap_bilinear10(const uint16_t *bgr, int w, int h, const float *mapx, const float *mapy, int blend, uint16_t *dst, int dw, int dh) {
+#pragma omp parallel for schedule(static)
+    for (int yy = 0; yy < dh; yy++)
+        for (int x = 0; x < dw; x++)
+            vo_remap_pixel10(bgr, w, h, mapx[(size_t)yy * dw + x], mapy[(size_t)yy * dw + x], blend, dst + ((size_t)yy * dw + x) * 3);
+}
+
 /* work: w*h*6 + 16 + 2*dw*dh*4 bytes.  rot_bottom may be NULL (one rotation for the frame). */
 VO_API void vo_warp_p010(const uint8_t *y, size_t pitch_y, const uint8_t *uv, size_t pitch_uv, int w, int h, const float *p,
                          const float *rot_bottom, int mode, int blend, uint16_t *dst, int dw, int dh, uint8_t *work) {

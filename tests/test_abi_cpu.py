@@ -115,3 +115,21 @@ def test_ctypes_mirrors_have_the_compiled_struct_sizes(vs):
     for k, t in enumerate((vs.Frame, vs.Source, vs.Config, vs.FrameLog, vs.Profile)):
         assert vs.lib.vstab_struct_size(k) == ctypes.sizeof(t), t.__name__
     assert vs.lib.vstab_struct_size(99) == -1
+
+
+def test_abi_version_gates_vstab_create(vs):
+    """vstab_config carries the struct-layout version: vstab_config_default writes it, vstab_create refuses a config that was
+    zero-filled or assembled against another header (before anything touches the device), and the header, the library and
+    the binding agree on the number."""
+    text = open(os.path.join(ROOT, "include", "vstab.h")).read()
+    assert int(re.search(r"#define VSTAB_ABI_VERSION (\d+)", text).group(1)) == vs.lib.vstab_abi_version() == vs.ABI_VERSION
+    cfg = vs.default_config()
+    assert cfg.abi_version == vs.ABI_VERSION and cfg.map_precision == vs.MAP_PRECISION_OPENCL
+    calls = []
+    cb = vs.PULL_FN(lambda user, out: calls.append(1) or vs.EOF)
+    src = vs.Source(cb, cb, None)
+    h = ctypes.c_void_p()
+    for bad in (vs.Config(), vs.default_config(abi_version=vs.ABI_VERSION - 1)):   # zero-filled; another header's layout
+        assert vs.lib.vstab_create(ctypes.byref(bad), ctypes.byref(src), ctypes.byref(h)) == vs.ERR_INVALID
+        assert b"vstab_config_default" in vs.lib.vstab_last_error() and not h.value
+    assert not calls   # refused before upstream was touched

@@ -3,6 +3,7 @@ rotation per output row) against its definition in the oracle (vo_warp_p010).  B
 import numpy as np
 import pytest
 
+import expect
 import oracle
 from test_p010_cpu import p010_frame
 
@@ -166,7 +167,7 @@ def test_pipeline_object_with_10bit_pixels(vs, cuda):
             assert np.array_equal(rots[i], rots8[i]), i                     # same tracker input -> same rotations, to the bit
             p = oracle.map_params(K, Ko, rots[i])
             y16, uv16 = wide[i + 1][:H], wide[i + 1][H:]
-            assert np.array_equal(outs[i].view(np.uint16), oracle.warp_p010(y16, uv16, p, cw, ch, None, 0, blend)), (blend, i)
+            assert np.array_equal(outs[i].view(np.uint16), expect.warp_p010(y16, uv16, p, cw, ch, None, blend)), (blend, i)
     assert max(oracle.rotation_angle(R) for R in rots8) > 1e-4
 
 
@@ -193,7 +194,7 @@ def test_p010_ring_source_with_readout_rotations(vs, cuda):
         Wr = stab.warp_rotation(i)
         p = oracle.map_params(K, Ko, Wr)
         rb = oracle.map_params(K, Ko, readouts[i + 1] @ Wr)[8:]
-        exp = oracle.warp_p010(wide[i + 1][:H], wide[i + 1][H:], p, cw, ch, rb, 0, 1)
+        exp = expect.warp_p010(wide[i + 1][:H], wide[i + 1][H:], p, cw, ch, rb, 1)
         assert np.array_equal(o.cpu().numpy().view(np.uint16), exp), i
         i += 1
     assert i == n - 1
@@ -250,7 +251,7 @@ def test_pipeline_emits_p010_planes(vs, cuda):
         if not stab.pull_p010_into(oy, ouv):
             break
         p = oracle.map_params(K, Ko, stab.warp_rotation(i))
-        ey, euv = oracle.cvt_bgr10_p010(oracle.warp_p010(wide[i + 1][:H], wide[i + 1][H:], p, cw, ch, None, 0, 0))
+        ey, euv = oracle.cvt_bgr10_p010(expect.warp_p010(wide[i + 1][:H], wide[i + 1][H:], p, cw, ch, None, 0))
         assert np.array_equal(host(oy), ey) and np.array_equal(host(ouv), euv), i
         i += 1
     assert i == n - 1

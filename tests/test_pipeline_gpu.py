@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 
+import expect
 import oracle
 import synth
 
@@ -33,9 +34,10 @@ def run_product(vs, cuda, frames, **cfg):
     return stab, outs
 
 
-def test_pipeline_matches_oracle_state_machine(vs, cuda, clip):
+@pytest.mark.parametrize("prec", [expect.OPENCL, expect.IEEE])
+def test_pipeline_matches_oracle_state_machine(vs, cuda, clip, prec):
     K, frames, rots = clip
-    stab, outs = run_product(vs, cuda, frames, smooth_radius=R_SMOOTH, seed=11)
+    stab, outs = run_product(vs, cuda, frames, smooth_radius=R_SMOOTH, seed=11, map_precision=prec)
     assert len(outs) == N - 1                                   # first frame never emitted (:403-407)
     log = stab.frame_log()
     assert len(log) == N - 1
@@ -78,7 +80,7 @@ def test_pipeline_matches_oracle_state_machine(vs, cuda, clip):
     # pixels: bit-exact against the oracle warp of the same frame with the product's own rotation
     for i in [0, 1, R_SMOOTH, N - 2]:
         p = oracle.map_params(K, Ko, stab.warp_rotation(i))
-        assert np.array_equal(outs[i], oracle.warp_nv12(exp_frames[i], p, cw, ch)), i
+        assert np.array_equal(outs[i], expect.warp(exp_frames[i], p, cw, ch, prec)), i
 
 
 def test_rotation_estimates_follow_ground_truth_and_stabilise(vs, cuda, clip):
@@ -95,28 +97,30 @@ def test_rotation_estimates_follow_ground_truth_and_stabilise(vs, cuda, clip):
     assert acc_err < 0.02
 
 
-def test_undistort_only_mode_is_identity_warp(vs, cuda, clip):
-    """BASELINE config 1: tracking off -> every emitted frame is the plain undistortion."""
+@pytest.mark.parametrize("prec", [expect.OPENCL, expect.IEEE])
+def test_undistort_only_mode_is_identity_warp(vs, cuda, clip, prec):
+    """BASELINE config 1: tracking off -> every emitted frame is the plain undistortion (from the third frame on it is warped
+    from the quantised map written once: the CACHED kernel, in the handle's map precision)."""
     K, frames, _ = clip
-    stab, outs = run_product(vs, cuda, frames[:8], smooth_radius=2, tracking=0)
+    stab, outs = run_product(vs, cuda, frames[:8], smooth_radius=2, tracking=0, map_precision=prec)
     assert len(outs) == 7
     Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
     p = oracle.map_params(K, Ko, np.eye(3))
-    for i in (0, 6):
+    for i in (0, 1, 2, 6):
         assert np.allclose(stab.warp_rotation(i), np.eye(3), atol=1e-12)
-        assert np.array_equal(outs[i], oracle.warp_nv12(frames[i + 1], p, cw, ch))
+        assert np.array_equal(outs[i], expect.warp(frames[i + 1], p, cw, ch, prec))
 
 
-def test_nearest_interpolation_through_the_pipeline(vs, cuda, clip):
+@pytest.mark.parametrize("prec", [expect.OPENCL, expect.IEEE])
+def test_nearest_interpolation_through_the_pipeline(vs, cuda, clip, prec):
     """vstab_config.interpolation 0 = INTER_NEAREST: same rotations, nearest-neighbour frames; other flags are refused."""
     K, frames, _ = clip
-    stab, outs = run_product(vs, cuda, frames[:8], smooth_radius=2, tracking=0, interpolation=0)
+    stab, outs = run_product(vs, cuda, frames[:8], smooth_radius=2, tracking=0, interpolation=0, map_precision=prec)
     Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
     p = oracle.map_params(K, Ko, np.eye(3))
-    mx, my = oracle.create_map(p, cw, ch)
     assert len(outs) == 7
     for i in (0, 6):
-        assert np.array_equal(outs[i], oracle.remap_nearest(oracle.cvt_nv12_bgr(frames[i + 1]), mx, my))
+        assert np.array_equal(outs[i], expect.warp(frames[i + 1], p, cw, ch, prec, nearest=True))
     ref, _ = run_product(vs, cuda, frames[:10], smooth_radius=2), None
     near, nouts = run_product(vs, cuda, frames[:10], smooth_radius=2, interpolation=0)
     for i in range(len(nouts)):
@@ -297,7 +301,7 @@ def test_pipeline_at_1080p_baseline_config(vs, cuda):
     assert log[0]["n_corners"] == len(corners) and log[0]["n_tracked"] == int((st > 0).sum())
     for i in range(n - 1):
         p = oracle.map_params(K, Ko, stab.warp_rotation(i))
-        assert np.array_equal(outs[i], oracle.warp_nv12(frames[i + 1], p, cw, ch)), i
+        assert np.array_equal(outs[i], expect.warp(frames[i + 1], p, cw, ch)), i
 
 
 def _run_raw_device_source(vs, cuda, frames, hold, recycle, p010=False, pool=0, lag=False, **cfg_kw):
@@ -381,97 +385,229 @@ def _hip_runtime():
     pytest.fail("no HIP runtime mapped")
 
 
+class _DmaBufPool:
+    """Device buffers exported as DMA-BUF fds (hipMemGetHandleForAddressRange): what a decoder's surface pool looks like to the
+    library.  Planes sit at byte offset 64 of each object."""
+
+    def __init__(self, frames):
+        import ctypes
+        self.ct = ctypes
+        hip = self.hip = _hip_runtime()
+        hip.hipMemGetHandleForAddressRange.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_ulonglong]
+        hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        hip.hipFree.argtypes = [ctypes.c_void_p]
+        hip.hipGetErrorString.restype = ctypes.c_char_p
+        hip.hipGetErrorString.argtypes = [ctypes.c_int]
+        self.size = (frames[0].nbytes + 64 + (1 << 21) - 1) & ~((1 << 21) - 1)        # whole 2 MiB pages
+        self.bufs, self.fds = [], []
+        for f in frames:
+            p = ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(p), self.size) == 0
+            self.bufs.append(p)
+            host = np.ascontiguousarray(f)
+            assert hip.hipMemcpy(ctypes.c_void_p(p.value + 64), host.ctypes.data_as(ctypes.c_void_p), host.nbytes, 1) == 0
+            fd = ctypes.c_int(-1)
+            e = hip.hipMemGetHandleForAddressRange(ctypes.byref(fd), p, self.size, 1, 0)   # hipMemRangeHandleTypeDmaBufFd
+            if e != 0:
+                self.close()
+                pytest.skip("this box cannot export device memory as a DMA-BUF: " + hip.hipGetErrorString(e).decode())
+            self.fds.append(fd.value)
+
+    def close(self):
+        import torch
+        torch.cuda.synchronize()
+        for fd in self.fds:
+            os.close(fd)
+        for p in self.bufs:
+            self.hip.hipFree(p)
+        self.fds, self.bufs = [], []
+
+
+def _run_dmabuf_source(vs, cuda, fill, **cfg_kw):
+    """Drive a handle from a callback that fills vstab_frame itself; -> (emitted frames, status of the pull that ended the
+    stream, its message, the handle's profile counters)."""
+    import ctypes
+    import torch
+    pull, peek = vs.PULL_FN(lambda u, o: fill(o.contents, True)), vs.PULL_FN(lambda u, o: fill(o.contents, False))
+    src = vs.Source(pull, peek, None)
+    cfg = vs.default_config(**cfg_kw)
+    h = ctypes.c_void_p()
+    assert vs.lib.vstab_create(ctypes.byref(cfg), ctypes.byref(src), ctypes.byref(h)) == vs.OK, vs.lib.vstab_last_error()
+    ow, oh = ctypes.c_int(), ctypes.c_int()
+    assert vs.lib.vstab_get_output_info(h, ctypes.byref(ow), ctypes.byref(oh), None, None) == vs.OK
+    outs = []
+    while True:
+        o = torch.empty((oh.value, ow.value, 3), dtype=torch.uint8, device=cuda)
+        st = vs.lib.vstab_pull_frame(h, o.data_ptr(), o.stride(0))
+        if st != vs.OK:
+            break
+        outs.append(o.cpu().numpy())
+    msg = vs.lib.vstab_last_error()
+    prof = vs.Profile()
+    assert vs.lib.vstab_get_profile(h, ctypes.byref(prof)) == vs.OK
+    vs.lib.vstab_destroy(h)
+    return outs, st, msg, prof
+
+
+def _open_fds():
+    return len(os.listdir("/proc/self/fd"))
+
+
 def test_dmabuf_frames_are_imported_and_read_in_place(vs, cuda, clip):
     """SURVEY.md 8(f) row 3 without libav: a decoder surface arrives as a DMA-BUF (what av_hwframe_map(..., DRM_PRIME) hands
     out: fd, size, per-plane offset and pitch).  A pool of device buffers is exported with
     hipMemGetHandleForAddressRange(DmaBufFd), every frame is handed over as {fd, size, offsets}; the library imports each
     object once and must produce the stream it produces from plain device pointers -- used in place (hold = forever) and
-    copied (hold = 0).  Replaces the VAAPI -> host -> OpenCL copies of AvFrameSourceMapOpenCl.cpp:17-66."""
-    import ctypes
-    import torch
+    copied (hold = 0) -- and one frame is compared with the checker as well (cvtColor -> reference createMap kernel -> remap).
+    Replaces the VAAPI -> host -> OpenCL copies of AvFrameSourceMapOpenCl.cpp:17-66."""
     K, frames, _ = clip
     n = 14
-    hip = _hip_runtime()
-    hip.hipMemGetHandleForAddressRange.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_ulonglong]
-    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
-    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-    hip.hipFree.argtypes = [ctypes.c_void_p]
-    hip.hipGetErrorString.restype = ctypes.c_char_p
-    hip.hipGetErrorString.argtypes = [ctypes.c_int]
-    size = (frames[0].nbytes + 64 + (1 << 21) - 1) & ~((1 << 21) - 1)        # whole 2 MiB pages, planes at an offset of 64 bytes
-    bufs, fds = [], []
+    pool = _DmaBufPool(frames[:n])
     try:
-        for f in frames[:n]:
-            p = ctypes.c_void_p()
-            assert hip.hipMalloc(ctypes.byref(p), size) == 0
-            bufs.append(p)
-            host = np.ascontiguousarray(f)
-            assert hip.hipMemcpy(ctypes.c_void_p(p.value + 64), host.ctypes.data_as(ctypes.c_void_p), host.nbytes, 1) == 0
-            fd = ctypes.c_int(-1)
-            e = hip.hipMemGetHandleForAddressRange(ctypes.byref(fd), p, size, 1, 0)   # hipMemRangeHandleTypeDmaBufFd
-            if e != 0:
-                pytest.skip("this box cannot export device memory as a DMA-BUF: " + hip.hipGetErrorString(e).decode())
-            fds.append(fd.value)
+        fds, size = pool.fds, pool.size
         ref_stab, ref = run_product(vs, cuda, frames[:n], smooth_radius=3, seed=9)
+        Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
         for hold in (1 << 29, 0):
             state = {"i": 0}
 
-            def fill(out, advance):
+            def fill(o, advance):
                 i = state["i"]
                 if i >= n:
                     return vs.EOF
-                o = out.contents
                 o.mem, o.dmabuf_fd, o.dmabuf_size = 2, fds[i], size
+                o.dmabuf_modifier = 0 if i % 2 else 0x00ffffffffffffff   # DRM_FORMAT_MOD_LINEAR / DRM_FORMAT_MOD_INVALID (implicit layout)
                 o.y, o.uv = 64, 64 + W * H                   # byte offsets inside the object
                 o.pitch_y = o.pitch_uv = W
                 o.width, o.height, o.pts, o.hold, o.bit_depth = W, H, i, hold, 8
                 if advance:
                     state["i"] += 1
                 return 0
-            pull, peek = vs.PULL_FN(lambda u, o: fill(o, True)), vs.PULL_FN(lambda u, o: fill(o, False))
-            src = vs.Source(pull, peek, None)
-            cfg = vs.default_config(smooth_radius=3, seed=9)
-            h = ctypes.c_void_p()
-            assert vs.lib.vstab_create(ctypes.byref(cfg), ctypes.byref(src), ctypes.byref(h)) == vs.OK, vs.lib.vstab_last_error()
-            ow, oh = ctypes.c_int(), ctypes.c_int()
-            assert vs.lib.vstab_get_output_info(h, ctypes.byref(ow), ctypes.byref(oh), None, None) == vs.OK
-            outs = []
-            while True:
-                o = torch.empty((oh.value, ow.value, 3), dtype=torch.uint8, device=cuda)
-                st = vs.lib.vstab_pull_frame(h, o.data_ptr(), o.stride(0))
-                if st == vs.EOF:
-                    break
-                assert st == vs.OK, vs.lib.vstab_last_error()
-                outs.append(o.cpu().numpy())
-            vs.lib.vstab_destroy(h)
-            assert len(outs) == len(ref) == n - 1
+            outs, st, _, prof = _run_dmabuf_source(vs, cuda, fill, smooth_radius=3, seed=9)
+            assert st == vs.EOF and len(outs) == len(ref) == n - 1
+            assert prof.dmabuf_imports == n and prof.dmabuf_evictions == 0 and prof.dmabuf_cached == n
             for i, (a, b) in enumerate(zip(outs, ref)):
                 assert np.array_equal(a, b), (hold, i)
+            assert np.array_equal(outs[4], expect.warp(frames[5], oracle.map_params(K, Ko, ref_stab.warp_rotation(4)), cw, ch))
         # a frame whose planes do not fit in the object is refused, with a message
-        state = {"i": 0}
 
-        def bad(out, advance):
-            o = out.contents
+        def bad(o, advance):
             o.mem, o.dmabuf_fd, o.dmabuf_size = 2, fds[0], size
             o.y, o.uv, o.pitch_y, o.pitch_uv = 64, size - 16, W, W
             o.width, o.height, o.hold, o.bit_depth = W, H, 0, 8
             return 0
-        pull, peek = vs.PULL_FN(lambda u, o: bad(o, True)), vs.PULL_FN(lambda u, o: bad(o, False))
-        src = vs.Source(pull, peek, None)
-        cfg = vs.default_config(smooth_radius=3, seed=9)
-        h = ctypes.c_void_p()
-        assert vs.lib.vstab_create(ctypes.byref(cfg), ctypes.byref(src), ctypes.byref(h)) == vs.OK
-        ow, oh = ctypes.c_int(), ctypes.c_int()
-        vs.lib.vstab_get_output_info(h, ctypes.byref(ow), ctypes.byref(oh), None, None)
-        o = torch.empty((oh.value, ow.value, 3), dtype=torch.uint8, device=cuda)
-        assert vs.lib.vstab_pull_frame(h, o.data_ptr(), o.stride(0)) == vs.ERR_INVALID and b"DMA-BUF" in vs.lib.vstab_last_error()
-        vs.lib.vstab_destroy(h)
+        outs, st, msg, _ = _run_dmabuf_source(vs, cuda, bad, smooth_radius=3, seed=9)
+        assert not outs and st == vs.ERR_INVALID and b"DMA-BUF" in msg
     finally:
-        torch.cuda.synchronize()
-        for fd in fds:
-            os.close(fd)
-        for p in bufs:
-            hip.hipFree(p)
+        pool.close()
+
+
+def test_dmabuf_tiled_surfaces_are_refused_not_read_as_linear(vs, cuda, clip):
+    """AVDRMObjectDescriptor.format_modifier travels in vstab_frame.dmabuf_modifier: anything but a linear layout (or "no
+    modifier") is refused with VSTAB_ERR_UNSUPPORTED -- the same buffer that is accepted as linear would otherwise be read as
+    rows of `pitch` bytes whatever its tiling (AvFrameSourceMapOpenCl.cpp:17-66 goes through hwframe transfers, which
+    de-tile; an in-place import must not pretend)."""
+    K, frames, _ = clip
+    pool = _DmaBufPool(frames[:4])
+    try:
+        AMD_TILED = (0x02 << 56) | 0x1001   # a DRM_FORMAT_MOD_AMD value (vendor 0x02): some GFX9+ tiling
+        for mod, ok in ((0, True), (AMD_TILED, False), (1 << 56 | 1, False)):
+            state = {"i": 0}
+
+            def fill(o, advance):
+                i = state["i"]
+                if i >= 4:
+                    return vs.EOF
+                o.mem, o.dmabuf_fd, o.dmabuf_size, o.dmabuf_modifier = 2, pool.fds[i], pool.size, mod
+                o.y, o.uv, o.pitch_y, o.pitch_uv = 64, 64 + W * H, W, W
+                o.width, o.height, o.pts, o.hold, o.bit_depth = W, H, i, 0, 8
+                if advance:
+                    state["i"] += 1
+                return 0
+            outs, st, msg, prof = _run_dmabuf_source(vs, cuda, fill, smooth_radius=1, tracking=0)
+            if ok:
+                assert st == vs.EOF and len(outs) == 3
+            else:
+                assert not outs and st == vs.ERR_UNSUPPORTED and b"modifier" in msg and b"LINEAR" in msg and prof.dmabuf_imports == 0
+    finally:
+        pool.close()
+
+
+def test_dmabuf_import_leaves_no_descriptor_behind(vs, cuda, clip):
+    """The import neither keeps nor needs the caller's descriptor (a duplicate per imported object used to leak).
+    Upstream hands a FRESH dup() of the surface's fd with every frame and closes it as soon as the next callback comes -- so
+    descriptor numbers are reused for different objects all the time (objects are recognised by their inode, not by the
+    number) -- and the process holds exactly as many descriptors after the handle is destroyed as before it was created."""
+    K, frames, _ = clip
+    n = 14
+    pool = _DmaBufPool(frames[:n])
+    try:
+        ref_stab, ref = run_product(vs, cuda, frames[:n], smooth_radius=3, seed=9)
+        before = _open_fds()
+        state = {"i": 0, "last": -1, "numbers": []}
+
+        def fill(o, advance):
+            if state["last"] >= 0:            # the descriptor handed out with the previous call: upstream is done with it
+                os.close(state["last"])
+                state["last"] = -1
+            i = state["i"]
+            if i >= n:
+                return vs.EOF
+            fd = os.dup(pool.fds[i])
+            state["last"] = fd
+            state["numbers"].append(fd)
+            o.mem, o.dmabuf_fd, o.dmabuf_size, o.dmabuf_modifier = 2, fd, pool.size, 0
+            o.y, o.uv, o.pitch_y, o.pitch_uv = 64, 64 + W * H, W, W
+            o.width, o.height, o.pts, o.hold, o.bit_depth = W, H, i, 1 << 29, 8
+            if advance:
+                state["i"] += 1
+            return 0
+        outs, st, _, prof = _run_dmabuf_source(vs, cuda, fill, smooth_radius=3, seed=9)
+        if state["last"] >= 0:
+            os.close(state["last"])
+        assert st == vs.EOF and len(outs) == n - 1 and prof.dmabuf_imports == n
+        assert len(set(state["numbers"])) < n          # the same descriptor number did stand for different objects
+        for i, (a, b) in enumerate(zip(outs, ref)):
+            assert np.array_equal(a, b), i
+        assert _open_fds() == before
+    finally:
+        pool.close()
+
+
+def test_dmabuf_cache_eviction_and_reimport(vs, cuda, clip, monkeypatch):
+    """More surfaces than the import cache holds (VSTAB_DMABUF_CACHE shrinks the 256-entry cache for the test): the least
+    recently used object is unmapped -- never one a frame of the look-ahead window may still refer to -- and imported again
+    when its turn comes round.  Every frame equals the plain-pointer stream, in place and copied."""
+    K, frames, _ = clip
+    n_pool, n = 30, 75
+    seq = [frames[i % n_pool] for i in range(n)]
+    pool = _DmaBufPool(frames[:n_pool])
+    try:
+        ref_stab, ref = run_product(vs, cuda, seq, smooth_radius=1, seed=9)
+        monkeypatch.setenv("VSTAB_DMABUF_CACHE", "4")
+        for hold in (1 << 29, 0):
+            state = {"i": 0}
+
+            def fill(o, advance):
+                i = state["i"]
+                if i >= n:
+                    return vs.EOF
+                o.mem, o.dmabuf_fd, o.dmabuf_size, o.dmabuf_modifier = 2, pool.fds[i % n_pool], pool.size, 0
+                o.y, o.uv, o.pitch_y, o.pitch_uv = 64, 64 + W * H, W, W
+                o.width, o.height, o.pts, o.hold, o.bit_depth = W, H, i, hold, 8
+                if advance:
+                    state["i"] += 1
+                return 0
+            outs, st, _, prof = _run_dmabuf_source(vs, cuda, fill, smooth_radius=1, seed=9)
+            assert st == vs.EOF and len(outs) == n - 1
+            # the ring has 18 slots: an object is kept for 20 pulls after its last use, so the cache settles at ~21 objects (not 4,
+            # not 30) and every object is imported again on each pass over the pool
+            assert prof.dmabuf_evictions >= n - n_pool and prof.dmabuf_imports == prof.dmabuf_evictions + prof.dmabuf_cached
+            assert 4 < prof.dmabuf_cached < n_pool and prof.dmabuf_imports > n_pool
+            for i, (a, b) in enumerate(zip(outs, ref)):
+                assert np.array_equal(a, b), (hold, i)
+    finally:
+        pool.close()
 
 
 def test_frame_lifetime_promise_hold(vs, cuda, clip):
@@ -668,12 +804,13 @@ def test_external_rotation_source_replaces_optical_flow(vs, cuda, clip):
         assert np.allclose(warp_R[i], rec[i], atol=1e-11), i
     for i in (0, 5, n - 2):
         p = oracle.map_params(K, Ko, warp_R[i])
-        assert np.array_equal(outs[i], oracle.warp_nv12(exp_frames[i], p, cw, ch)), i
+        assert np.array_equal(outs[i], expect.warp(exp_frames[i], p, cw, ch)), i
     # the correction really follows the sensor: it is not the identity
     assert max(oracle.rotation_angle(R) for R in warp_R) > 1e-3
 
 
-def test_rolling_shutter_readout_rotation_reaches_the_warp(vs, cuda, clip):
+@pytest.mark.parametrize("prec", [expect.OPENCL, expect.IEEE])
+def test_rolling_shutter_readout_rotation_reaches_the_warp(vs, cuda, clip, prec):
     """BASELINE config 5 in the pipeline object: a sensor source that also reports the camera's rotation during the frame's
     read-out.  The stabilising rotation W is what it would be without it (the smoother sees the per-frame deltas only); the
     frame is warped with W for its first row and readout * W for its last (oracle.warp_nv12_rs, the definition of
@@ -710,7 +847,7 @@ def test_rolling_shutter_readout_rotation_reaches_the_warp(vs, cuda, clip):
         pull = vs.PULL_FN(lambda u, o: fill(o, True))
         peek = vs.PULL_FN(lambda u, o: fill(o, False))
         src = vs.Source(pull, peek, None)
-        cfg = vs.default_config(smooth_radius=r, tracking=0)
+        cfg = vs.default_config(smooth_radius=r, tracking=0, map_precision=prec)
         h = ctypes.c_void_p()
         assert vs.lib.vstab_create(ctypes.byref(cfg), ctypes.byref(src), ctypes.byref(h)) == vs.OK
         outs, warp_R = [], []
@@ -737,11 +874,11 @@ def test_rolling_shutter_readout_rotation_reaches_the_warp(vs, cuda, clip):
         p = oracle.map_params(K, Ko, warp_R[i])
         if k % 4 != 2:
             pb = oracle.map_params(K, Ko, readouts[k] @ warp_R[i])
-            assert np.array_equal(outs[i], oracle.warp_nv12_rs(frames[k], p, pb[8:], cw, ch)), i
+            assert np.array_equal(outs[i], expect.warp(frames[k], p, cw, ch, prec, rot_bottom=pb[8:])), i
             differ += not np.array_equal(outs[i], plain[i])
         else:
             assert np.array_equal(outs[i], plain[i]), i
-            assert np.array_equal(outs[i], oracle.warp_nv12(frames[k], p, cw, ch)), i
+            assert np.array_equal(outs[i], expect.warp(frames[k], p, cw, ch, prec)), i
     assert differ >= 6                                             # it is not a no-op
 
 
@@ -778,7 +915,7 @@ def _check_against_oracle_state_machine(vs, cuda, frames, K, w, h, r, seed):
     for i in range(len(outs)):
         assert np.allclose(stab.warp_rotation(i), warp_rots[i], atol=1e-9), i
         p = oracle.map_params(K, Ko, stab.warp_rotation(i))
-        assert np.array_equal(outs[i], oracle.warp_nv12(exp[i], p, cw, ch)), i
+        assert np.array_equal(outs[i], expect.warp(exp[i], p, cw, ch)), i
     return log
 
 
@@ -850,7 +987,7 @@ def test_pipeline_at_4k_baseline_config(vs, cuda):
     assert (cw, ch) == (3524, 1999)
     s2 = vs.Stabilizer([torch.from_numpy(f).to(cuda) for f in frames], total=n, smooth_radius=r, seed=2)
     y, uv = s2.pull_nv12()
-    bgr = oracle.warp_nv12(frames[1], oracle.map_params(K, Ko, s2.warp_rotation(0)), cw, ch)
+    bgr = expect.warp(frames[1], oracle.map_params(K, Ko, s2.warp_rotation(0)), cw, ch)
     ey, euv = oracle.cvt_bgr_nv12(bgr)
     assert np.array_equal(y.cpu().numpy(), ey) and np.array_equal(uv.cpu().numpy().reshape(euv.shape), euv)
 
@@ -951,7 +1088,7 @@ def _bench_shaped_run(vs, cuda, w, h, r, n, min_keys):
     for k in range(n - 1):
         assert np.allclose(stab.warp_rotation(k), warp_rots[k], atol=1e-9), k
     for k, got in outs.items():
-        assert np.array_equal(got, oracle.warp_nv12(exp[k], oracle.map_params(K, Ko, stab.warp_rotation(k)), cw, ch)), k
+        assert np.array_equal(got, expect.warp(exp[k], oracle.map_params(K, Ko, stab.warp_rotation(k)), cw, ch)), k
 
 
 @pytest.mark.gpu

@@ -222,5 +222,128 @@ def test_pipeline_object_in_opencl_map_precision(refcl, vs, cuda):
         assert np.array_equal(img, oracle.remap_bilinear(oracle.cvt_nv12_bgr(frames[i + 1]), rx, ry)), i
         differ += int((img != g0[i]).sum())
     assert differ > 0   # the two precisions are different maps (a few bytes per frame), not the same mode twice
+
+
+def test_opencl_precision_is_the_default_of_the_pipeline_object(vs):
+    """vstab_config_default: the reference's map is what ITS kernel computes on this GPU, so that is the handle's default."""
+    cfg = vs.default_config()
+    assert cfg.map_precision == vs.MAP_PRECISION_OPENCL == 1 and cfg.abi_version == vs.ABI_VERSION
+
+
+@pytest.mark.parametrize("w,h", [(322, 182), (640, 360), (1920, 1080)])
+def test_rolling_shutter_warp_opencl_mode_is_the_reference_kernel_row_by_row(refcl, vs, cuda, w, h):
+    """vstab_warp_nv12_rs in mode 5.  The per-row matrix m(y) is this library's definition (config 5 has no reference
+    counterpart); what is done with it is the reference's: row y of the output must be row y of what createMap.cl's code object
+    returns when it is handed m(y) as its rotation (oracle.create_map_ref_gfx950_rs: one launch of the reference kernel per
+    row), then cv::remap.  BGR and NV12 output; equal first / last rotations reproduce the per-frame warp."""
+    K, Ko, (cw, ch) = cams(w, h)
+    frame = synth.nv12(23, w, h)
+    fd = dev(frame, cuda)
+    bgr = oracle.cvt_nv12_bgr(frame)
+    for top, bottom in (((0.01, -0.02, 0.005), (0.03, -0.01, -0.01)), ((-0.15, 0.1, 0.3), (-0.13, 0.12, 0.28))):
+        p = oracle.map_params(K, Ko, oracle.rodrigues(top))
+        rb = oracle.map_params(K, Ko, oracle.rodrigues(bottom))[8:]
+        rx, ry = oracle.create_map_ref_gfx950_rs(p, rb, cw, ch)
+        exp = oracle.remap_bilinear(bgr, rx, ry)
+        got = vs.warp_nv12_rs(fd, p, rb, cw, ch, OCL).cpu().numpy()
+        assert np.array_equal(got, exp), (w, top, int((got != exp).sum()))
+        if w < 1000:
+            y, uv = vs.warp_nv12_rs(fd, p, rb, cw, ch, OCL, vs.OUT_NV12)
+            ey, euv = oracle.cvt_bgr_nv12(exp)
+            assert np.array_equal(y.cpu().numpy(), ey) and np.array_equal(uv.cpu().numpy().reshape(euv.shape), euv)
+        # and it is not the IEEE-mode warp with another name
+        assert w < 1000 or not np.array_equal(got, vs.warp_nv12_rs(fd, p, rb, cw, ch, 0).cpu().numpy())
+    # the first row's launch of the per-row checker IS the plain reference map's first row; equal rotations: the whole map
+    same_x, same_y = oracle.create_map_ref_gfx950_rs(p, p[8:], cw, ch)
+    px, py = refcl(p, cw, ch)
+    assert same_bits(same_x, px) and same_bits(same_y, py)
+    assert np.array_equal(vs.warp_nv12_rs(fd, p, p[8:], cw, ch, OCL).cpu().numpy(), vs.warp_nv12(fd, p, cw, ch, mode=OCL).cpu().numpy())
+
+
+def test_nearest_warp_opencl_mode_equals_reference_kernel_then_nearest_remap(refcl, vs, cuda):
+    """INTER_NEAREST (FrameSourceWarp.hpp:90) with the reference kernel's map: cvRound + saturate_cast<short> of every entry."""
+    for w, h in ((640, 360), (130, 74)):
+        K, Ko, (cw, ch) = cams(w, h)
+        frame = synth.nv12(24, w, h)
+        for rv in ROTS[:4]:
+            p = oracle.map_params(K, Ko, oracle.rodrigues(rv))
+            exp = oracle.remap_nearest(oracle.cvt_nv12_bgr(frame), *refcl(p, cw, ch))
+            got = vs.warp_nv12_nearest(dev(frame, cuda), p, cw, ch, mode=OCL).cpu().numpy()
+            assert np.array_equal(got, exp), (w, rv)
     with pytest.raises(vs.VstabError):
-        vs.Stabilizer(dev_frames, total=4, smooth_radius=1, map_precision=1, pixel_depth=10)
+        vs.warp_nv12_nearest(dev(frame, cuda), p, cw, ch, mode=1)
+
+
+def _p010(seed, w, h):
+    from test_p010_cpu import p010_frame
+    y, uv, _, _ = p010_frame(seed, w, h)
+    return y, uv
+
+
+def _dev16(a, cuda):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).to(cuda)
+
+
+@pytest.mark.parametrize("w,h", [(640, 360), (328, 182), (72, 34)])
+def test_p010_warp_opencl_mode_equals_reference_kernel_then_10bit_remap(refcl, vs, cuda, w, h):
+    """The 10-bit pixel path (config 5) with the reference kernel's map: 10-bit conversion (oracle) -> createMap (REFERENCE, on this
+    GPU; per row for the rolling-shutter variant) -> 10-bit remap (oracle), both blends, through the LDS-tiled kernel (aligned
+    planes), the direct-gather kernel (planes that are 2-byte-aligned views) and with P010 planes out."""
+    import torch
+    y, uv = _p010(41, w, h)
+    yd, ud = _dev16(y, cuda), _dev16(uv, cuda)
+    K, Ko, (cw, ch) = cams(w, h)
+    bgr10 = oracle.cvt_p010_bgr10(y, uv)
+    # unaligned views of the same samples: the direct-gather kernel
+    Yb = torch.zeros((h + 1, w + 6), dtype=torch.int16, device=cuda)
+    Ub = torch.zeros((h // 2 + 1, w + 6), dtype=torch.int16, device=cuda)
+    Yb[1:, 2:w + 2] = yd
+    Ub[1:, 2:w + 2] = ud
+    for top, bottom in (((0.0, 0.0, 0.0), None), ((0.02, -0.03, 0.01), None), ((0.01, -0.02, 0.005), (0.03, -0.01, -0.01))):
+        p = oracle.map_params(K, Ko, oracle.rodrigues(top))
+        rb = None if bottom is None else oracle.map_params(K, Ko, oracle.rodrigues(bottom))[8:]
+        rx, ry = refcl(p, cw, ch) if rb is None else oracle.create_map_ref_gfx950_rs(p, rb, cw, ch)
+        for blend in (vs.BLEND_EXACT, vs.BLEND_FP16):
+            exp = oracle.remap_bilinear10(bgr10, rx, ry, blend)
+            got = vs.warp_p010(yd, ud, p, cw, ch, rb, OCL, blend).cpu().numpy().view(np.uint16)
+            assert np.array_equal(got, exp), (w, top, blend, int((got != exp).sum()))
+            got = vs.warp_p010(Yb[1:, 2:w + 2], Ub[1:, 2:w + 2], p, cw, ch, rb, OCL, blend).cpu().numpy().view(np.uint16)
+            assert np.array_equal(got, exp), ("direct", w, top, blend)
+            oy, ouv = vs.warp_p010_planes(yd, ud, p, cw, ch, rb, OCL, blend)
+            ey, euv = oracle.cvt_bgr10_p010(exp)
+            assert np.array_equal(oy.cpu().numpy().view(np.uint16), ey) and np.array_equal(ouv.cpu().numpy().view(np.uint16), euv), ("planes", w, top, blend)
+
+
+def test_p010_warp_opencl_mode_at_4k_config5(refcl, vs, cuda):
+    """BASELINE config 5 at full size in the reference kernel's arithmetic: 4K P010, fp16 blend, a rotation per output row
+    (1999 launches of the reference kernel, one per row, make the checker's map)."""
+    w, h = 3840, 2160
+    y, uv = _p010(42, w, h)
+    K, Ko, (cw, ch) = cams(w, h)
+    p = oracle.map_params(K, Ko, oracle.rodrigues((0.02, -0.03, 0.01)))
+    rb = oracle.map_params(K, Ko, oracle.rodrigues((0.022, -0.028, 0.012)))[8:]
+    rx, ry = oracle.create_map_ref_gfx950_rs(p, rb, cw, ch)
+    exp = oracle.remap_bilinear10(oracle.cvt_p010_bgr10(y, uv), rx, ry, 1)
+    got = vs.warp_p010(_dev16(y, cuda), _dev16(uv, cuda), p, cw, ch, rb, OCL, vs.BLEND_FP16).cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, exp), int((got != exp).sum())
+
+
+def test_undistort_only_pipeline_at_1080p_warps_from_the_cached_reference_map(refcl, vs, cuda):
+    """BASELINE config 1 geometry through the pipeline object with its defaults (tracking off): from the third frame on the
+    handle warps from the quantised map it wrote once (the CACHED kernel) -- that map is the reference kernel's, rounded."""
+    import torch
+    w, h = 1920, 1080
+    K, Ko, (cw, ch) = cams(w, h)
+    frames = [synth.nv12(50 + i, w, h) for i in range(6)]
+    stab = vs.Stabilizer([torch.from_numpy(f).to(cuda) for f in frames], total=len(frames), smooth_radius=1, tracking=0)
+    p = oracle.map_params(K, Ko, np.eye(3))
+    rx, ry = refcl(p, cw, ch)
+    i = 0
+    while True:
+        o = stab.pull()
+        if o is None:
+            break
+        assert np.array_equal(o.cpu().numpy(), oracle.remap_bilinear(oracle.cvt_nv12_bgr(frames[i + 1]), rx, ry)), i
+        i += 1
+    assert i == len(frames) - 1

@@ -44,7 +44,7 @@ _u8p, _i64, _u64 = _c.POINTER(_c.c_ubyte), _c.c_int64, _c.c_uint64
 class Frame(_c.Structure):  # vstab_frame
     _fields_ = [("y", _vp), ("uv", _vp), ("pitch_y", _sz), ("pitch_uv", _sz), ("width", _i), ("height", _i),
                 ("mem", _i), ("pts", _i64), ("delta_rotation", _dp), ("bit_depth", _i), ("hold", _i),
-                ("readout_rotation", _dp), ("dmabuf_fd", _i), ("dmabuf_size", _sz)]
+                ("readout_rotation", _dp), ("dmabuf_fd", _i), ("dmabuf_size", _sz), ("dmabuf_modifier", _u64)]
 
 
 PULL_FN = _c.CFUNCTYPE(_i, _vp, _c.POINTER(Frame))
@@ -55,7 +55,7 @@ class Source(_c.Structure):  # vstab_source
 
 
 class Config(_c.Structure):  # vstab_config
-    _fields_ = [("preset", _i), ("scale", _d), ("crop_borders", _i), ("zoom", _d), ("smooth_radius", _i),
+    _fields_ = [("abi_version", _i), ("preset", _i), ("scale", _d), ("crop_borders", _i), ("zoom", _d), ("smooth_radius", _i),
                 ("interpolation", _i), ("smoother", _i), ("tracking", _i), ("seed", _u64), ("stream", _vp),
                 ("lens_mode", _i), ("in_projection", _i), ("out_projection", _i), ("in_dfov", _d), ("out_dfov", _d),
                 ("out_width", _i), ("out_height", _i), ("out_cx", _d), ("out_cy", _d), ("debug", _i), ("pixel_depth", _i),
@@ -71,13 +71,15 @@ class Profile(_c.Structure):  # vstab_profile
     _fields_ = [("frames_consumed", _c.c_long), ("frames_emitted", _c.c_long), ("key_frames", _c.c_long),
                 ("gpu_ingest_ms", _d), ("gpu_pyramid_ms", _d), ("gpu_corners_ms", _d), ("gpu_lk_ms", _d), ("gpu_warp_ms", _d),
                 ("host_corners_ms", _d), ("host_track_wait_ms", _d), ("host_estimate_ms", _d), ("host_smooth_ms", _d),
-                ("warp_launches", _c.c_long), ("warp_timed", _c.c_long)]
+                ("warp_launches", _c.c_long), ("warp_timed", _c.c_long),
+                ("dmabuf_imports", _c.c_long), ("dmabuf_evictions", _c.c_long), ("dmabuf_cached", _c.c_long)]
 
 
 SMOOTHER_SG, SMOOTHER_KALMAN, SMOOTHER_NONE, SMOOTHER_FIXED = 0, 1, 2, 3
 PROJ_RECT, PROJ_FISH = 0, 1
 MAP_CREATEMAP_CL, MAP_FISH_TO_RECT, MAP_FISH_TO_FISH, MAP_RECT_TO_RECT, MAP_RECT_TO_FISH, MAP_CREATEMAP_CL_OPENCL = range(6)
 OUT_BGR8, OUT_NV12 = 0, 1
+MAP_PRECISION_IEEE, MAP_PRECISION_OPENCL = 0, 1
 _pp = _c.POINTER(_vp)
 
 # name -> (restype, argtypes); mirrors include/vstab.h one to one
@@ -86,6 +88,7 @@ SIGNATURES = {
     "vstab_version": (_c.c_char_p, []),
     "vstab_device_count": (_i, []),
     "vstab_struct_size": (_i, [_i]),
+    "vstab_abi_version": (_i, []),
     "vstab_get_preset_camera": (_i, [_i, _i, _i, _dp]),
     "vstab_get_output_camera": (_i, [_dp, _i, _i, _d, _i, _d, _dp, _ip, _ip]),
     "vstab_fisheye_undistort_points": (_i, [_dp, _i, _dp, _dp, _dp, _dp]),
@@ -97,6 +100,7 @@ SIGNATURES = {
     "vstab_remap_bilinear": (_i, [_vp, _sz, _i, _i, _i, _vp, _sz, _vp, _sz, _vp, _sz, _i, _i, _vp]),
     "vstab_warp_nv12_bgr": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _vp, _sz, _i, _i, _vp]),
     "vstab_warp_nv12_nearest": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _vp, _sz, _i, _i, _vp]),
+    "vstab_warp_nv12_nearest_ex": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _vp, _sz, _i, _i, _vp]),
     "vstab_create_map_ex": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _vp]),
     "vstab_warp_nv12_ex": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _i, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
     "vstab_warp_nv12_rs": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _fp, _i, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
@@ -147,6 +151,9 @@ for _name, (_res, _args) in SIGNATURES.items():
     _f.restype, _f.argtypes = _res, _args
 
 lib = _L
+ABI_VERSION = 4  # include/vstab.h: VSTAB_ABI_VERSION
+if _L.vstab_abi_version() != ABI_VERSION:
+    raise ImportError(f"video-annotator_amd: this binding mirrors ABI version {ABI_VERSION}, libvstab.so is version {_L.vstab_abi_version()}")
 for _k, _t in enumerate((Frame, Source, Config, FrameLog, Profile)):  # the ctypes mirrors must match the compiled structs
     if _L.vstab_struct_size(_k) != _c.sizeof(_t):
         raise ImportError(f"video-annotator_amd: ctypes mirror of {_t.__name__} is {_c.sizeof(_t)} bytes, libvstab.so has {_L.vstab_struct_size(_k)}")
@@ -310,14 +317,18 @@ def warp_nv12_bgr(nv12, params, dw, dh, out=None):
     return out
 
 
-def warp_nv12_nearest(nv12, params, dw, dh, out=None):
-    """vstab_warp_nv12_nearest: the fused warp with cv::remap's INTER_NEAREST."""
+def warp_nv12_nearest(nv12, params, dw, dh, out=None, mode=None):
+    """vstab_warp_nv12_nearest(_ex): the fused warp with cv::remap's INTER_NEAREST."""
     import torch
     yp, uvp, pitch, w, h = _planes(nv12)
     p = np.ascontiguousarray(params, np.float32)
     if out is None:
         out = torch.empty((dh, dw, 3), dtype=torch.uint8, device=nv12.device)
-    _check(_L.vstab_warp_nv12_nearest(yp, pitch, uvp, pitch, w, h, _fptr(p), out.data_ptr(), out.stride(0), dw, dh, _stream()), "vstab_warp_nv12_nearest")
+    if mode is None:
+        _check(_L.vstab_warp_nv12_nearest(yp, pitch, uvp, pitch, w, h, _fptr(p), out.data_ptr(), out.stride(0), dw, dh, _stream()), "vstab_warp_nv12_nearest")
+    else:
+        _check(_L.vstab_warp_nv12_nearest_ex(yp, pitch, uvp, pitch, w, h, _fptr(p), int(mode), out.data_ptr(), out.stride(0), dw, dh, _stream()),
+               "vstab_warp_nv12_nearest_ex")
     return out
 
 

@@ -214,8 +214,13 @@ __device__ __forceinline__ void map_pixel32_x2(float icx32, float icy32, float i
 enum MapMode { MAP_CREATEMAP_CL = 0, MAP_FISH_TO_RECT = 1, MAP_FISH_TO_FISH = 2, MAP_RECT_TO_RECT = 3, MAP_RECT_TO_FISH = 4,
                // createMap.cl with the arithmetic ROCm's OpenCL compiler gives it on gfx950 (below)
                MAP_CREATEMAP_CL_OPENCL = 5,
-               // internal: modes 0 / 1 with a per-row rotation (rolling shutter, BASELINE config 5)
-               MAP_RS_CREATEMAP_CL = 6, MAP_RS_FISH_TO_RECT = 7 };
+               // internal: modes 0 / 1 / 5 with a per-row rotation (rolling shutter, BASELINE config 5)
+               MAP_RS_CREATEMAP_CL = 6, MAP_RS_FISH_TO_RECT = 7, MAP_RS_CREATEMAP_CL_OPENCL = 8 };
+// the projection pair (and arithmetic) of a mode: the rolling-shutter modes share their base mode's
+constexpr bool map_mode_is_rs(int mode) { return mode >= MAP_RS_CREATEMAP_CL; }
+constexpr int map_mode_base(int mode) {
+    return mode == MAP_RS_CREATEMAP_CL ? MAP_CREATEMAP_CL : mode == MAP_RS_FISH_TO_RECT ? MAP_FISH_TO_RECT : mode == MAP_RS_CREATEMAP_CL_OPENCL ? MAP_CREATEMAP_CL_OPENCL : mode;
+}
 template <int MODE>
 struct ModeTraits {
     static constexpr bool out_fish = MODE == MAP_FISH_TO_FISH || MODE == MAP_RECT_TO_FISH;
@@ -277,11 +282,12 @@ __device__ __forceinline__ float ocl_atan(float x) {
 }
 // One pixel, the code object's stream literally.  vx, vy = ocl_div(x - ocx, ofx), ocl_div(y - ocy, ofy); a = r_i0 * vx.
 // c = centre, f = focal length of the input camera (both may carry cv::remap's exact factor 32).
-__device__ __forceinline__ void map_pixel_ocl_literal(float icx, float icy, float ifx, float ify, const MapParams &P, float a0, float a1, float a2,
+// r = the nine rotation entries (the frame's, or one output row's in the rolling-shutter warp).
+__device__ __forceinline__ void map_pixel_ocl_literal(float icx, float icy, float ifx, float ify, const float (&r)[9], float a0, float a1, float a2,
                                                       float vy, float &ax, float &ay) {
-    const float wz = __builtin_fmaf(P.r[7], vy, a2) + P.r[8];
-    const float wx = __builtin_fmaf(P.r[1], vy, a0) + P.r[2];
-    const float wy = __builtin_fmaf(P.r[4], vy, a1) + P.r[5];
+    const float wz = __builtin_fmaf(r[7], vy, a2) + r[8];
+    const float wx = __builtin_fmaf(r[1], vy, a0) + r[2];
+    const float wy = __builtin_fmaf(r[4], vy, a1) + r[5];
     const float px = ocl_div(wx, wz), py = ocl_div(wy, wz);
     const float rad = ocl_length2(px, py);
     const float k = ocl_div(ocl_atan(rad), rad);
@@ -292,11 +298,11 @@ __device__ __forceinline__ void map_pixel_ocl_literal(float icx, float icy, floa
 // rounding does not depend on its operands' exponents and v_rcp_f32 works on the significand alone, so
 // frexp / ldexp around `a * rcp(b)` change nothing, and the reciprocal of the radius serves both atan's argument
 // reduction and the final division.  `regular` says whether that holds for this pixel (else: the literal stream).
-__device__ __forceinline__ bool map_pixel_ocl_fast(float icx, float icy, float ifx, float ify, const MapParams &P, float a0, float a1, float a2,
+__device__ __forceinline__ bool map_pixel_ocl_fast(float icx, float icy, float ifx, float ify, const float (&r)[9], float a0, float a1, float a2,
                                                    float vy, float &ax, float &ay) {
-    const float wz = __builtin_fmaf(P.r[7], vy, a2) + P.r[8];
-    const float wx = __builtin_fmaf(P.r[1], vy, a0) + P.r[2];
-    const float wy = __builtin_fmaf(P.r[4], vy, a1) + P.r[5];
+    const float wz = __builtin_fmaf(r[7], vy, a2) + r[8];
+    const float wx = __builtin_fmaf(r[1], vy, a0) + r[2];
+    const float wy = __builtin_fmaf(r[4], vy, a1) + r[5];
     const float rz = __builtin_amdgcn_rcpf(wz);
     const float px = wx * rz, py = wy * rz;
     const float q = __builtin_fmaf(py, py, px * px);
@@ -340,8 +346,8 @@ __device__ __forceinline__ void map_pixel_ex(const MapParams32 &p, const MapPara
     if constexpr (MODE == MAP_CREATEMAP_CL) {
         map_pixel32(p, c, r, ax, ay);
     } else if constexpr (MODE == MAP_CREATEMAP_CL_OPENCL) {
-        if (!map_pixel_ocl_fast(p.icx32, p.icy32, p.ifx32, p.ify32, P, c.a0, c.a1, c.a2, vy, ax, ay))
-            map_pixel_ocl_literal(p.icx32, p.icy32, p.ifx32, p.ify32, P, c.a0, c.a1, c.a2, vy, ax, ay);
+        if (!map_pixel_ocl_fast(p.icx32, p.icy32, p.ifx32, p.ify32, P.r, c.a0, c.a1, c.a2, vy, ax, ay))
+            map_pixel_ocl_literal(p.icx32, p.icy32, p.ifx32, p.ify32, P.r, c.a0, c.a1, c.a2, vy, ax, ay);
     } else {
         float wx, wy, wz;
         bool ok = true;

@@ -784,7 +784,8 @@ struct vstab_handle {
         long last_use;
     };
     std::vector<DmaBuf> dmabufs;
-    long dmabuf_clock = 0, dmabuf_imports = 0;
+    long dmabuf_clock = 0, dmabuf_imports = 0, dmabuf_evictions = 0;
+    int dmabuf_cache_cap = 256;  // VSTAB_DMABUF_CACHE=n (tests): a smaller cache, so that eviction is reached with a few objects
     bool chain_lk = true;        // VSTAB_CHAIN_LK=0 disables chained launches
     bool two_lk_streams = false; // VSTAB_LK_STREAMS=2 (development): chained launches alternate between two streams and every slot waits for
                                  // its own predecessor in the kernel -- measured slower than the stream-ordered chain
@@ -882,30 +883,43 @@ static vstab_status resolve_dmabuf(vstab_handle *H, vstab_frame &f) {
     if (f.dmabuf_fd < 0 || f.dmabuf_size == 0 || f.height <= 0 || off_y + f.pitch_y * (size_t)f.height > f.dmabuf_size ||
         off_uv + f.pitch_uv * (size_t)(f.height / 2) > f.dmabuf_size || f.pitch_y < (size_t)f.width * bps || f.pitch_uv < (size_t)f.width * bps)
         return fail(VSTAB_ERR_INVALID, "vstab_frame: DMA-BUF planes do not fit in the object (fd, size, offsets, pitches)");
+    // AVDRMObjectDescriptor.format_modifier: the kernels address rows of `pitch` bytes, so a tiled or compressed surface would be
+    // read as garbage without any error -- refuse everything but a linear layout (or "no modifier": the exporter's implicit, linear one)
+    if (f.dmabuf_modifier != VSTAB_DRM_FORMAT_MOD_LINEAR && f.dmabuf_modifier != VSTAB_DRM_FORMAT_MOD_INVALID) {
+        char mod[32];
+        std::snprintf(mod, sizeof(mod), "0x%016llx", (unsigned long long)f.dmabuf_modifier);
+        return fail(VSTAB_ERR_UNSUPPORTED, std::string("vstab_frame: DMA-BUF with format modifier ") + mod +
+                                               " (tiled / compressed surface): only DRM_FORMAT_MOD_LINEAR is read; map the surface linear first");
+    }
     struct stat sb;
     if (fstat(f.dmabuf_fd, &sb) != 0) return fail(VSTAB_ERR_INVALID, "vstab_frame: dmabuf_fd is not an open file descriptor");
     vstab_handle::DmaBuf *hit = nullptr;
     for (auto &d : H->dmabufs)
         if (d.ino == (unsigned long long)sb.st_ino && d.size == f.dmabuf_size) hit = &d;
     if (!hit) {
-        if (H->dmabufs.size() >= 256) {  // a pool larger than any decoder's: drop the entry used longest ago
+        if (H->dmabufs.size() >= (size_t)H->dmabuf_cache_cap) {  // a pool larger than any decoder's: drop the entry used longest ago
             size_t old = 0;
             for (size_t i = 1; i < H->dmabufs.size(); i++)
                 if (H->dmabufs[i].last_use < H->dmabufs[old].last_use) old = i;
-            (void)hipDestroyExternalMemory(H->dmabufs[old].ext);
-            H->dmabufs.erase(H->dmabufs.begin() + (long)old);
+            // A frame stays in the pipeline for at most `slots` pulls (read-ahead + look-ahead window + warp): an object used
+            // more recently than that may still be read in place, so it is never unmapped -- the cache then grows past its cap.
+            if (H->dmabuf_clock - H->dmabufs[old].last_use > (long)H->slots.size() + 2) {
+                (void)hipStreamSynchronize(H->pstream);  // (rare: a copy out of the object may only just have been enqueued)
+                (void)hipDestroyExternalMemory(H->dmabufs[old].ext);
+                H->dmabufs.erase(H->dmabufs.begin() + (long)old);
+                H->dmabuf_evictions++;
+            }
         }
-        const int fd = dup(f.dmabuf_fd);  // the import takes the descriptor it is given; the caller keeps its own
-        if (fd < 0) return fail(VSTAB_ERR_INVALID, "vstab_frame: cannot duplicate dmabuf_fd");
+        // ROCm's import maps the object (the kernel driver takes its own reference on the DMA-BUF) and neither consumes nor
+        // closes the descriptor -- unlike CUDA's, which takes ownership.  So the caller's fd is handed over as it is: no
+        // duplicate to leak, and the caller may close its fd as soon as the callback returns
+        // (test_dmabuf_import_leaves_no_descriptor_behind checks both on the GPU box).
         hipExternalMemoryHandleDesc hd;
         std::memset(&hd, 0, sizeof(hd));
-        hd.type = hipExternalMemoryHandleTypeOpaqueFd, hd.handle.fd = fd, hd.size = f.dmabuf_size;
+        hd.type = hipExternalMemoryHandleTypeOpaqueFd, hd.handle.fd = f.dmabuf_fd, hd.size = f.dmabuf_size;
         hipExternalMemory_t ext = nullptr;
         hipError_t e = hipImportExternalMemory(&ext, &hd);
-        if (e != hipSuccess) {
-            (void)close(fd);
-            return fail(VSTAB_ERR_DEVICE, std::string("hipImportExternalMemory(DMA-BUF): ") + hipGetErrorString(e));
-        }
+        if (e != hipSuccess) return fail(VSTAB_ERR_DEVICE, std::string("hipImportExternalMemory(DMA-BUF): ") + hipGetErrorString(e));
         hipExternalMemoryBufferDesc bd;
         std::memset(&bd, 0, sizeof(bd));
         bd.offset = 0, bd.size = f.dmabuf_size;
@@ -1047,7 +1061,8 @@ static vstab_status prefetch_next(vstab_handle *H) {
     if (f.delta_rotation) std::memcpy(H->slots[slot].delta.m, f.delta_rotation, sizeof(double) * 9);
     H->slots[slot].have_readout = f.readout_rotation != nullptr;
     if (f.readout_rotation) {
-        if (H->cfg.pixel_depth != 10 && H->map_mode != VSTAB_MAP_CREATEMAP_CL && H->map_mode != VSTAB_MAP_FISH_TO_RECT)
+        if (H->cfg.pixel_depth != 10 && H->map_mode != VSTAB_MAP_CREATEMAP_CL && H->map_mode != VSTAB_MAP_FISH_TO_RECT &&
+            H->map_mode != VSTAB_MAP_CREATEMAP_CL_OPENCL)
             return fail(VSTAB_ERR_INVALID, "vstab_frame.readout_rotation: the 8-bit rolling-shutter warp exists for the preset and fisheye -> rectilinear maps only");
         std::memcpy(H->slots[slot].readout.m, f.readout_rotation, sizeof(double) * 9);
     }
@@ -1277,24 +1292,32 @@ int vstab_struct_size(int which) {
     }
 }
 
+int vstab_abi_version(void) { return VSTAB_ABI_VERSION; }
+
 void vstab_config_default(vstab_config *cfg) {
     if (!cfg) return;
     std::memset(cfg, 0, sizeof(*cfg));
+    cfg->abi_version = VSTAB_ABI_VERSION;
     cfg->preset = VSTAB_GOPRO_H4B_WIDE169_MEASURED;
     cfg->scale = 1, cfg->crop_borders = 0, cfg->zoom = 1, cfg->smooth_radius = 30;  // FrameSourceWarp.hpp:86-89
     cfg->interpolation = 1, cfg->smoother = VSTAB_SMOOTHER_SG, cfg->tracking = 1, cfg->seed = 1, cfg->stream = nullptr;
     cfg->lens_mode = 0, cfg->in_projection = VSTAB_PROJ_FISH, cfg->out_projection = VSTAB_PROJ_RECT;
     cfg->in_dfov = 0, cfg->out_dfov = 0, cfg->out_width = 0, cfg->out_height = 0, cfg->out_cx = -1, cfg->out_cy = -1, cfg->debug = 0;
-    cfg->pixel_depth = 8, cfg->blend = VSTAB_BLEND_EXACT, cfg->map_precision = VSTAB_MAP_PRECISION_IEEE;
+    cfg->pixel_depth = 8, cfg->blend = VSTAB_BLEND_EXACT;
+    // the reference's map is what ITS kernel computes on this GPU (createMap.cl through ROCm's OpenCL compiler): the default
+    cfg->map_precision = VSTAB_MAP_PRECISION_OPENCL;
 }
 
 vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vstab_handle **out) {
     if (!cfg || !src || !out || !src->pull || !src->peek) return fail(VSTAB_ERR_INVALID, "vstab_create: null argument");
+    if (cfg->abi_version != VSTAB_ABI_VERSION)
+        return fail(VSTAB_ERR_INVALID, "vstab_create: vstab_config.abi_version is " + std::to_string(cfg->abi_version) + ", this library is version " +
+                                           std::to_string(VSTAB_ABI_VERSION) + ": initialise the struct with vstab_config_default() of THIS library (include/vstab.h)");
     if (cfg->smooth_radius < 0 || cfg->smooth_radius > 10000) return fail(VSTAB_ERR_INVALID, "vstab_create: bad smooth_radius");
     if (cfg->interpolation != 1 && cfg->interpolation != 0)
         return fail(VSTAB_ERR_INVALID, "vstab_create: interpolation must be INTER_LINEAR (1, the only mode the reference passes) or INTER_NEAREST (0)");
-    if (cfg->interpolation == 0 && (cfg->lens_mode != 0 || cfg->pixel_depth == 10 || cfg->map_precision != VSTAB_MAP_PRECISION_IEEE))
-        return fail(VSTAB_ERR_INVALID, "vstab_create: INTER_NEAREST exists for the reference's own map (lens_mode 0, 8-bit pixels, IEEE map)");
+    if (cfg->interpolation == 0 && (cfg->lens_mode != 0 || cfg->pixel_depth == 10))
+        return fail(VSTAB_ERR_INVALID, "vstab_create: INTER_NEAREST exists for the reference's own map (lens_mode 0, 8-bit pixels)");
     if (!(cfg->scale > 0) || !(cfg->zoom > 0)) return fail(VSTAB_ERR_INVALID, "vstab_create: scale and zoom must be positive");
     if (cfg->smoother < VSTAB_SMOOTHER_SG || cfg->smoother > VSTAB_SMOOTHER_FIXED) return fail(VSTAB_ERR_INVALID, "vstab_create: unknown smoother");
     if (cfg->lens_mode != 0 && cfg->lens_mode != 1) return fail(VSTAB_ERR_INVALID, "vstab_create: lens_mode must be 0 or 1");
@@ -1302,8 +1325,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (cfg->blend != VSTAB_BLEND_EXACT && cfg->blend != VSTAB_BLEND_FP16) return fail(VSTAB_ERR_INVALID, "vstab_create: unknown blend");
     if (cfg->map_precision != VSTAB_MAP_PRECISION_IEEE && cfg->map_precision != VSTAB_MAP_PRECISION_OPENCL)
         return fail(VSTAB_ERR_INVALID, "vstab_create: unknown map_precision");
-    if (cfg->map_precision == VSTAB_MAP_PRECISION_OPENCL && (cfg->lens_mode != 0 || cfg->pixel_depth == 10))
-        return fail(VSTAB_ERR_INVALID, "vstab_create: map_precision OPENCL exists for the reference's own map (lens_mode 0, 8-bit pixels)");
+    // (lens_mode 1 ignores map_precision: those maps are this library's own definitions, IEEE arithmetic throughout)
     std::unique_ptr<vstab_handle> H(new vstab_handle);
     H->cfg = *cfg, H->src = *src;
     H->rng = Pcg32(cfg->seed);
@@ -1312,6 +1334,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (const char *e = getenv("VSTAB_CHAIN_LK")) H->chain_lk = atoi(e) != 0;
     if (const char *e = getenv("VSTAB_LK_STREAMS")) H->two_lk_streams = atoi(e) == 2;
     if (const char *e = getenv("VSTAB_MAP_CACHE")) H->map_cache = atoi(e) != 0;
+    if (const char *e = getenv("VSTAB_DMABUF_CACHE")) H->dmabuf_cache_cap = std::max(1, atoi(e));
     H->stream = static_cast<hipStream_t>(cfg->stream);  // NULL = the default stream, as for the stateless operators
     {
         // the tracking chain is the per-frame critical path; the warp only has to finish before the
@@ -1471,6 +1494,15 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         // the profiling events bracket the launch call and nothing else, so the interval is the kernel
         // (plus its dispatch), not host work between two API calls
         GpuStage gs(H, vstab_handle::ST_WARP);
+#ifdef VSTAB_DEV
+        // development builds: VSTAB_DEV_SKIP_WARP=1 launches no warp at all, so that tools/lk_timeline.py sees the tracker chain with
+        // nothing but the pyramid kernels beside it (how much of an iteration is the chain, how much is contention with the warp)
+        static const bool skip_warp = getenv("VSTAB_DEV_SKIP_WARP") != nullptr;
+        if (skip_warp) {
+            (void)take_launch_events();
+            st = VSTAB_OK;
+        } else
+#endif
         if (out_format == OUT_BGR16)
             st = vstab_warp_p010(S.y16, S.pitch_y16, S.uv16, S.pitch_uv16, H->w, H->h, p,
                                  S.have_readout ? p_bottom + 8 : nullptr, H->map_mode, H->cfg.blend, dst, pitch_dst, H->ow, H->oh, H->stream);
@@ -1487,9 +1519,9 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
             }
         }
         else if (H->cfg.interpolation == 0) {
-            (void)take_launch_events();
+            // (this kernel does not take the profiler's event pair: ~GpuStage then records stream positions around the launch)
             if (out_format != VSTAB_OUT_BGR8 || S.have_readout) st = fail(VSTAB_ERR_INVALID, "INTER_NEAREST emits 8-bit BGR frames without a read-out rotation");
-            else st = vstab_warp_nv12_nearest(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, p, dst, pitch_dst, H->ow, H->oh, H->stream);
+            else st = vstab_warp_nv12_nearest_ex(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, p, H->map_mode, dst, pitch_dst, H->ow, H->oh, H->stream);
         } else if (cached)
             st = vstab_warp_nv12_mapped(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, H->qmap.p, out_format, dst, pitch_dst, dst_uv, pitch_dst_uv,
                                         H->ow, H->oh, H->stream);
@@ -1604,6 +1636,7 @@ vstab_status vstab_enable_profiling(vstab_handle *h, int enable) {
 vstab_status vstab_get_profile(vstab_handle *h, vstab_profile *out) {
     if (!h || !out) return fail(VSTAB_ERR_INVALID, "vstab_get_profile: null argument");
     h->fold_pending();
+    h->prof.dmabuf_imports = h->dmabuf_imports, h->prof.dmabuf_evictions = h->dmabuf_evictions, h->prof.dmabuf_cached = (long)h->dmabufs.size();
     *out = h->prof;
     return VSTAB_OK;
 }

@@ -6,6 +6,8 @@
 #include <climits>
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "vstab_device.hpp"
 #include "vstab_internal.hpp"
 #include "vstab_warp_args.hpp"
@@ -162,7 +164,7 @@ __global__ void __launch_bounds__(256) k_create_map_ex(float *__restrict__ mapx,
         const ColTerm ct = {p.r[0] * vx, p.r[3] * vx, p.r[6] * vx};
         // the map-plane operator runs the OpenCL build's instruction stream literally; the fused kernel and the
         // quantised map use its shortened form with this one as the fall-back (vstab_device.hpp)
-        if constexpr (OCL) map_pixel_ocl_literal(p.icx, p.icy, p.ifx, p.ify, p, ct.a0, ct.a1, ct.a2, vy, mx[i], my[i]);
+        if constexpr (OCL) map_pixel_ocl_literal(p.icx, p.icy, p.ifx, p.ify, p.r, ct.a0, ct.a1, ct.a2, vy, mx[i], my[i]);
         else map_pixel_ex<MODE>(in, p, ct, rt, vx, vy, mx[i], my[i]);
     }
     float *px = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(mapx) + (size_t)y * pitch_x) + x0;
@@ -274,11 +276,17 @@ __global__ void __launch_bounds__(256) k_warp_nv12_bgr(WarpArgs a, int vec_ok) {
 // on; the reference itself only ever passes INTER_LINEAR): createMap.cl's map, cvRound (half to even) + saturate_cast<short>
 // per coordinate, ONE tap converted with the cvtColor arithmetic, 0 outside the source.  Direct gather: this mode is
 // about completeness, the bilinear kernel carries the rate.
+template <bool OCL>  // OCL: the map in the arithmetic of the reference's kernel as built for this GPU (VSTAB_MAP_CREATEMAP_CL_OPENCL)
 __global__ void __launch_bounds__(256) k_warp_nearest(WarpArgs a) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.dw || y >= a.dh) return;
     float mx, my;
-    map_pixel(a.p, col_term(a.p, x), row_term(a.p, y), mx, my);
+    if constexpr (OCL) {
+        const float vx = ocl_div((float)x - a.p.ocx, a.p.ofx), vy = ocl_div((float)y - a.p.ocy, a.p.ofy);
+        map_pixel_ocl_literal(a.p.icx, a.p.icy, a.p.ifx, a.p.ify, a.p.r, a.p.r[0] * vx, a.p.r[3] * vx, a.p.r[6] * vx, vy, mx, my);
+    } else {
+        map_pixel(a.p, col_term(a.p, x), row_term(a.p, y), mx, my);
+    }
     // cvRound -> int (NaN / out of range: INT_MIN on x86), then saturate_cast<short>
     const bool far = !(fabsf(mx) < 2147483520.0f) || !(fabsf(my) < 2147483520.0f);
     const int sx = far ? -32768 : min(max((int)__builtin_rintf(mx), -32768), 32767), sy = far ? -32768 : min(max((int)__builtin_rintf(my), -32768), 32767);
@@ -506,8 +514,8 @@ static vstab_status warp_impl(const void *y, size_t pitch_y, const void *uv, siz
     a.p = to_params(params);
     const int vec_ok = aligned(dst, 4) && pitch_dst % 4 == 0 && (!nv12_out || (aligned(dst_uv, 4) && pitch_dst_uv % 4 == 0));
     const bool small_pitch = pitch_y < (1u << 24) && pitch_uv < (1u << 24) && (uint64_t)pitch_y * sh < (1ull << 32);
-    if (rot_bottom && map_mode != VSTAB_MAP_CREATEMAP_CL && map_mode != VSTAB_MAP_FISH_TO_RECT)
-        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_rs: the per-row warp exists for the fisheye -> pinhole modes (0, 1) only");
+    if (rot_bottom && map_mode != VSTAB_MAP_CREATEMAP_CL && map_mode != VSTAB_MAP_FISH_TO_RECT && map_mode != VSTAB_MAP_CREATEMAP_CL_OPENCL)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_rs: the per-row warp exists for the fisheye -> pinhole modes (0, 1, 5) only");
     const bool plain = map_mode == VSTAB_MAP_CREATEMAP_CL && !nv12_out && !qmap && !rot_bottom;
     if (!plain && !small_pitch) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: source pitch too large for this mode");
     bool direct = !small_pitch;
@@ -590,21 +598,37 @@ vstab_status vstab_warp_nv12_mapped(const void *y, size_t pitch_y, const void *u
                      qmap, (dw + 3) & ~3);
 }
 
-vstab_status vstab_warp_nv12_nearest(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh, const float params[17],
-                                     void *dst, size_t pitch_dst, int dw, int dh, void *stream) {
+vstab_status vstab_warp_nv12_nearest_ex(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh, const float params[17],
+                                        int map_mode, void *dst, size_t pitch_dst, int dw, int dh, void *stream) {
     if (!y || !uv || !dst || !params) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_nearest: null pointer");
     if (sw <= 0 || sh <= 0 || (sw & 1) || (sh & 1) || sw > 32767 || sh > 32767 || dw <= 0 || dh <= 0 || dw > 32767 || dh > 32767)
         return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_nearest: sizes must be in [1, 32767], source even");
     if (pitch_y < (size_t)sw || pitch_uv < (size_t)sw || pitch_dst < (size_t)dw * 3 || !aligned(uv, 2) || pitch_uv % 2)
         return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_nearest: bad pitch or chroma alignment");
+    if (map_mode != VSTAB_MAP_CREATEMAP_CL && map_mode != VSTAB_MAP_CREATEMAP_CL_OPENCL)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_nearest: the nearest-neighbour warp exists for the reference's own map (modes 0 and 5)");
     WarpArgs a;
     a.y = (const uint8_t *)y, a.uv = (const uint8_t *)uv, a.dst = (uint8_t *)dst, a.dst_uv = nullptr;
     a.pitch_y = pitch_y, a.pitch_uv = pitch_uv, a.pitch_dst = pitch_dst, a.pitch_dst_uv = 0;
     a.sw = sw, a.sh = sh, a.dw = dw, a.dh = dh;
     a.p = to_params(params);
-    hipLaunchKernelGGL(k_warp_nearest, dim3(div_up(dw, 64), div_up(dh, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    const dim3 grid(div_up(dw, 64), div_up(dh, 4));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const LaunchEvents ev = take_launch_events();  // a profiling caller's pair: the kernel's own start / end stamps
+    if (map_mode == VSTAB_MAP_CREATEMAP_CL_OPENCL) {
+        if (ev.start) hipExtLaunchKernelGGL(k_warp_nearest<true>, grid, dim3(256), 0, st, ev.start, ev.stop, 0, a);
+        else hipLaunchKernelGGL(k_warp_nearest<true>, grid, dim3(256), 0, st, a);
+    } else {
+        if (ev.start) hipExtLaunchKernelGGL(k_warp_nearest<false>, grid, dim3(256), 0, st, ev.start, ev.stop, 0, a);
+        else hipLaunchKernelGGL(k_warp_nearest<false>, grid, dim3(256), 0, st, a);
+    }
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
+}
+
+vstab_status vstab_warp_nv12_nearest(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh, const float params[17],
+                                     void *dst, size_t pitch_dst, int dw, int dh, void *stream) {
+    return vstab_warp_nv12_nearest_ex(y, pitch_y, uv, pitch_uv, sw, sh, params, VSTAB_MAP_CREATEMAP_CL, dst, pitch_dst, dw, dh, stream);
 }
 
 vstab_status vstab_warp_nv12_bgr(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh,

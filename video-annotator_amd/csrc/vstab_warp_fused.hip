@@ -102,8 +102,8 @@ struct StageTrips {
 // {bx0, by0, wb, hb, use_lds} to hdr.  Run by one wave.
 template <int TH, int STAGE_MAX, int MODE, bool CACHED>
 __device__ __forceinline__ void probe_tile(const FusedArgs &ta, int x0, int y0, int lane, float rfx, float rfy, uint32_t *hdr) {
-    constexpr bool RS = MODE >= MAP_RS_CREATEMAP_CL;              // per-row rotation
-    constexpr int BASE = RS ? MODE - MAP_RS_CREATEMAP_CL : MODE;  // the projection pair
+    constexpr bool RS = map_mode_is_rs(MODE);    // per-row rotation
+    constexpr int BASE = map_mode_base(MODE);    // the projection pair and its arithmetic
     const WarpArgs &a = ta.w;
     int px, py;  // tile-local perimeter point of this lane: 16 along the top, 16 along the bottom, 16 per side
     const int l16 = lane & 15, side = (l16 * (TH - 1) + 7) / 15;
@@ -318,8 +318,8 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
     constexpr int TH = 4 * RW;
     constexpr int STAGE_MAX = StageTrips<RWB, RW>::value;
     constexpr int QB = CACHED ? 0 : QMAGIC_BITS;  // offset of the quantised-coordinate representation kept in registers
-    constexpr bool RS = MODE >= MAP_RS_CREATEMAP_CL;              // per-row rotation (BASELINE config 5)
-    constexpr int BASE = RS ? MODE - MAP_RS_CREATEMAP_CL : MODE;  // the projection pair
+    constexpr bool RS = map_mode_is_rs(MODE);    // per-row rotation (BASELINE config 5)
+    constexpr int BASE = map_mode_base(MODE);    // the projection pair and its arithmetic
     uint32_t *const tile = smem + 8;  // smem[0..4]: the tile header (box, flag), written by wave 0
     const WarpArgs &a = ta.w;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -471,10 +471,17 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
                 f32x2 wx[NP], wy[NP], wz[NP], ax[NP], ay[NP];
 #pragma unroll
                 for (int c = 0; c < NP; c++) {
-                    const f32x2 vy2 = bcast2(vy_l, 2 * (g0 + c));
-                    wz[c] = fma2(splat2(a.p.r[7]), vy2, splat2(ct.a2)) + splat2(a.p.r[8]);
-                    wx[c] = fma2(splat2(a.p.r[1]), vy2, splat2(ct.a0)) + splat2(a.p.r[2]);
-                    wy[c] = fma2(splat2(a.p.r[4]), vy2, splat2(ct.a1)) + splat2(a.p.r[5]);
+                    const int j = 2 * (g0 + c);
+                    const f32x2 vy2 = bcast2(vy_l, j);
+                    if constexpr (RS) {  // every row has its own matrix (the definition's fp32 interpolation), fed to createMap.cl's stream
+                        wz[c] = fma2(bcast2(m_l[7], j), vy2, bcast2(m_l[6], j) * splat2(vx)) + bcast2(m_l[8], j);
+                        wx[c] = fma2(bcast2(m_l[1], j), vy2, bcast2(m_l[0], j) * splat2(vx)) + bcast2(m_l[2], j);
+                        wy[c] = fma2(bcast2(m_l[4], j), vy2, bcast2(m_l[3], j) * splat2(vx)) + bcast2(m_l[5], j);
+                    } else {
+                        wz[c] = fma2(splat2(a.p.r[7]), vy2, splat2(ct.a2)) + splat2(a.p.r[8]);
+                        wx[c] = fma2(splat2(a.p.r[1]), vy2, splat2(ct.a0)) + splat2(a.p.r[2]);
+                        wy[c] = fma2(splat2(a.p.r[4]), vy2, splat2(ct.a1)) + splat2(a.p.r[5]);
+                    }
                 }
                 irregular |= map_pairs_ocl<NP>(icx32, icy32, ifx32, ify32, wx, wy, wz, ax, ay);
 #pragma unroll
@@ -489,7 +496,14 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
 #pragma unroll 1
                 for (int j = 0; j < RW; j++) {
                     float fx, fy;
-                    map_pixel_ocl_literal(icx32, icy32, ifx32, ify32, a.p, ct.a0, ct.a1, ct.a2, bcast(vy_l, j), fx, fy);
+                    if constexpr (RS) {
+                        float mr[9];
+#pragma unroll
+                        for (int k = 0; k < 9; k++) mr[k] = bcast(m_l[k], j);
+                        map_pixel_ocl_literal(icx32, icy32, ifx32, ify32, mr, mr[0] * vx, mr[3] * vx, mr[6] * vx, bcast(vy_l, j), fx, fy);
+                    } else {
+                        map_pixel_ocl_literal(icx32, icy32, ifx32, ify32, a.p.r, ct.a0, ct.a1, ct.a2, bcast(vy_l, j), fx, fy);
+                    }
                     const int ix = __float_as_int(fx + QMAGIC), iy = __float_as_int(fy + QMAGIC);
 #pragma unroll
                     for (int k = 0; k < RW; k++) qxb[k] = j == k ? ix : qxb[k], qyb[k] = j == k ? iy : qyb[k];
@@ -841,7 +855,7 @@ static unsigned tile_schedule(FusedArgs &ta, int rwb, int lds_kb, double tail_ro
     return 8u * (unsigned)share;
 }
 
-// The 10-bit pixel path on the same kernel (DEPTH 10): fisheye -> pinhole maps (modes 0 / 1, optionally a rotation per
+// The 10-bit pixel path on the same kernel (DEPTH 10): fisheye -> pinhole maps (modes 0 / 1 / 5, optionally a rotation per
 // output row), both blends; called by vstab_warp_p010 when the planes allow 16-byte staging loads.
 vstab_status launch_warp_fused10(const WarpArgs &a, const float params[17], int map_mode, int blend, const float *rot_bottom, bool p010_out, bool dst_vec_ok,
                                  hipStream_t st) {
@@ -875,9 +889,11 @@ vstab_status launch_warp_fused10(const WarpArgs &a, const float params[17], int 
     } while (0)
     if (rot_bottom) {
         if (map_mode == VSTAB_MAP_CREATEMAP_CL) VSTAB_LAUNCH10_M(MAP_RS_CREATEMAP_CL);
+        else if (map_mode == VSTAB_MAP_CREATEMAP_CL_OPENCL) VSTAB_LAUNCH10_M(MAP_RS_CREATEMAP_CL_OPENCL);
         else VSTAB_LAUNCH10_M(MAP_RS_FISH_TO_RECT);
     } else {
         if (map_mode == VSTAB_MAP_CREATEMAP_CL) VSTAB_LAUNCH10_M(MAP_CREATEMAP_CL);
+        else if (map_mode == VSTAB_MAP_CREATEMAP_CL_OPENCL) VSTAB_LAUNCH10_M(MAP_CREATEMAP_CL_OPENCL);
         else VSTAB_LAUNCH10_M(MAP_FISH_TO_RECT);
     }
 #undef VSTAB_LAUNCH10_M
@@ -895,7 +911,8 @@ vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int ma
     ta.qmap = static_cast<const int2 *>(qmap), ta.qpitch = qpitch;
     for (int k = 0; k < 9; k++) ta.rs_d[k] = rot_bottom ? rot_bottom[k] - params[8 + k] : 0.0f;  // fp32, as the definition forms it
     ta.rs_den = (float)(a.dh > 1 ? a.dh - 1 : 1);
-    if (rot_bottom) map_mode += MAP_RS_CREATEMAP_CL;  // modes 0 / 1 only (checked by the caller)
+    if (rot_bottom)  // modes 0 / 1 / 5 only (checked by the caller)
+        map_mode = map_mode == VSTAB_MAP_CREATEMAP_CL_OPENCL ? (int)MAP_RS_CREATEMAP_CL_OPENCL : map_mode + (int)MAP_RS_CREATEMAP_CL;
 #ifdef VSTAB_DEV
     ta.timing = g_dev_timing;
     static const int ablate = getenv("VSTAB_ABLATE") ? atoi(getenv("VSTAB_ABLATE")) : 0;
@@ -942,6 +959,7 @@ vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int ma
             case VSTAB_MAP_RECT_TO_FISH: VSTAB_LAUNCH_RF(MAP_RECT_TO_FISH, false); break;
             case VSTAB_MAP_CREATEMAP_CL_OPENCL: VSTAB_LAUNCH_RF(MAP_CREATEMAP_CL_OPENCL, false); break;
             case MAP_RS_CREATEMAP_CL: VSTAB_LAUNCH_RF(MAP_RS_CREATEMAP_CL, false); break;
+            case MAP_RS_CREATEMAP_CL_OPENCL: VSTAB_LAUNCH_RF(MAP_RS_CREATEMAP_CL_OPENCL, false); break;
             default: VSTAB_LAUNCH_RF(MAP_RS_FISH_TO_RECT, false); break;
         }
     }

@@ -72,8 +72,10 @@ __global__ void __launch_bounds__(256) k_warp_p010(P010Args a) {
 #pragma unroll
         for (int k = 0; k < 9; k++) m[r][k] = a.rs ? __builtin_fmaf(t, a.rs_d[k], a.p.r[k]) : a.p.r[k];
     }
-    const float vx = ((float)x - a.p.ocx) / a.p.ofx;
-    const float vy[2] = {((float)y0 - a.p.ocy) / a.p.ofy, ((float)(y0 + 1) - a.p.ocy) / a.p.ofy};
+    constexpr bool OCL = MODE == MAP_CREATEMAP_CL_OPENCL;  // createMap.cl as ROCm's OpenCL compiler builds it: reciprocal-based divisions
+    const float vx = OCL ? ocl_div((float)x - a.p.ocx, a.p.ofx) : ((float)x - a.p.ocx) / a.p.ofx;
+    const float vy[2] = {OCL ? ocl_div((float)y0 - a.p.ocy, a.p.ofy) : ((float)y0 - a.p.ocy) / a.p.ofy,
+                         OCL ? ocl_div((float)(y0 + 1) - a.p.ocy, a.p.ofy) : ((float)(y0 + 1) - a.p.ocy) / a.p.ofy};
     float ax[2], ay[2];
     if constexpr (MODE == MAP_CREATEMAP_CL || MODE == MAP_FISH_TO_RECT) {
         f32x2 px, py;
@@ -145,7 +147,8 @@ extern "C" vstab_status vstab_warp_p010_planes(const void *y, size_t pitch_y, co
         reinterpret_cast<uintptr_t>(dst_y) % 2 || reinterpret_cast<uintptr_t>(dst_uv) % 4)
         return fail(VSTAB_ERR_INVALID, "vstab_warp_p010_planes: bad output pitch or alignment (16-bit samples; chroma pairs 4-byte aligned)");
     if (blend != VSTAB_BLEND_EXACT && blend != VSTAB_BLEND_FP16) return fail(VSTAB_ERR_INVALID, "vstab_warp_p010_planes: unknown blend");
-    const bool tiled_ok = (map_mode == VSTAB_MAP_CREATEMAP_CL || map_mode == VSTAB_MAP_FISH_TO_RECT) && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+    const bool tiled_ok = (map_mode == VSTAB_MAP_CREATEMAP_CL || map_mode == VSTAB_MAP_FISH_TO_RECT || map_mode == VSTAB_MAP_CREATEMAP_CL_OPENCL) &&
+                          reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
                           reinterpret_cast<uintptr_t>(uv) % 16 == 0 && pitch_y % 16 == 0 && pitch_uv % 16 == 0 && pitch_y >= (size_t)sw * 2 &&
                           pitch_uv >= (size_t)sw * 2 && pitch_y < (1u << 24) && pitch_uv < (1u << 24) && (uint64_t)pitch_y * sh < (1ull << 32) &&
                           (uint64_t)pitch_dst_y * dh < (1ull << 32);
@@ -181,11 +184,12 @@ extern "C" vstab_status vstab_warp_p010(const void *y, size_t pitch_y, const voi
     if (pitch_y < (size_t)sw * 2 || pitch_uv < (size_t)sw * 2 || pitch_dst < (size_t)dw * 6 || pitch_y % 2 || pitch_uv % 4 || pitch_dst % 2 ||
         reinterpret_cast<uintptr_t>(y) % 2 || reinterpret_cast<uintptr_t>(uv) % 4 || reinterpret_cast<uintptr_t>(dst) % 2)
         return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: bad pitch or alignment (16-bit samples; chroma pairs 4-byte aligned)");
-    if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_RECT_TO_FISH) return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: unknown map mode");
+    if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_CREATEMAP_CL_OPENCL) return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: unknown map mode");
     if (blend != VSTAB_BLEND_EXACT && blend != VSTAB_BLEND_FP16) return fail(VSTAB_ERR_INVALID, "vstab_warp_p010: unknown blend");
     // The LDS-tiled kernel (the 8-bit hot kernel's structure with a 10:10:10 LDS pixel) serves the fisheye -> pinhole maps when
     // the planes allow its 16-byte staging loads; everything else takes the direct-gather kernel below.  Same results.
-    const bool tiled_ok = (map_mode == VSTAB_MAP_CREATEMAP_CL || map_mode == VSTAB_MAP_FISH_TO_RECT) && sw >= 8 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+    const bool tiled_ok = (map_mode == VSTAB_MAP_CREATEMAP_CL || map_mode == VSTAB_MAP_FISH_TO_RECT || map_mode == VSTAB_MAP_CREATEMAP_CL_OPENCL) && sw >= 8 &&
+                          reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
                           reinterpret_cast<uintptr_t>(uv) % 16 == 0 && pitch_y % 16 == 0 && pitch_uv % 16 == 0 && pitch_y < (1u << 24) &&
                           pitch_uv < (1u << 24) && (uint64_t)pitch_y * sh < (1ull << 32);
     static const bool force_direct = getenv("VSTAB_P010_DIRECT") != nullptr;  // development: the direct-gather kernel for every call
@@ -223,6 +227,7 @@ extern "C" vstab_status vstab_warp_p010(const void *y, size_t pitch_y, const voi
         case VSTAB_MAP_FISH_TO_RECT: VSTAB_LAUNCH(MAP_FISH_TO_RECT); break;
         case VSTAB_MAP_FISH_TO_FISH: VSTAB_LAUNCH(MAP_FISH_TO_FISH); break;
         case VSTAB_MAP_RECT_TO_RECT: VSTAB_LAUNCH(MAP_RECT_TO_RECT); break;
+        case VSTAB_MAP_CREATEMAP_CL_OPENCL: VSTAB_LAUNCH(MAP_CREATEMAP_CL_OPENCL); break;
         default: VSTAB_LAUNCH(MAP_RECT_TO_FISH); break;
     }
 #undef VSTAB_LAUNCH
