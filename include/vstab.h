@@ -224,6 +224,11 @@ VSTAB_API vstab_status vstab_cvt_bgr16_p010(const void *src_bgr16, size_t pitch_
 VSTAB_API vstab_status vstab_pyr_down(const void *src, size_t pitch_src, int width, int height,
                                       void *dst, size_t pitch_dst, void *stream);
 
+/* Two pyramid levels in one launch, as the pipeline builds levels 2 and 3 of the LK pyramid: mid = pyrDown(src) ((w+1)/2 x (h+1)/2),
+ * dst = pyrDown(mid) -- the bytes of two vstab_pyr_down calls (the small levels are launch- and latency-bound as kernels of their own). */
+VSTAB_API vstab_status vstab_pyr_down_x2(const void *src, size_t pitch_src, int width, int height, void *mid, size_t pitch_mid,
+                                         void *dst, size_t pitch_dst, void *stream);
+
 /* cornerMinEigenVal(blockSize 3, ksize 3): dense width x height float response (device). */
 VSTAB_API vstab_status vstab_min_eig(const void *gray, size_t pitch, int width, int height,
                                      void *eig_f32, void *stream);

@@ -43,6 +43,29 @@ def test_pyr_down_size_sweep_and_unaligned_views(vs, cuda):
             assert np.array_equal(vs.pyr_down(d[3:64, x0:x0 + w]).cpu().numpy(), oracle.pyr_down(np.ascontiguousarray(v))), (x0, w)
 
 
+def test_pyr_down_two_levels_in_one_launch(vs, cuda):
+    """vstab_pyr_down_x2 (levels 2 and 3 of the LK pyramid in one launch): both levels equal two pyrDown calls of the oracle --
+    the pipeline's level sizes (1920x1080 and 960x540 are what a 4K / 1080p frame hands it), every residue of the 28 x 24 /
+    14 x 12 tile sizes, odd sizes, images smaller than a tile, the smallest ones (which fall back to two launches), views whose
+    base or pitch is not 4-byte aligned."""
+    rng = np.random.default_rng(12)
+    sizes = [(1920, 1080), (960, 540), (640, 360), (333, 181), (57, 49), (56, 48), (55, 47), (29, 25), (28, 24), (27, 23), (16, 16), (15, 15), (9, 7), (5, 3)]
+    sizes += [(w, 33) for w in range(100, 130)] + [(61, h) for h in range(40, 66)]
+    for w, h in sizes:
+        img = synth.luma(w + h, w, h) if w >= 320 else rng.integers(0, 256, (h, w), dtype=np.uint8)
+        mid, dst = vs.pyr_down_x2(dev(img, cuda))
+        e1 = oracle.pyr_down(img)
+        assert np.array_equal(mid.cpu().numpy(), e1), (w, h, "first level")
+        assert np.array_equal(dst.cpu().numpy(), oracle.pyr_down(e1)), (w, h, "second level")
+    big = rng.integers(0, 256, (90, 203), dtype=np.uint8)
+    d = dev(big, cuda)
+    for x0 in (0, 1, 2, 3):
+        for w in (64, 65, 131):
+            v = np.ascontiguousarray(big[3:84, x0:x0 + w])
+            mid, dst = vs.pyr_down_x2(d[3:84, x0:x0 + w])
+            assert np.array_equal(mid.cpu().numpy(), oracle.pyr_down(v)) and np.array_equal(dst.cpu().numpy(), oracle.pyr_down(oracle.pyr_down(v))), (x0, w)
+
+
 def test_min_eig_bit_exact(vs, cuda):
     for seed, w, h in [(1, 320, 180), (2, 333, 181), (6, 64, 48)]:
         img = synth.luma(seed, w, h)

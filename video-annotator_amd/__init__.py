@@ -109,6 +109,7 @@ SIGNATURES = {
     "vstab_warp_nv12_mapped": (_i, [_vp, _sz, _vp, _sz, _i, _i, _vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
     "vstab_draw_markers": (_i, [_vp, _sz, _i, _i, _i, _vp, _i, _i, _c.c_uint, _vp]),
     "vstab_pyr_down": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp]),
+    "vstab_pyr_down_x2": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp, _sz, _vp]),
     "vstab_min_eig": (_i, [_vp, _sz, _i, _i, _vp, _vp]),
     "vstab_good_features": (_i, [_vp, _sz, _i, _i, _i, _d, _d, _fp, _ip, _vp]),
     "vstab_pull_frame_bgr16": (_i, [_vp, _vp, _sz]),
@@ -469,6 +470,17 @@ def pyr_down(img):
     out = torch.empty(((h + 1) // 2, (w + 1) // 2), dtype=torch.uint8, device=img.device)
     _check(_L.vstab_pyr_down(img.data_ptr(), img.stride(0), w, h, out.data_ptr(), out.stride(0), _stream()), "vstab_pyr_down")
     return out
+
+
+def pyr_down_x2(img):
+    """vstab_pyr_down_x2: two pyramid levels in one launch -> (mid, dst)."""
+    import torch
+    h, w = img.shape
+    mw, mh = (w + 1) // 2, (h + 1) // 2
+    mid = torch.empty((mh, mw), dtype=torch.uint8, device=img.device)
+    dst = torch.empty(((mh + 1) // 2, (mw + 1) // 2), dtype=torch.uint8, device=img.device)
+    _check(_L.vstab_pyr_down_x2(img.data_ptr(), img.stride(0), w, h, mid.data_ptr(), mid.stride(0), dst.data_ptr(), dst.stride(0), _stream()), "vstab_pyr_down_x2")
+    return mid, dst
 
 
 def min_eig(gray):

@@ -81,7 +81,10 @@ constexpr int PREFETCH_DEPTH = 8;
 
 class Tracker {
   public:
-    static constexpr int REC_BUFS = 3;  // record / point buffers in rotation: in flight, chained behind it, being read by the host
+    // One record buffer per tracked frame pair, in rotation: a launch covers up to LK_SEG_MAX pairs and launches run up to
+    // PREFETCH_DEPTH frames ahead of the frame the host reads, so a buffer comes round again long after its reader is done
+    // (and after any launch whose results were dropped has finished: it precedes its replacement on the tracker stream).
+    static constexpr int REC_BUFS = 32, PTS_BUFS = 8;
     vstab_status init(int w, int h) {
         w_ = w, h_ = h, levels_ = lk_levels(w, h);
         int lw = w, lh = h;
@@ -98,9 +101,9 @@ class Tracker {
         for (int b = 0; b < REC_BUFS; b++) {
             VSTAB_TRY(hrec_[b].ensure(256 * 16));
             VSTAB_TRY(drec_[b].ensure(256 * 16));
-            VSTAB_HIP_TRY(hipMemset(drec_[b].p, 0, 256 * 16));  // tag 0 is never a launch's sequence number: a chained slot never mistakes stale bytes for its predecessor
-            VSTAB_TRY(hpts_[b].ensure(256 * sizeof(float2)));
+            VSTAB_HIP_TRY(hipMemset(drec_[b].p, 0, 256 * 16));  // tag 0 is never a sequence number: a chained slot never mistakes stale bytes for its predecessor
         }
+        for (int b = 0; b < PTS_BUFS; b++) VSTAB_TRY(hpts_[b].ensure(256 * sizeof(float2)));
         return VSTAB_OK;
     }
 
@@ -109,6 +112,11 @@ class Tracker {
         const uint8_t *src = gray;
         size_t sp = pitch;
         for (int l = 1; l < levels_; l++) {
+            // levels 2 and 3 in ONE launch (k_pyr_down_x2): as kernels of their own the small levels are launch- and latency-bound
+            if (l == 2 && levels_ == 4 && pyr_down_x2_ok(lvl_w_[1], lvl_h_[1]) && !single_level_pyramid_) {
+                VSTAB_TRY(launch_pyr_down_x2(src, sp, lvl_w_[1], lvl_h_[1], pyr_[s][2].as<uint8_t>(), (size_t)lvl_w_[2], pyr_[s][3].as<uint8_t>(), (size_t)lvl_w_[3], st));
+                break;
+            }
             VSTAB_TRY(launch_pyr_down(src, sp, lvl_w_[l - 1], lvl_h_[l - 1], pyr_[s][l].as<uint8_t>(), (size_t)lvl_w_[l], st));
             src = pyr_[s][l].as<uint8_t>(), sp = (size_t)lvl_w_[l];
         }
@@ -336,63 +344,54 @@ class Tracker {
     // writes one self-validating record per feature over the link directly (a few KB), and the host polls
     // the records' sequence tags instead of paying a copy launch + stream-sync round trip.
     //
-    // Chained launches: the tracker of frame k+1 starts from the points the tracker of frame k ended on
-    // (FrameSourceWarp.cpp:427), so its launch can be enqueued right behind frame k's without waiting for
-    // the host: slot f reads its start point from the device copy of frame k's record f and lost slots stay
-    // lost.  Three record buffers rotate (in flight, chained behind it, being read by the host).
+    // A launch is a SEGMENT of consecutive frame pairs (k_lk_track): pair i tracks from pyramid i into pyramid i + 1, every
+    // slot starts pair i + 1 from the point it reached in pair i (FrameSourceWarp.cpp:427) and lost slots stay lost.
+    // Chained launches: a segment that continues where another ended reads its start points from the device copy of the
+    // parent's last records, so it can be enqueued without waiting for the host.
     struct Launch {
-        int buf = -1, n_slots = 0;
-        uint32_t seq = 0;
+        int n_slots = 0, n_frames = 0;
+        int buf[LK_SEG_MAX] = {0};        // record buffer of every frame pair
+        uint32_t seq[LK_SEG_MAX] = {0};   // and its sequence tag
         bool chained = false, timed = false;
     };
 
-    vstab_status track_launch(const LkPyramid &I, const LkPyramid &J, const std::vector<float> &prev_xy, hipStream_t st,
-                              bool timed, Launch &L) {
+    // pyr: n_frames + 1 pyramids (the frame before the segment's first, then the segment's frames)
+    vstab_status track_launch(const LkPyramid *pyr, int n_frames, const std::vector<float> &prev_xy, hipStream_t st, bool timed, Launch &L) {
         L = Launch();
         L.n_slots = (int)(prev_xy.size() / 2), L.timed = timed;
-        const int n = L.n_slots;
-        if (n == 0) return VSTAB_OK;
-        L.buf = (int)(launches_++ % REC_BUFS), L.seq = ++seq_;
-        VSTAB_TRY(hrec_[L.buf].ensure((size_t)n * 16));
-        VSTAB_TRY(drec_[L.buf].ensure((size_t)n * 16));
-        VSTAB_TRY(hpts_[L.buf].ensure((size_t)n * sizeof(float2)));  // one per record buffer: a launch still queued keeps its points
-        if (!hrec_[L.buf].dev() || !hpts_[L.buf].dev()) return fail(VSTAB_ERR_DEVICE, "hipHostGetDevicePointer failed");
-        std::memcpy(hpts_[L.buf].p, prev_xy.data(), sizeof(float) * prev_xy.size());
-        if (timed && !ev_a_) (void)hipEventCreate(&ev_a_), (void)hipEventCreate(&ev_b_);
-        if (timed) (void)hipEventRecord(ev_a_, st);
-        VSTAB_TRY(launch_lk(I, J, static_cast<const float2 *>(hpts_[L.buf].dev()), n, nullptr, nullptr, hrec_[L.buf].dev(), L.seq, st, nullptr, 0,
-                            drec_[L.buf].p, clock_slot()));
-        if (timed) (void)hipEventRecord(ev_b_, st);
-        return VSTAB_OK;
+        if (L.n_slots == 0) return VSTAB_OK;
+        PinnedBuf &pts = hpts_[pts_launches_++ % PTS_BUFS];  // one per launch: a launch still queued keeps its points
+        VSTAB_TRY(pts.ensure((size_t)L.n_slots * sizeof(float2)));
+        if (!pts.dev()) return fail(VSTAB_ERR_DEVICE, "hipHostGetDevicePointer failed");
+        std::memcpy(pts.p, prev_xy.data(), sizeof(float) * prev_xy.size());
+        return launch_segment(pyr, n_frames, static_cast<const float2 *>(pts.dev()), nullptr, 0, st, L);
     }
 
-    // the launch for the NEXT frame pair, chained behind `parent` (same slots; see above)
-    vstab_status track_launch_chained(const LkPyramid &I, const LkPyramid &J, const Launch &parent, hipStream_t st, Launch &L) {
+    // the launch for the frames FOLLOWING `parent`'s last one, chained behind it on the same stream (same slots; see above)
+    vstab_status track_launch_chained(const LkPyramid *pyr, int n_frames, const Launch &parent, hipStream_t st, Launch &L) {
         L = Launch();
-        if (parent.n_slots == 0 || parent.buf < 0) return VSTAB_OK;
+        if (parent.n_slots == 0 || parent.n_frames == 0) return VSTAB_OK;
         L.n_slots = parent.n_slots, L.chained = true;
-        L.buf = (int)(launches_++ % REC_BUFS), L.seq = ++seq_;
-        VSTAB_TRY(hrec_[L.buf].ensure((size_t)L.n_slots * 16));
-        VSTAB_TRY(drec_[L.buf].ensure((size_t)L.n_slots * 16));
-        if (!hrec_[L.buf].dev()) return fail(VSTAB_ERR_DEVICE, "hipHostGetDevicePointer failed");
-        return launch_lk(I, J, nullptr, L.n_slots, nullptr, nullptr, hrec_[L.buf].dev(), L.seq, st, drec_[parent.buf].p, parent.seq, drec_[L.buf].p,
-                         clock_slot());
+        const int last = parent.n_frames - 1;
+        return launch_segment(pyr, n_frames, nullptr, drec_[parent.buf[last]].p, parent.seq[last], st, L);
     }
 
-    // results of launch L in the order of the (compacted) point list it tracked: expect_n entries
-    vstab_status track_wait(const Launch &L, size_t expect_n, std::vector<float> &next_xy, std::vector<uint8_t> &status, hipStream_t st,
+    // results of frame pair `idx` of launch L in the order of the (compacted) point list it tracked: expect_n entries
+    vstab_status track_wait(const Launch &L, int idx, size_t expect_n, std::vector<float> &next_xy, std::vector<uint8_t> &status, hipStream_t st,
                             double *gpu_ms) {
         next_xy.clear(), status.clear();
         next_xy.reserve(2 * expect_n), status.reserve(expect_n);
         const int n = L.n_slots;
         if (n == 0) return expect_n == 0 ? VSTAB_OK : fail(VSTAB_ERR_DEVICE, "tracker bookkeeping mismatch");
-        const volatile uint32_t *rec = hrec_[L.buf].as<uint32_t>();
+        if (idx < 0 || idx >= L.n_frames) return fail(VSTAB_ERR_DEVICE, "tracker bookkeeping mismatch (frame pair outside its launch)");
+        const uint32_t seq = L.seq[idx];
+        const volatile uint32_t *rec = hrec_[L.buf[idx]].as<uint32_t>();
         const auto t0 = std::chrono::steady_clock::now();
         unsigned long spins = 0;
         // a record = two 8-byte granules {x, seq} {y, seq << 2 | status}, each valid once its own tag matches (make_record)
-        const uint32_t tag1 = L.seq << 2;
+        const uint32_t tag1 = seq << 2;
         auto ready = [&](int i) {
-            return __atomic_load_n(&rec[4 * i + 1], __ATOMIC_ACQUIRE) == L.seq && (__atomic_load_n(&rec[4 * i + 3], __ATOMIC_ACQUIRE) & ~3u) == tag1;
+            return __atomic_load_n(&rec[4 * i + 1], __ATOMIC_ACQUIRE) == seq && (__atomic_load_n(&rec[4 * i + 3], __ATOMIC_ACQUIRE) & ~3u) == tag1;
         };
         for (int i = 0; i < n; i++) {
             while (!ready(i)) {
@@ -403,7 +402,7 @@ class Tracker {
                 }
             }
             const uint32_t x = rec[4 * i], y = rec[4 * i + 2], s = rec[4 * i + 3] & 3u;
-            if (s == 3u) return fail(VSTAB_ERR_DEVICE, "LK chain: a slot's predecessor record never arrived");
+            if (s == 3u) return fail(VSTAB_ERR_DEVICE, "LK chain: a slot's predecessor record does not carry its parent's tag");
             if (s == 2u) continue;  // lost in an earlier frame of the chain: not part of this frame's point list
             float fx, fy;
             std::memcpy(&fx, &x, 4), std::memcpy(&fy, &y, 4);
@@ -420,8 +419,9 @@ class Tracker {
     vstab_status track(const LkPyramid &I, const LkPyramid &J, const std::vector<float> &prev_xy, std::vector<float> &next_xy,
                        std::vector<uint8_t> &status, hipStream_t st, double *gpu_ms = nullptr) {
         Launch L;
-        VSTAB_TRY(track_launch(I, J, prev_xy, st, gpu_ms != nullptr, L));
-        return track_wait(L, prev_xy.size() / 2, next_xy, status, st, gpu_ms);
+        const LkPyramid pyr[2] = {I, J};
+        VSTAB_TRY(track_launch(pyr, 1, prev_xy, st, gpu_ms != nullptr, L));
+        return track_wait(L, 0, prev_xy.size() / 2, next_xy, status, st, gpu_ms);
     }
 
     int levels() const { return levels_; }
@@ -465,11 +465,38 @@ class Tracker {
     }
 
   private:
+    vstab_status launch_segment(const LkPyramid *pyr, int n_frames, const float2 *prev_pts, const void *chain_in, uint32_t parent_seq, hipStream_t st,
+                                Launch &L) {
+        if (n_frames < 1 || n_frames > LK_SEG_MAX) return fail(VSTAB_ERR_INVALID, "tracker: a launch covers 1 .. LK_SEG_MAX frame pairs");
+        LkSegArgs a;
+        std::memset(&a, 0, sizeof(a));
+        L.n_frames = n_frames;
+        for (int i = 0; i <= n_frames; i++) a.pyr[i] = pyr[i];
+        for (int i = 0; i < n_frames; i++) {
+            L.buf[i] = (int)(rec_next_++ % REC_BUFS);
+            if (++seq_ == 0) ++seq_;  // tag 0 means "never written"
+            L.seq[i] = seq_;
+            VSTAB_TRY(hrec_[L.buf[i]].ensure((size_t)L.n_slots * 16));
+            VSTAB_TRY(drec_[L.buf[i]].ensure((size_t)L.n_slots * 16));
+            if (!hrec_[L.buf[i]].dev()) return fail(VSTAB_ERR_DEVICE, "hipHostGetDevicePointer failed");
+            a.host_rec[i] = static_cast<uint4 *>(hrec_[L.buf[i]].dev()), a.dev_rec[i] = drec_[L.buf[i]].as<uint4>(), a.seq[i] = L.seq[i];
+        }
+        a.n_frames = n_frames, a.n = L.n_slots;
+        a.prev_pts = prev_pts, a.chain_in = static_cast<const uint4 *>(chain_in), a.parent_seq = parent_seq;
+        a.clk = static_cast<unsigned long long *>(clock_slot());
+        if (L.timed && !ev_a_) (void)hipEventCreate(&ev_a_), (void)hipEventCreate(&ev_b_);
+        if (L.timed) (void)hipEventRecord(ev_a_, st);
+        VSTAB_TRY(launch_lk(a, st));
+        if (L.timed) (void)hipEventRecord(ev_b_, st);
+        return VSTAB_OK;
+    }
+
     int w_ = 0, h_ = 0, levels_ = 1;
     int lvl_w_[LK_MAX_LEVELS] = {0}, lvl_h_[LK_MAX_LEVELS] = {0};
     DevBuf pyr_[PYR_SETS][LK_MAX_LEVELS], eig_, keys_, small_;  // pyramid sets: previous, current, prefetched x2
     DevBuf spec_raw_, spec_keys_, spec_small_, raw_keys_;
     bool two_pass_detector_ = false;
+    const bool single_level_pyramid_ = getenv("VSTAB_PYR_SINGLE") != nullptr;  // development: one launch per pyramid level
     long fused_overflows_ = 0;
     PinnedBuf spec_host_;
     hipEvent_t spec_ev_ = nullptr;
@@ -485,11 +512,11 @@ class Tracker {
     static constexpr int CLK_N = 4096;
     DevBuf clk_;
     int clk_used_ = 0;
-    PinnedBuf hsmall_, hkeys_, hpts_[REC_BUFS], hrec_[REC_BUFS];
+    PinnedBuf hsmall_, hkeys_, hpts_[PTS_BUFS], hrec_[REC_BUFS];
     DevBuf drec_[REC_BUFS];
     unsigned int cap_ = 0;
     hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
-    unsigned long launches_ = 0;
+    unsigned long rec_next_ = 0, pts_launches_ = 0;
     uint32_t seq_ = 0;
 };
 
@@ -574,7 +601,7 @@ using namespace vstab;
 struct vstab_handle {
     // every way out of vstab_create after the streams and events exist, and vstab_destroy, ends here
     ~vstab_handle() {
-        for (hipStream_t s : {tstream, tstream2, pstream, dstream})
+        for (hipStream_t s : {tstream, pstream, dstream})
             if (s) (void)hipStreamSynchronize(s);
         for (auto &pe : pending) (void)hipEventDestroy(pe.a), (void)hipEventDestroy(pe.b);
         for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
@@ -582,7 +609,7 @@ struct vstab_handle {
             if (s.ingested) (void)hipEventDestroy(s.ingested);
         for (hipEvent_t e : warp_events)
             if (e) (void)hipEventDestroy(e);
-        for (hipStream_t s : {dstream, pstream, tstream2, tstream})
+        for (hipStream_t s : {dstream, pstream, tstream})
             if (s) (void)hipStreamDestroy(s);
         for (auto &d : dmabufs) (void)hipDestroyExternalMemory(d.ext);
     }
@@ -590,10 +617,6 @@ struct vstab_handle {
     vstab_source src;
     hipStream_t stream = nullptr;   // caller-visible stream: the warp runs here, dst is complete when it drains
     hipStream_t tstream = nullptr;  // internal stream: corner detection + LK (the per-frame critical path)
-    hipStream_t tstream2 = nullptr; // a second one for LK: a launch chained behind the previous frame's goes to the stream its
-                                    // parent is NOT on, so the two run side by side and every slot follows its own predecessor
-    bool lk_on_second = false;      // which of the two the launch in flight sits on
-    hipStream_t lk_stream(bool second) const { return second && tstream2 ? tstream2 : tstream; }
     hipStream_t pstream = nullptr;  // internal stream: ingest + pyramid of the NEXT frame (prefetch, overlaps LK)
     int w = 0, h = 0, ow = 0, oh = 0;
     Mat3 Kin, Kout;
@@ -738,7 +761,6 @@ struct vstab_handle {
         if (dstream) (void)hipStreamSynchronize(dstream);
         (void)hipStreamSynchronize(pstream);
         (void)hipStreamSynchronize(tstream);
-        if (tstream2) (void)hipStreamSynchronize(tstream2);
         (void)hipStreamSynchronize(stream);
         double *sums[ST_COUNT] = {&prof.gpu_ingest_ms, &prof.gpu_pyramid_ms, &prof.gpu_corners_ms, &prof.gpu_lk_ms, &prof.gpu_warp_ms};
         for (auto &p : pending) {
@@ -755,14 +777,27 @@ struct vstab_handle {
         vstab_frame_log lg{};
         std::vector<float> prev, pp, cp;
     };
-    Tracked inflight, ready;
-    bool have_inflight = false, have_ready = false, src_eof = false;
+    Tracked inflight, ready, estimating;  // ... and whose rotation estimate is running (or waiting to be computed)
+    bool have_inflight = false, have_ready = false, have_estimating = false, src_eof = false;
     // LK launches: the one whose results the host waits for next, and the one chained behind it for the
     // following frame (speculative: valid unless that frame turns out to be a key frame, :415)
-    Tracker::Launch inflight_launch, spec_launch;
-    long spec_frame = -1;        // frame index the chained launch tracks into; -1 = none
-    bool spec_is_key = false;    // that launch is a pre-launched key frame (fresh corners from the speculative detection)
-    std::vector<float> pre_corners;
+    // Tracker launches.  One launch covers a SEGMENT of consecutive frames (k_lk_track: every feature slot runs down its own
+    // chain through the segment's frames); segments are enqueued ahead of the frame the host is at, as far as the frames read
+    // ahead reach, each chained on the device behind the one before it -- or started from freshly detected corners where the
+    // counter half of the key-frame rule (:415) says a key frame will be.  Everything enqueued ahead is speculative: it is
+    // dropped when the count half of the rule (< 150 survivors) makes a frame a key frame nobody planned for.
+    struct Segment {
+        long first = 0;            // frame index (frame_index numbering) of its first frame
+        int n = 0;                 // frames covered
+        bool key = false;          // starts from fresh corners detected on frame first - 1 (a planned key frame); else chained
+        long last_key_after = -1;  // what last_key will be once the host has passed this segment
+        std::vector<float> corners;  // key segments: the corners it was launched with
+        Tracker::Launch launch;
+    };
+    std::deque<Segment> segs;        // launched, not yet used up; consecutive, in frame order; front covers the host's frame
+    Tracker::Launch inflight_launch; // the launch, and the frame pair of it, whose results the host waits for next
+    int inflight_idx = 0;
+    long segs_launched = 0, seg_frames_launched = 0, seg_frames_dropped = 0;
     DevBuf host_out;                // staging buffer of vstab_pull_frame_host
     DevBuf bgr16_out;               // 16-bit BGR frame of vstab_pull_frame_p010 (converted to P010 planes behind the warp)
     // Quantised-map cache: when two consecutive frames are warped with the same 17 parameters (tracking off, or any
@@ -786,10 +821,9 @@ struct vstab_handle {
     std::vector<DmaBuf> dmabufs;
     long dmabuf_clock = 0, dmabuf_imports = 0, dmabuf_evictions = 0;
     int dmabuf_cache_cap = 256;  // VSTAB_DMABUF_CACHE=n (tests): a smaller cache, so that eviction is reached with a few objects
-    bool chain_lk = true;        // VSTAB_CHAIN_LK=0 disables chained launches
-    bool two_lk_streams = false; // VSTAB_LK_STREAMS=2 (development): chained launches alternate between two streams and every slot waits for
-                                 // its own predecessor in the kernel -- measured slower than the stream-ordered chain
-    bool spec_on_second = false; // the stream of spec_launch
+    bool chain_lk = true;        // VSTAB_CHAIN_LK=0: no launches ahead of the host's frame (one frame per launch, on demand)
+    int seg_max = LK_SEG_MAX;    // VSTAB_LK_SEGMENT=n: frames per tracker launch at most (1 = a launch per frame, chained one frame ahead)
+    int seg_target = 4;          // a chained segment is enqueued once this many frames are waiting (fewer only at a key frame or when the tracker would idle)
     long chained_adopted = 0, chained_discarded = 0, key_prelaunched = 0;
     // a frame that has been pulled from upstream, copied into the ring and whose pyramid is being built
     std::deque<std::pair<int, int>> prefetched;  // (ring slot, pyramid set), oldest first
@@ -1089,7 +1123,7 @@ static vstab_status prefetch_next(vstab_handle *H) {
     {
         if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "spec launch for frame %ld (last_key %ld)\n", H->prefetch_count, H->last_key);
         HT t(HostTimers::SPEC_DETECT);
-        hipStream_t ds = H->dstream ? H->dstream : H->pstream;  // with two tracker streams the detection shares the prefetch stream
+        hipStream_t ds = H->dstream ? H->dstream : H->pstream;
         if (ds != H->pstream) VSTAB_HIP_TRY(hipStreamWaitEvent(ds, H->slots[slot].ingested, 0));
         VSTAB_TRY(H->tracker.spec_launch(H->gray(slot), H->gpitch(slot), 0.01, ds, H->prefetch_count));
         H->tracker.spec_select_async(200, 30.0);
@@ -1132,21 +1166,69 @@ static vstab_status launch_tracking(vstab_handle *H) {
         vstab_handle::Tracked &T = H->inflight;
         T = vstab_handle::Tracked();
         T.slot = slot;
+        const long F = H->frame_index;
         const uint8_t *pg = H->gray(H->last_slot);
         const size_t ppitch = H->gpitch(H->last_slot);
-        bool used_pre = false;
+        // pyramid of a frame at or after F - 1 (all of them are in the ring: F - 1 is the last tracked frame, F the one popped
+        // above, the following ones wait in `prefetched`)
+        auto pyr_of = [&](long fr) {
+            if (fr == F - 1) return H->tracker.pyramid(H->cur_pyr, pg, ppitch);
+            if (fr == F) return H->tracker.pyramid(pyr, g, pitch);
+            const auto &pf = H->prefetched[(size_t)(fr - F - 1)];
+            return H->tracker.pyramid(pf.second, H->gray(pf.first), H->gpitch(pf.first));
+        };
+        auto slot_of = [&](long fr) { return fr == F ? slot : H->prefetched[(size_t)(fr - F - 1)].first; };
+        // the last frame read ahead whose copy + pyramid (prefetch stream) have COMPLETED, as far as the host can see without
+        // waiting: a launch may only start once the pyramid of its last frame exists, so a segment that reached for the
+        // frame pulled a moment ago would hold all its earlier frames back (measured: segments of 8 were slower than of 1)
+        long reach = F;
+        for (size_t j = 0; j < H->prefetched.size(); j++) {
+            if (hipEventQuery(H->slots[H->prefetched[j].first].ingested) != hipSuccess) break;
+            reach = F + 1 + (long)j;
+        }
+        auto drop_segments = [&]() {
+            for (const auto &sg : H->segs) H->seg_frames_dropped += sg.first + sg.n - std::max(sg.first, F);
+            H->segs.clear();
+        };
+        // enqueue a segment of n frames from `first` on: from `start` (host points) or chained behind `parent`
+        auto launch_segment = [&](long first, int n, bool key, const std::vector<float> *start, const Tracker::Launch *parent, long last_key_after,
+                                  bool timed) -> vstab_status {
+            LkPyramid pyrs[LK_SEG_MAX + 1];
+            for (int i = 0; i <= n; i++) pyrs[i] = pyr_of(first - 1 + i);
+            // copy + pyramid of the segment's frames: they are enqueued in frame order on the prefetch stream, the last one covers all
+            VSTAB_TRY(vstab_handle::wait_if_pending(H->tstream, H->slots[slot_of(first + n - 1)].ingested));
+            vstab_handle::Segment sg;
+            sg.first = first, sg.n = n, sg.key = key, sg.last_key_after = last_key_after;
+            if (start) {
+                if (key) sg.corners = *start;
+                VSTAB_TRY(H->tracker.track_launch(pyrs, n, *start, H->tstream, timed, sg.launch));
+            } else {
+                VSTAB_TRY(H->tracker.track_launch_chained(pyrs, n, *parent, H->tstream, sg.launch));
+            }
+            H->segs_launched++, H->seg_frames_launched += n;
+            H->segs.push_back(std::move(sg));
+            return VSTAB_OK;
+        };
+        while (!H->segs.empty() && H->segs.front().first + H->segs.front().n <= F) H->segs.pop_front();  // used up
         // :415-419 key-frame rule; corners are found in the PREVIOUS gray frame
-        if (H->frame_index - H->last_key > 20 || H->corners.size() / 2 < 150) {
-            H->last_key = H->frame_index - 1;
+        const bool is_key = F - H->last_key > 20 || H->corners.size() / 2 < 150;
+        const vstab_handle::Segment *front = H->segs.empty() ? nullptr : &H->segs.front();
+        // what was enqueued for this frame stands if it made the same decision: a key segment starting here for a key frame,
+        // the inside of a segment (or the start of a chained one) for an ordinary frame
+        const bool covered = front && front->first <= F;
+        const bool planned_key = covered && front->key && front->first == F;
+        bool adopt = covered && planned_key == is_key;
+        if (covered && !adopt) H->chained_discarded++;
+        if (is_key) {
+            H->last_key = F - 1;
             HostStage hs(&H->prof.host_corners_ms);
-            if (H->spec_frame == H->frame_index && H->spec_is_key) {
-                H->corners = H->pre_corners;  // this key frame's tracker is already running on them
-                used_pre = true;
+            if (adopt) {
+                H->corners = front->corners;  // this key frame's tracker is already running on them
                 H->key_prelaunched++;
             } else {
-                // the previous frame is frame_index - 1: use its speculative detection if there is one
-                const bool spec = H->tracker.spec_tag() == H->frame_index - 1 && H->tracker.spec_finish(200, 30.0, H->corners);
-                if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "key frame at %ld: spec_tag %ld used %d\n", H->frame_index, H->tracker.spec_tag(), (int)spec);
+                // the previous frame is F - 1: use its speculative detection if there is one
+                const bool spec = H->tracker.spec_tag() == F - 1 && H->tracker.spec_finish(200, 30.0, H->corners);
+                if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "key frame at %ld: spec_tag %ld used %d\n", F, H->tracker.spec_tag(), (int)spec);
                 if (!spec) VSTAB_TRY(H->tracker.good_features(pg, ppitch, 200, 0.01, 30.0, H->corners, H->tstream));
             }
             T.lg.key_frame = 1;
@@ -1154,55 +1236,48 @@ static vstab_status launch_tracking(vstab_handle *H) {
         }
         T.lg.n_corners = (int)(H->corners.size() / 2);
         T.prev = H->corners;
-        if (H->spec_frame == H->frame_index && (H->spec_is_key ? used_pre : !T.lg.key_frame)) {
-            // the launch chained behind the previous frame's tracker is this frame's tracker: same points (the
-            // survivors, read on the device), same images
-            H->inflight_launch = H->spec_launch;
-            H->lk_on_second = H->spec_on_second;
+        // how many frames a launch may cover: the whole read-ahead when launches are chained ahead, one frame otherwise
+        const bool ahead = H->chain_lk && H->profiling < 2;
+        const int seg_max = ahead ? H->seg_max : 1;
+        if (adopt) {
             H->chained_adopted++;
         } else {
-            if (H->spec_frame == H->frame_index) H->chained_discarded++;  // key frame after all: its results are ignored
+            // everything enqueued ahead assumed another course of events (or nothing was enqueued): start afresh from the host's
+            // corner list.  Dropped launches may still be running; this one queues behind them on the tracker stream.
+            drop_segments();
             HT t(HostTimers::LK_LAUNCH);
-            // a discarded chained launch may still be running: this one takes the other stream (its parent's, which has drained)
-            H->lk_on_second = H->spec_frame == H->frame_index ? !H->spec_on_second : false;
-            hipStream_t ls = H->lk_stream(H->lk_on_second);
-            VSTAB_TRY(vstab_handle::wait_if_pending(ls, H->slots[slot].ingested));  // pyramid (and ring copy) of this frame
-            VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(H->cur_pyr, pg, ppitch), H->tracker.pyramid(pyr, g, pitch), H->corners,
-                                              ls, H->profiling >= 2, H->inflight_launch));
+            const long kc = H->last_key + 21;  // the next frame the counter makes a key frame
+            const int n = (int)std::max<long>(1, std::min<long>({(long)seg_max, reach - F + 1, kc - F}));
+            VSTAB_TRY(launch_segment(F, n, false, &H->corners, nullptr, H->last_key, H->profiling >= 2));
         }
-        H->spec_frame = -1, H->spec_is_key = false;
+        H->inflight_launch = H->segs.front().launch, H->inflight_idx = (int)(F - H->segs.front().first);
         H->have_inflight = true;
-        // Chain the NEXT frame's tracker behind this one if its frame is already in the ring and the counter
-        // half of the key-frame rule (:415) cannot fire for it; the count half (< 150 survivors) is checked
-        // when that frame's turn comes, and the chained launch is dropped if it does.
-        if (H->chain_lk && H->profiling < 2 && !H->prefetched.empty() && H->inflight_launch.n_slots > 0 &&
-            (H->frame_index + 1) - H->last_key <= 20) {
+        // Enqueue further segments as far as the read-ahead reaches: chained behind the last one up to the next key frame the
+        // counter half of the rule (:415) predicts, and -- once that key frame's corners (detected speculatively on the frame before
+        // it) are selected -- a segment from those corners, which does not depend on any earlier tracking at all.  The count half
+        // (< 150 survivors) is checked when a frame's turn comes; if it fires, what was enqueued beyond is dropped (above).
+        while (ahead) {
             HT t(HostTimers::LK_CHAIN);
-            const int nslot = H->prefetched.front().first, npyr = H->prefetched.front().second;
-            // on the stream the parent is NOT on: the two launches overlap, each slot waits for its own predecessor
-            // in the kernel (k_lk_track).  The launch before the parent (same stream) has been read by the host already.
-            H->spec_on_second = H->two_lk_streams ? !H->lk_on_second : H->lk_on_second;
-            hipStream_t cs = H->lk_stream(H->spec_on_second);
-            VSTAB_TRY(vstab_handle::wait_if_pending(cs, H->slots[nslot].ingested));
-            VSTAB_TRY(H->tracker.track_launch_chained(H->tracker.pyramid(pyr, g, pitch), H->tracker.pyramid(npyr, H->gray(nslot), H->gpitch(nslot)),
-                                                      H->inflight_launch, cs, H->spec_launch));
-            H->spec_frame = H->frame_index + 1;
-        } else if (H->chain_lk && H->profiling < 2 && !H->prefetched.empty() && (H->frame_index + 1) - H->last_key > 20 &&
-                   H->tracker.spec_tag() == H->frame_index && H->tracker.spec_state() != 2) {
-            if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "frame %ld: selection not ready (state %d)\n", H->frame_index, H->tracker.spec_state());
-        } else if (H->chain_lk && H->profiling < 2 && !H->prefetched.empty() && (H->frame_index + 1) - H->last_key > 20 &&
-                   H->tracker.spec_tag() == H->frame_index && H->tracker.spec_state() == 2) {
-            // The next frame is a key frame by the counter, its corners (detected on THIS frame, speculatively) are
-            // already selected, and they do not depend on this frame's tracking at all: launch its tracker now.
-            HT t(HostTimers::LK_CHAIN);
-            H->tracker.spec_take(H->pre_corners);
-            const int nslot = H->prefetched.front().first, npyr = H->prefetched.front().second;
-            H->spec_on_second = H->two_lk_streams ? !H->lk_on_second : H->lk_on_second;  // independent of the launch in flight: beside it
-            hipStream_t cs = H->lk_stream(H->spec_on_second);
-            VSTAB_TRY(vstab_handle::wait_if_pending(cs, H->slots[nslot].ingested));
-            VSTAB_TRY(H->tracker.track_launch(H->tracker.pyramid(pyr, g, pitch), H->tracker.pyramid(npyr, H->gray(nslot), H->gpitch(nslot)), H->pre_corners,
-                                              cs, false, H->spec_launch));
-            H->spec_frame = H->frame_index + 1, H->spec_is_key = true;
+            const vstab_handle::Segment &back = H->segs.back();
+            const long tail = back.first + back.n - 1, next = tail + 1, avail = reach - tail;
+            if (avail <= 0 || back.launch.n_slots == 0) break;
+            const long kc = back.last_key_after + 21;  // next planned key frame
+            if (next == kc) {
+                if (H->tracker.spec_tag() != tail || H->tracker.spec_state() != 2) {
+                    if (getenv("VSTAB_DEBUG_SPEC") && H->tracker.spec_tag() == tail)
+                        std::fprintf(stderr, "frame %ld: corners for key frame %ld not selected yet (state %d)\n", F, next, H->tracker.spec_state());
+                    break;  // not detected / selected yet: next pull, or on demand when the host gets there
+                }
+                std::vector<float> fresh;
+                H->tracker.spec_take(fresh);
+                const int n = (int)std::min<long>({(long)seg_max, avail, 21});
+                VSTAB_TRY(launch_segment(next, n, true, &fresh, nullptr, next - 1, false));
+                continue;
+            }
+            const int n = (int)std::min<long>({(long)seg_max, avail, kc - next});
+            // full segments; shorter ones only up to a key frame, or when nothing is enqueued beyond the host's frame
+            if (n < H->seg_target && next + n != kc && tail > F) break;
+            VSTAB_TRY(launch_segment(next, n, false, nullptr, &back.launch, back.last_key_after, false));
         }
     }
     H->cur_pyr = pyr;
@@ -1224,7 +1299,7 @@ static vstab_status finish_wait(vstab_handle *H) {
     std::vector<uint8_t> st;
     {
         HostStage hs(&H->prof.host_track_wait_ms);
-        VSTAB_TRY(H->tracker.track_wait(H->inflight_launch, T.prev.size() / 2, nxt, st, H->lk_stream(H->lk_on_second),
+        VSTAB_TRY(H->tracker.track_wait(H->inflight_launch, H->inflight_idx, T.prev.size() / 2, nxt, st, H->tstream,
                                         H->profiling >= 2 ? &H->prof.gpu_lk_ms : nullptr));
     }
     // :261-268 keep pairs with status != 0
@@ -1240,17 +1315,24 @@ static vstab_status finish_wait(vstab_handle *H) {
     return VSTAB_OK;
 }
 
-// start the rotation estimate of the ready frame on the worker thread (:429-431)
+// start the rotation estimate of the ready frame on the worker thread (:429-431).  The frame moves on to `estimating`, so
+// that the next frame's LK results can be read while this estimate runs: the worker gets a whole frame period (the launches
+// of the following frames, the warp of the emitted one, the caller's own code) instead of the few microseconds between two
+// steps of one call.  Estimates are still computed and applied strictly in frame order (one at a time: the random stream,
+// the < 40 inlier fallback and the accumulation of :441 are sequential).
 static void post_estimate(vstab_handle *H) {
-    if (!H->have_ready || H->estimate_posted || !H->threaded_estimate) return;
-    vstab_handle::Tracked &T = H->ready;
+    if (!H->have_ready || H->have_estimating) return;
+    H->estimating = std::move(H->ready);
+    H->have_ready = false, H->have_estimating = true;
+    if (!H->threaded_estimate) return;  // computed by finish_estimate on the calling thread
+    vstab_handle::Tracked &T = H->estimating;
     H->worker.post(T.pp.data(), T.cp.data(), T.lg.n_tracked, &H->Kin, &H->Kout, &H->rng, H->in_fish);
     H->estimate_posted = true;
 }
 
 static void finish_estimate(vstab_handle *H) {
-    if (!H->have_ready) return;
-    vstab_handle::Tracked &T = H->ready;
+    if (!H->have_estimating) return;
+    vstab_handle::Tracked &T = H->estimating;
     vstab_frame_log &lg = T.lg;
     // :429-438 rotation since the last frame, with the < 40 inlier fallback
     Mat3 R;
@@ -1276,7 +1358,7 @@ static void finish_estimate(vstab_handle *H) {
     std::memcpy(lg.R_accum, H->measured.m, sizeof(R.m));
     H->log.push_back(lg);
     if (H->log.size() > vstab_handle::LOG_KEEP) H->log.pop_front(), H->log_base++;
-    H->have_ready = false;
+    H->have_estimating = false;
 }
 
 extern "C" {
@@ -1332,7 +1414,8 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (const char *e = getenv("VSTAB_SPECULATE")) H->speculate = atoi(e) != 0;
     if (const char *e = getenv("VSTAB_THREADED_ESTIMATE")) H->threaded_estimate = atoi(e) != 0;
     if (const char *e = getenv("VSTAB_CHAIN_LK")) H->chain_lk = atoi(e) != 0;
-    if (const char *e = getenv("VSTAB_LK_STREAMS")) H->two_lk_streams = atoi(e) == 2;
+    if (const char *e = getenv("VSTAB_LK_SEGMENT")) H->seg_max = std::max(1, std::min(atoi(e), LK_SEG_MAX));
+    H->seg_target = std::min(H->seg_target, H->seg_max);
     if (const char *e = getenv("VSTAB_MAP_CACHE")) H->map_cache = atoi(e) != 0;
     if (const char *e = getenv("VSTAB_DMABUF_CACHE")) H->dmabuf_cache_cap = std::max(1, atoi(e));
     H->stream = static_cast<hipStream_t>(cfg->stream);  // NULL = the default stream, as for the stateless operators
@@ -1342,15 +1425,14 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->tstream, hipStreamNonBlocking, hi));
-        if (H->two_lk_streams) VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->tstream2, hipStreamNonBlocking, hi));
         // copy + pyramid of the NEXT frame have a whole frame period of slack: lowest priority, so they fill
         // in behind the warp instead of taking its CUs
         VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, lo));
         // (this runtime offers two priority levels; beside a saturating warp the detection takes ~500 us at either)
         // The runtime multiplexes its streams onto four hardware queues, and two streams that share one serialise (a fifth
-        // stream cost the 4K pipeline 4 k frames/s merely by existing): caller + tracker + prefetch leave ONE more.  It goes
-        // to the second tracker stream when chained launches alternate, else to the speculative detection.
-        if (!H->two_lk_streams) VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->dstream, hipStreamNonBlocking, lo));
+        // stream cost the 4K pipeline 4 k frames/s merely by existing): caller + tracker + prefetch leave ONE more: the
+        // speculative corner detection's.
+        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->dstream, hipStreamNonBlocking, lo));
         for (auto &e : H->warp_events) VSTAB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // :214-219 peek the first frame for the input size, then derive both cameras
@@ -1413,11 +1495,19 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: a pixel_depth 10 handle emits through vstab_pull_frame_bgr16, an 8-bit handle through the others");
     HT t_total(HostTimers::TOTAL);
     while (H->queue.size() <= (size_t)H->cfg.smooth_radius) {  // :453
-        // 1. LK results of the frame in flight -> surviving corners; its rotation estimate starts on the
-        //    worker thread right away
+        if (!H->have_inflight && !H->have_ready && !H->have_estimating && H->prefetched.empty() && H->src_eof) {  // every frame read has been queued
+            if (H->src_error) return fail(VSTAB_ERR_SOURCE, "upstream pull failed with " + std::to_string(H->src_error));
+            // :456-461 pretend the camera kept its last orientation (once per call while draining)
+            if (H->sg) H->sg->add(H->measured);
+            break;
+        }
+        // 1. LK results of the frame in flight -> surviving corners
         if (H->have_inflight) VSTAB_TRY(finish_wait(H));
+        // 2. the rotation estimate that was started a frame ago (it ran beside everything since) -> queue its frame; then
+        //    the frame just read starts its estimate on the worker thread
+        finish_estimate(H);
         post_estimate(H);
-        // 2. key-frame rule + LK launch for the oldest prefetched frame (the GPU's critical path)
+        // 3. key-frame rule + LK launch for the oldest prefetched frame, and the launches that can be enqueued ahead of it
         if (H->prefetched.empty() && !H->src_eof) {
             const vstab_status st = prefetch_next(H);
             if (st != VSTAB_OK && st != VSTAB_EOF) return st;
@@ -1427,21 +1517,10 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
             VSTAB_TRY(launch_tracking(H));
             if (H->queue.size() != queued) continue;  // (tracking off: the frame is queued at once) re-check :453 before :456
         }
-        // 3. read ahead: pull + copy + pyramid of the following frames (prefetch stream)
+        // 4. read ahead: pull + copy + pyramid of the following frames (prefetch stream)
         while ((int)H->prefetched.size() < PREFETCH_DEPTH && !H->src_eof) {
             const vstab_status st = prefetch_next(H);
             if (st != VSTAB_OK && st != VSTAB_EOF) return st;
-        }
-        // 4. collect the rotation estimate (it ran beside steps 2-3) and queue the frame
-        if (H->have_ready) {
-            finish_estimate(H);
-            continue;
-        }
-        if (!H->have_inflight && H->prefetched.empty() && H->src_eof) {
-            if (H->src_error) return fail(VSTAB_ERR_SOURCE, "upstream pull failed with " + std::to_string(H->src_error));
-            // :456-461 pretend the camera kept its last orientation (once per call while draining)
-            if (H->sg) H->sg->add(H->measured);
-            break;
         }
     }
     if (H->queue.empty()) return VSTAB_EOF;  // :465-467
@@ -1654,8 +1733,10 @@ void vstab_destroy(vstab_handle *h) {
         std::fprintf(stderr, "frames used in place %ld, copied into the ring %ld; warps from the cached map %ld\n", h->frames_borrowed, h->frames_copied,
                      h->warps_from_cache);
     if (getenv("VSTAB_DEBUG_SPEC"))
-        std::fprintf(stderr, "chained LK launches: adopted %ld, discarded %ld of %ld frames; key frames pre-launched %ld of %ld\n", h->chained_adopted,
-                     h->chained_discarded, h->frame_index, h->key_prelaunched, h->prof.key_frames);
+        std::fprintf(stderr, "tracker launches: %ld segments covering %ld frames (%ld of them dropped); frames taken from a launch enqueued ahead %ld, "
+                             "replaced on demand %ld, of %ld; key frames pre-launched %ld of %ld\n",
+                     h->segs_launched, h->seg_frames_launched, h->seg_frames_dropped, h->chained_adopted, h->chained_discarded, h->frame_index,
+                     h->key_prelaunched, h->prof.key_frames);
     if (h->estimate_posted) {
         Mat3 r;
         (void)h->worker.join(r);
@@ -1746,6 +1827,17 @@ vstab_status vstab_pyr_down(const void *src, size_t pitch_src, int width, int he
     if (!src || !dst || width <= 0 || height <= 0 || pitch_src < (size_t)width || pitch_dst < (size_t)((width + 1) / 2))
         return fail(VSTAB_ERR_INVALID, "vstab_pyr_down: bad argument");
     return launch_pyr_down((const uint8_t *)src, pitch_src, width, height, (uint8_t *)dst, pitch_dst, static_cast<hipStream_t>(stream));
+}
+
+vstab_status vstab_pyr_down_x2(const void *src, size_t pitch_src, int width, int height, void *mid, size_t pitch_mid, void *dst, size_t pitch_dst, void *stream) {
+    const int mw = (width + 1) / 2, mh = (height + 1) / 2;
+    if (!src || !mid || !dst || width <= 0 || height <= 0 || pitch_src < (size_t)width || pitch_mid < (size_t)mw || pitch_dst < (size_t)((mw + 1) / 2))
+        return fail(VSTAB_ERR_INVALID, "vstab_pyr_down_x2: bad argument");
+    if (!pyr_down_x2_ok(width, height)) {  // tiny images: two single-level launches, the same bytes
+        VSTAB_TRY(launch_pyr_down((const uint8_t *)src, pitch_src, width, height, (uint8_t *)mid, pitch_mid, static_cast<hipStream_t>(stream)));
+        return launch_pyr_down((const uint8_t *)mid, pitch_mid, mw, mh, (uint8_t *)dst, pitch_dst, static_cast<hipStream_t>(stream));
+    }
+    return launch_pyr_down_x2((const uint8_t *)src, pitch_src, width, height, (uint8_t *)mid, pitch_mid, (uint8_t *)dst, pitch_dst, static_cast<hipStream_t>(stream));
 }
 
 vstab_status vstab_min_eig(const void *gray, size_t pitch, int width, int height, void *eig, void *stream) {

@@ -149,6 +149,85 @@ __global__ void __launch_bounds__(256) k_pyr_down(const uint8_t *__restrict__ sr
 }
 
 // =============================================================================================
+// k_pyr_down_x2 -- TWO pyramid levels in one launch (levels 2 and 3 of the LK pyramid from level 1): the small levels are
+// launch- and latency-bound as kernels of their own (a 4K frame's level 3 is 480 x 270), and the prefetch stream paid three
+// launches per frame.  A workgroup owns 14 x 12 outputs of the SECOND level: it stages the source region they depend on
+// (80 x 57 bytes, REFLECT_101 applied while staging), computes the 36 x 27 first-level outputs around them with the same
+// v_dot4 arithmetic as k_pyr_down (into LDS, and to global memory for the 28 x 24 of them it owns), then the second level
+// from those -- reflecting FIRST-LEVEL coordinates, as pyrDown of the stored first level does.  Integer sums: exact in any order.
+// =============================================================================================
+constexpr int P2_TW = 14, P2_TH = 12;                   // second-level outputs per workgroup
+constexpr int P2_MW = 36, P2_MH = 2 * P2_TH + 3;        // first-level region: columns 2 x0 - 4 .. 2 x0 + 31 (9 groups of 4), rows 2 y0 - 2 .. 2 y0 + 24
+constexpr int P2_SW = 80, P2_SH = 2 * P2_MH + 3;        // source region: columns 4 x0 - 12 .. 4 x0 + 67, rows 4 y0 - 6 .. 4 y0 + 50
+
+__global__ void __launch_bounds__(256) k_pyr_down_x2(const uint8_t *__restrict__ src, uint32_t spitch, int sw, int sh, uint8_t *__restrict__ mid,
+                                                     uint32_t mpitch, int mw, int mh, uint8_t *__restrict__ dst, uint32_t dpitch, int dw, int dh, int vec_ok) {
+    __shared__ __attribute__((aligned(16))) uint8_t ssrc[P2_SH][P2_SW];
+    __shared__ __attribute__((aligned(16))) uint8_t smid[P2_MH][P2_MW];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * P2_TW, y0 = blockIdx.y * P2_TH;  // second-level origin of the tile
+    const int mx0 = 2 * x0 - 4, my0 = 2 * y0 - 2;                 // first-level origin of the region
+    const int sx0 = 2 * mx0 - 4, sy0 = 2 * my0 - 2;               // source origin of the region (a multiple of 4)
+    // ---- stage the source region, reflected -----------------------------------------------------------------------------
+    for (int e = tid; e < P2_SH * (P2_SW / 4); e += 256) {
+        const int ry = e / (P2_SW / 4), rd = e - ry * (P2_SW / 4);
+        reinterpret_cast<uint32_t *>(&ssrc[ry][0])[rd] = load4_reflect(src, spitch, sw, sh, sx0 + 4 * rd, sy0 + ry, vec_ok != 0);
+    }
+    __syncthreads();
+    // ---- first level: 9 groups of 4 outputs x 27 rows, one group per thread ---------------------------------------------
+    if (tid < 9 * P2_MH) {
+        const int ry = tid / 9, g = tid - ry * 9;
+        const int my = my0 + ry, mx = mx0 + 4 * g;
+        if (my >= 0 && my < mh && mx + 3 >= 0 && mx < mw) {
+            // output column c of the group uses source bytes 8 g + 2 c + 2 .. + 6 of source rows 2 ry .. 2 ry + 4
+            uint32_t acc[4] = {128u, 128u, 128u, 128u};
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const uint2 dl = *reinterpret_cast<const uint2 *>(&ssrc[2 * ry + j][8 * g]), dh2 = *reinterpret_cast<const uint2 *>(&ssrc[2 * ry + j][8 * g + 8]);
+                const uint4 d = make_uint4(dl.x, dl.y, dh2.x, dh2.y);  // (8-byte aligned: rows are 80 bytes, groups 8 bytes apart)
+                const uint32_t k = j == 0 || j == 4 ? 1u : j == 2 ? 6u : 4u;
+                const uint32_t w_hi2 = (k << 16) | (4 * k << 24);
+                const uint32_t w_lo3 = 6 * k | (4 * k << 8) | (k << 16);
+                const uint32_t w_all = k | (4 * k << 8) | (6 * k << 16) | (4 * k << 24);
+                acc[0] = udot4(d.y, w_lo3, udot4(d.x, w_hi2, acc[0]));
+                acc[1] = udot4(d.z, k, udot4(d.y, w_all, acc[1]));
+                acc[2] = udot4(d.z, w_lo3, udot4(d.y, w_hi2, acc[2]));
+                acc[3] = udot4(d.w, k, udot4(d.z, w_all, acc[3]));
+            }
+            const uint32_t p01 = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0501u), p23 = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0501u);
+            const uint32_t out = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+            *reinterpret_cast<uint32_t *>(&smid[ry][4 * g]) = out;
+            // the tile owns first-level columns 2 x0 .. 2 x0 + 27 (groups 1 .. 7) and rows 2 y0 .. 2 y0 + 23
+            if (g >= 1 && g <= 7 && ry >= 2 && ry < 2 + 2 * P2_TH) {
+                uint8_t *o = mid + (uint32_t)my * mpitch + mx;
+                if (vec_ok && mx + 4 <= mw) *reinterpret_cast<uint32_t *>(o) = out;
+                else
+                    for (int c = 0; c < 4 && mx + c < mw; c++) o[c] = (uint8_t)(out >> (8 * c));
+            }
+        }
+    }
+    __syncthreads();
+    // ---- second level from the first-level region (REFLECT_101 in first-level coordinates) ------------------------------
+    if (tid < P2_TW * P2_TH) {
+        const int ty = tid / P2_TW, tx = tid - ty * P2_TW;
+        const int x = x0 + tx, y = y0 + ty;
+        if (x < dw && y < dh) {
+            int col[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) col[i] = reflect101(2 * x - 2 + i, mw) - mx0;
+            uint32_t acc = 128u;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const uint8_t *r = smid[reflect101(2 * y - 2 + j, mh) - my0];
+                const uint32_t k = j == 0 || j == 4 ? 1u : j == 2 ? 6u : 4u;
+                acc += k * ((uint32_t)r[col[0]] + 4u * r[col[1]] + 6u * r[col[2]] + 4u * r[col[3]] + r[col[4]]);
+            }
+            dst[(uint32_t)y * dpitch + x] = (uint8_t)(acc >> 8);
+        }
+    }
+}
+
+// =============================================================================================
 // k_min_eig -- cornerMinEigenVal(blockSize 3, ksize 3): Sobel
 // derivatives scaled by 1/(4*3*255) in the documented operation order, products, 3x3 box sum
 // (exact in double), minimum eigenvalue in float; also reduces the frame maximum.
@@ -638,36 +717,9 @@ __device__ __forceinline__ uint4 make_record(float x, float y, unsigned int stat
 }
 __device__ __forceinline__ unsigned int record_status(const uint4 &r) { return r.w & 3u; }
 
-// The device copy of a record is what the NEXT frame's tracker starts from, slot by slot, possibly while this launch is
-// still running (chained launches sit on alternating streams): each 8-byte granule goes out as ONE agent-scope store
-// (global_store_dwordx2 ... sc1, written through the XCD's L2) and is polled with agent-scope loads of the same width --
-// the data-tagged granule hand-off of /opt/skills/guides/MI355X_MICROARCH.md ("handoff-1to1"): a granule is valid as soon
-// as its own tag is, no fence on either side.
-__device__ __forceinline__ void publish_device_record(uint4 *slot, const uint4 &rec) {
-#ifdef VSTAB_LK_PLAIN_CHAIN
-    *slot = rec;
-    return;
-#endif
-    unsigned long long *g = reinterpret_cast<unsigned long long *>(slot);
-    __hip_atomic_store(g, (unsigned long long)rec.x | ((unsigned long long)rec.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(g + 1, (unsigned long long)rec.z | ((unsigned long long)rec.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Wait until the parent launch (sequence number parent_seq) has published slot's record; bounded: on a time-out the slot
-// reports status 3 and the host fails the frame instead of hanging.
-__device__ __forceinline__ bool await_device_record(const uint4 *slot, unsigned int parent_seq, uint4 &rec) {
-    const unsigned long long *g = reinterpret_cast<const unsigned long long *>(slot);
-    for (unsigned int spins = 0; spins < (1u << 22); spins++) {
-        const unsigned long long a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned int)(a >> 32) == parent_seq && ((unsigned int)(b >> 32) >> 2) == (parent_seq & 0x3fffffffu)) {
-            rec = make_uint4((unsigned int)a, (unsigned int)(a >> 32), (unsigned int)b, (unsigned int)(b >> 32));
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(8);
-    }
-    return false;
-}
-
+// The device copy of a record is what the NEXT launch starts from, slot by slot.  A chained launch sits on the SAME stream
+// behind its parent, so the record is complete when the child starts: a plain 16-byte store here, a plain load there, and the
+// child checks the tag (a mismatch means the host chained the wrong buffers: reported as status 3, never tracked from).
 #ifdef VSTAB_DEV
 // development builds: sixteen 100 MHz wall-clock stamps per feature and launch (tools/lk_timeline.py):
 // [0] entry, [1] start point known, [2] blocks staged, then per level (3 -> 0): [3 + 3 i] derivatives + patch matrix done,
@@ -684,11 +736,14 @@ extern "C" __attribute__((visibility("default"))) void vstab_dev_set_lk_timing(v
 #define LK_NOW() 0ull
 #endif
 
-__global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkPyramid I, LkPyramid J, const float2 *__restrict__ prev_pts,
-                                                         int n, float2 *__restrict__ next_pts, uint8_t *__restrict__ status,
-                                                         uint4 *__restrict__ host_rec, unsigned int seq,
-                                                         const uint4 *chain_in, unsigned int parent_seq, uint4 *dev_rec,
-                                                         unsigned long long *__restrict__ clk) {
+// One launch tracks every feature slot through args.n_frames CONSECUTIVE frame pairs (a "segment"): frame pair i is
+// (args.pyr[i], args.pyr[i + 1]); a slot starts pair 0 from the host's point list (prev_pts) or from the record the parent
+// launch left for it (chain_in), and pair i + 1 from the point it tracked to in pair i -- FrameSourceWarp.cpp:427, where the
+// surviving points of one frame are the next frame's input.  Every slot runs down its own chain at its own pace: the launch
+// lasts as long as the slowest slot's SUM over the frames instead of the sum over the frames of each frame's slowest slot, and
+// the gap between launches is paid once per segment.  Results leave per frame pair (host_rec[i], dev_rec[i]) as soon as the
+// slot has them.  A slot that loses its feature reports status 0 for that pair and status 2 ("lost earlier") for the rest.
+__global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
     __shared__ __attribute__((aligned(16))) int regI[LK_MAX_LEVELS][LKR * LKR];
     __shared__ uint32_t dpk[LK_MAX_LEVELS][LKT * LKT];     // Scharr derivative pairs of the 22 x 22 taps: dx | dy << 16 (int16 each)
     __shared__ short patch[LK_MAX_LEVELS][3][LKW * LKW];   // the interpolated window of every level: I, Ix, Iy
@@ -696,49 +751,39 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkPyramid I, LkPyram
     __shared__ __attribute__((aligned(16))) int regJ[2][LKJR * LKJR];
     __shared__ LkExchange ex;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = args.n;
     if (f >= n) return;
+    unsigned long long *const clk = args.clk;
 #ifdef VSTAB_LK_PRIO
     __builtin_amdgcn_s_setprio(VSTAB_LK_PRIO);
 #endif
     // development aid (VSTAB_LK_CLOCK): first workgroup start / last workgroup end on the 100 MHz wall clock
     if (clk && tid == 0) atomicMin(&clk[0], wall_clock64());
+    unsigned int seq = args.seq[0];
     LK_STAMP(0, LK_NOW());
     float2 pp;
-    if (chain_in) {
-        // chained launch: this slot's input is the record the previous frame's launch wrote for it -- the point it
-        // tracked to, if it survived (status 1).  That launch may still be running (it sits on the other tracker
-        // stream): one lane waits for this slot's record, so every slot follows its OWN predecessor and a frame's
-        // slowest feature no longer holds up the other slots of the next frame.  Slots that were lost earlier stay
-        // lost (status 2) and are skipped by the host, which is exactly the status filter of FrameSourceWarp.cpp:261-268.
-#ifdef VSTAB_LK_PLAIN_CHAIN
-        const uint4 r = chain_in[f];
-#else
-        __shared__ uint4 parent;
-        if (tid == 0) {
-            uint4 r = make_uint4(0, 0, 0, 3u);
-            if (!await_device_record(chain_in + f, parent_seq, r)) r.w = 3u;  // time-out: reported as status 3
-            parent = r;
-        }
-        __syncthreads();
-        const uint4 r = parent;
-#endif
-        if (record_status(r) != 1u) {  // uniform for the workgroup
+    if (args.chain_in) {
+        // chained launch: this slot's input is the record the parent launch wrote for it in its LAST frame pair -- the point it
+        // tracked to, if it survived (status 1).  Slots that were lost earlier stay lost (status 2) and are skipped by the
+        // host, which is exactly the status filter of FrameSourceWarp.cpp:261-268.
+        const uint4 r = args.chain_in[f];
+        const bool tagged = r.y == args.parent_seq && (r.w >> 2) == (args.parent_seq & 0x3fffffffu);
+        if (!tagged || record_status(r) != 1u) {  // uniform for the workgroup
             if (tid == 0) {
-                const uint4 dead = make_record(0.0f, 0.0f, record_status(r) == 3u ? 3u : 2u, seq);
-                if (dev_rec) publish_device_record(dev_rec + f, dead);
-                if (host_rec) host_rec[f] = dead;
+                for (int i = 0; i < args.n_frames; i++) {
+                    const uint4 dead = make_record(0.0f, 0.0f, tagged && record_status(r) != 3u ? 2u : 3u, args.seq[i]);
+                    if (args.dev_rec[i]) args.dev_rec[i][f] = dead;
+                    if (args.host_rec[i]) args.host_rec[i][f] = dead;
+                }
             }
             return;
         }
         pp = make_float2(__uint_as_float(r.x), __uint_as_float(r.z));
     } else {
-        pp = prev_pts[f];
+        pp = args.prev_pts[f];
     }
-    LK_STAMP(1, LK_NOW());
-    float2 np = make_float2(0.f, 0.f);
-    int st = 1, parity = 0;
+    int parity = 0;
     const float half = (LKW - 1) * 0.5f;
-    const int max_level = I.levels - 1;
     // this thread's window pixels: k = tid and tid + 256 (441 pixels in all)
     int woff[2];
 #pragma unroll
@@ -747,6 +792,15 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkPyramid I, LkPyram
         const int wy = k / LKW, wx = k - wy * LKW;
         woff[m] = k < LKW * LKW ? (wy << 8) | wx : -1;
     }
+#pragma unroll 1
+    for (int fi = 0; fi < args.n_frames; fi++) {
+    const LkPyramid &I = args.pyr[fi], &J = args.pyr[fi + 1];
+    seq = args.seq[fi];
+    if (fi) LK_STAMP(0, LK_NOW());
+    LK_STAMP(1, LK_NOW());
+    float2 np = make_float2(0.f, 0.f);
+    int st = 1;
+    const int max_level = I.levels - 1;
     // Everything whose address is known now is loaded now, in one exposed latency: the previous-image neighbourhood
     // of EVERY level (it depends on the feature position only) and the top level's next-image block.  The block of
     // each lower level is fetched one level ahead, while the level above computes, around the zero-flow position;
@@ -965,18 +1019,24 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkPyramid I, LkPyram
     }
     LK_STAMP(15, LK_NOW());
     if (tid == 0) {
-        if (host_rec) {
-            // one 16-byte record per feature in coherent host memory (make_record); the host polls the tags.  The device
-            // copy feeds a chained launch for the next frame.
-            const uint4 rec = make_record(np.x, np.y, (unsigned int)st, seq);
-            if (dev_rec) publish_device_record(dev_rec + f, rec);
-            host_rec[f] = rec;
-            if (clk) atomicMax(&clk[1], wall_clock64());
-        } else {
-            next_pts[f] = np;
-            status[f] = (uint8_t)st;
+        // one 16-byte record per feature and frame pair in coherent host memory (make_record); the host polls the tags.  The
+        // device copy of the LAST pair feeds the launch chained behind this one.
+        const uint4 rec = make_record(np.x, np.y, (unsigned int)st, seq);
+        if (args.dev_rec[fi]) args.dev_rec[fi][f] = rec;
+        if (args.host_rec[fi]) args.host_rec[fi][f] = rec;
+        if (!st) {  // lost here: the remaining pairs of the segment report "lost earlier"
+            for (int i = fi + 1; i < args.n_frames; i++) {
+                const uint4 dead = make_record(0.0f, 0.0f, 2u, args.seq[i]);
+                if (args.dev_rec[i]) args.dev_rec[i][f] = dead;
+                if (args.host_rec[i]) args.host_rec[i][f] = dead;
+            }
         }
+        if (clk) atomicMax(&clk[1], wall_clock64());
     }
+    if (!st) return;  // uniform
+    pp = np;          // FrameSourceWarp.cpp:427
+    __syncthreads();  // the last readers of this pair's LDS state are through before the next pair's staging overwrites it
+    }  // frame pairs of the segment
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -997,6 +1057,21 @@ vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, 
     const int nb_edge = div_up(dh * (n_groups - (g_hi - g_lo)), 256);
     hipLaunchKernelGGL(k_pyr_down, dim3(nb_edge + nb_int), dim3(256), 0, s, src, spitch, sw, sh, dst, dpitch, dw, dh, vec_ok, g_lo, g_hi, nbx, nb_edge, n_groups,
                        near);
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+// Two levels in one launch (k_pyr_down_x2): mid = pyrDown(src), dst = pyrDown(mid).  Needs an image a reflected tap never leaves
+// twice (>= 4 x 4 at the middle level); the caller falls back to two single-level launches otherwise.
+bool pyr_down_x2_ok(int sw, int sh) { return (sw + 1) / 2 >= 8 && (sh + 1) / 2 >= 8; }
+vstab_status launch_pyr_down_x2(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *mid, size_t mpitch, uint8_t *dst, size_t dpitch, hipStream_t s) {
+    const int mw = (sw + 1) / 2, mh = (sh + 1) / 2, dw = (mw + 1) / 2, dh = (mh + 1) / 2;
+    if (!pyr_down_x2_ok(sw, sh)) return fail(VSTAB_ERR_INVALID, "pyr_down_x2: image too small");
+    if ((uint64_t)spitch * (uint64_t)sh >= (1ull << 32) || (uint64_t)mpitch * (uint64_t)mh >= (1ull << 32) || (uint64_t)dpitch * (uint64_t)dh >= (1ull << 32))
+        return fail(VSTAB_ERR_INVALID, "pyr_down_x2: planes of 4 GiB or more are not supported");
+    const int vec_ok = reinterpret_cast<uintptr_t>(src) % 4 == 0 && spitch % 4 == 0 && reinterpret_cast<uintptr_t>(mid) % 4 == 0 && mpitch % 4 == 0;
+    hipLaunchKernelGGL(k_pyr_down_x2, dim3(div_up(dw, P2_TW), div_up(dh, P2_TH)), dim3(256), 0, s, src, (uint32_t)spitch, sw, sh, mid, (uint32_t)mpitch, mw, mh, dst,
+                       (uint32_t)dpitch, dw, dh, vec_ok);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }
@@ -1045,14 +1120,11 @@ vstab_status launch_corners_fused(const uint8_t *src, size_t pitch, int w, int h
     return VSTAB_OK;
 }
 
-vstab_status launch_lk(const LkPyramid &I, const LkPyramid &J, const float2 *prev_pts, int n, float2 *next_pts,
-                       uint8_t *status, void *host_records, unsigned int seq, hipStream_t s, const void *chain_in,
-                       unsigned int parent_seq, void *dev_records, void *clock_pair) {
-    if (n <= 0) return VSTAB_OK;
-    if (!prev_pts && !chain_in) return fail(VSTAB_ERR_INVALID, "launch_lk: no input points");
-    hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(LK_THREADS), 0, s, I, J, prev_pts, n, next_pts, status, static_cast<uint4 *>(host_records), seq,
-                       static_cast<const uint4 *>(chain_in), parent_seq, static_cast<uint4 *>(dev_records),
-                       static_cast<unsigned long long *>(clock_pair));
+vstab_status launch_lk(const LkSegArgs &a, hipStream_t s) {
+    if (a.n <= 0 || a.n_frames <= 0) return VSTAB_OK;
+    if (a.n_frames > LK_SEG_MAX) return fail(VSTAB_ERR_INVALID, "launch_lk: too many frame pairs in one launch");
+    if (!a.prev_pts && !a.chain_in) return fail(VSTAB_ERR_INVALID, "launch_lk: no input points");
+    hipLaunchKernelGGL(k_lk_track, dim3(a.n), dim3(LK_THREADS), 0, s, a);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }

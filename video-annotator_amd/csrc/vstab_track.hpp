@@ -29,20 +29,35 @@ inline int lk_levels(int w, int h) {
 }
 
 vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *dst, size_t dpitch, hipStream_t s);
+// two levels in one launch: mid = pyrDown(src) ((sw+1)/2 x (sh+1)/2), dst = pyrDown(mid); only where pyr_down_x2_ok(sw, sh)
+bool pyr_down_x2_ok(int sw, int sh);
+vstab_status launch_pyr_down_x2(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *mid, size_t mpitch, uint8_t *dst, size_t dpitch, hipStream_t s);
 vstab_status launch_min_eig(const uint8_t *src, size_t pitch, int w, int h, float *eig, int *max_bits, hipStream_t s);
 vstab_status launch_corner_candidates(const float *eig, int w, int h, const int *max_bits, double quality,
                                       unsigned long long *keys, unsigned int *count, unsigned int cap, hipStream_t s);
 size_t corners_fused_scratch_bytes(int w, int h);
 vstab_status launch_corners_fused(const uint8_t *src, size_t pitch, int w, int h, double quality, void *scratch, unsigned long long *keys,
                                   unsigned int cap, unsigned int *small, hipStream_t s);
-// host_records (may be NULL): n 16-byte records {x, seq, y, seq << 2 | status} in mapped host memory, written instead
-// of next_pts / status so the host can poll for completion without a stream synchronisation
-// chain_in (may be NULL): the device records of the previous frame's launch, whose sequence number is parent_seq; slot f
-// WAITS for that launch's record f (the two launches may run side by side on different streams), then starts from the
-// point it holds (status 1) or reports status 2 ("lost earlier") without tracking; status 3 = the record never came.
-// dev_records (may be NULL): device copy of the records for the launch chained behind this one.
-vstab_status launch_lk(const LkPyramid &I, const LkPyramid &J, const float2 *prev_pts, int n, float2 *next_pts,
-                       uint8_t *status, void *host_records, unsigned int seq, hipStream_t s, const void *chain_in = nullptr,
-                       unsigned int parent_seq = 0, void *dev_records = nullptr, void *clock_pair = nullptr);
+// One tracker launch = a SEGMENT of up to LK_SEG_MAX consecutive frame pairs (k_lk_track): pair i is (pyr[i], pyr[i + 1]).
+//   prev_pts  the n start points of pair 0 (device-readable), or NULL when
+//   chain_in  the device records of the parent launch's last pair, whose sequence number is parent_seq: slot f starts from the
+//             point record f holds (status 1) or reports status 2 ("lost earlier") for every pair; a record with another tag
+//             is a bookkeeping error (status 3).  The parent must precede this launch on the same stream.
+//   host_rec[i] / dev_rec[i] (either may be NULL): where pair i's n 16-byte records {x, seq[i], y, seq[i] << 2 | status} go --
+//             mapped host memory the host polls / device memory for the launch chained behind this one
+//   clk       development aid (VSTAB_LK_CLOCK): first-workgroup start / last-workgroup end stamps
+constexpr int LK_SEG_MAX = 8;
+struct LkSegArgs {
+    LkPyramid pyr[LK_SEG_MAX + 1];
+    uint4 *host_rec[LK_SEG_MAX];
+    uint4 *dev_rec[LK_SEG_MAX];
+    unsigned int seq[LK_SEG_MAX];
+    int n_frames, n;
+    const float2 *prev_pts;
+    const uint4 *chain_in;
+    unsigned int parent_seq;
+    unsigned long long *clk;
+};
+vstab_status launch_lk(const LkSegArgs &args, hipStream_t s);
 
 }  // namespace vstab
