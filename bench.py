@@ -64,6 +64,11 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo only for rehearsing ranks on one GPU")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--rehearse-launcher", action="store_true",
+                    help="functional rehearsal of the multi-rank plumbing WITHOUT any GPU work (gloo on the CPU): start the ranks, rendezvous, pin "
+                         "every rank to its own CPUs, barriers, the MAX all-reduce, the all-gather of the per-clip records, the concat list. "
+                         "The line carries value null: nothing is measured.  (A GPU box admits six processes on its card, so N = 8 can only be "
+                         "rehearsed like this; the real 1 -> 8 curve is the driver's.)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: initialise torch.distributed and run the collectives even with one rank (exercises the RCCL path on one GPU)")
     ap.add_argument("--ingest", default="inplace", choices=["inplace", "copy"],
@@ -249,40 +254,99 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def pin_rank(local, world, torch):
-    """Keep this rank's threads (the library's helper threads inherit the mask) on the CPUs of its GPU's NUMA node; without
-    that information, on an equal share of the allowed CPUs.  Returns a short description for the JSON line."""
-    allowed = sorted(os.sched_getaffinity(0))
+def _numa_cpus(torch, dev_index):
+    """CPUs of the NUMA node the GPU hangs off (sysfs), or None."""
     try:
-        bdf = torch.cuda.get_device_properties(local).pci_bus_id if hasattr(torch.cuda.get_device_properties(local), "pci_bus_id") else None
+        pr = torch.cuda.get_device_properties(dev_index)
+        path = f"/sys/bus/pci/devices/{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{getattr(pr, 'pci_device_id', 0):02x}.0/numa_node"
+        node = int(open(path).read())
+        if node < 0:
+            return None, None
+        ids = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            ids.update(range(int(a), int(b or a) + 1))
+        return node, sorted(ids)
     except Exception:
-        bdf = None
-    cpus, how = None, None
-    if bdf is not None:
-        try:
-            dom = getattr(torch.cuda.get_device_properties(local), "pci_domain_id", 0)
-            dev_id = getattr(torch.cuda.get_device_properties(local), "pci_device_id", 0)
-            path = f"/sys/bus/pci/devices/{dom:04x}:{bdf:02x}:{dev_id:02x}.0/numa_node"
-            node = int(open(path).read())
-            if node >= 0:
-                spec = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
-                ids = set()
-                for part in spec.split(","):
-                    a, _, b = part.partition("-")
-                    ids.update(range(int(a), int(b or a) + 1))
-                cpus, how = sorted(ids & set(allowed)), f"numa node {node}"
-        except Exception:
-            cpus = None
-    if not cpus and world > 1:
-        share = max(1, len(allowed) // world)
-        cpus, how = allowed[local * share:(local + 1) * share] or allowed, "equal share of the allowed CPUs"
-    if cpus and world > 1:
-        try:
-            os.sched_setaffinity(0, cpus)
-            return f"{len(cpus)} CPUs ({how})"
-        except OSError:
-            pass
-    return f"{len(allowed)} CPUs (unpinned)"
+        return None, None
+
+
+PIN_CPUS = 8  # one handle runs four busy threads (caller, estimate worker, corner-selection helper, runtime): a CCX-sized set keeps them on one L3
+
+
+def pin_rank(local, rank, world, share_gpu, torch):
+    """Keep this rank's threads (the library's helper threads inherit the mask) on a few CPUs of its GPU's NUMA node: the node's
+    CPUs are dealt in equal consecutive shares to the ranks whose GPU hangs off that node (so the ranks of a node never share a
+    core), and a rank takes the first PIN_CPUS of its share.  Without sysfs information: an equal share of the allowed CPUs.
+    Unpinned, the 1080p rate on a two-socket host was bimodal (31 k / 36 k / 39 k frames/s: profiles/r04_cpu_pinning_1080p.txt).
+    Returns (description, previous mask)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    if os.environ.get("VSTAB_BENCH_PIN", "1") == "0":
+        return f"{len(allowed)} CPUs (unpinned)", allowed
+    node, cpus = _numa_cpus(torch, local)
+    if cpus:
+        cpus = [c for c in cpus if c in set(allowed)]
+    if cpus:
+        if share_gpu:     # rehearsal: every rank on one card -> the node's CPUs in `world` disjoint shares
+            peers, k = world, rank
+        elif world == 1:  # one GPU visible: a node of an 8-GPU box serves 8 / (number of NUMA nodes) GPUs; take the first share
+            nodes = max(1, len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()]))
+            peers, k = max(1, GPUS_PER_NODE // nodes), 0
+        else:             # the local ranks whose GPU hangs off the same node share it
+            same = [r for r in range(world) if _numa_cpus(torch, r)[0] == node]
+            peers, k = max(1, len(same)), same.index(local) if local in same else 0
+        share = max(1, len(cpus) // peers)
+        cpus, how = cpus[k * share:(k + 1) * share][:PIN_CPUS] or cpus[:PIN_CPUS], f"numa node {node}, share {k + 1} of {peers}"
+    else:
+        share = max(1, len(allowed) // max(1, world))
+        cpus, how = (allowed[rank * share:(rank + 1) * share] or allowed)[:PIN_CPUS], "equal share of the allowed CPUs"
+    try:
+        os.sched_setaffinity(0, cpus)
+        return f"CPUs {cpus[0]}-{cpus[-1]} ({len(cpus)}; {how})", allowed
+    except OSError:
+        return f"{len(allowed)} CPUs (unpinned)", allowed
+
+
+def rehearse_launcher(args, rank, local, world, torch, dist):
+    """--rehearse-launcher: everything around the GPU work of an N-rank run, on the CPU over gloo (see parse())."""
+    class _NoCuda:  # pin_rank asks torch.cuda for the GPU's PCI address; there is none here -> equal shares of the allowed CPUs
+        class cuda:
+            @staticmethod
+            def get_device_properties(i):
+                raise RuntimeError("no GPU in a launcher rehearsal")
+    pinned, _ = pin_rank(local, rank, world, True, _NoCuda)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    dist.init_process_group("gloo")
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (1 + rank % 3))  # stands in for the timed region; ranks finish at different times
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    shard = importlib.import_module("video-annotator_amd.shard")
+    mine = sorted(os.sched_getaffinity(0))
+    n_frames = args.steps * args.batch
+    rec = dict(rank=rank, clip=rank, frames=n_frames, elapsed_ns=int(float(t.item()) * 1e9), crc=shard.crc_of(np.full(16, rank, np.uint8)), cpu_first=mine[0],
+               cpu_last=mine[-1], cpu_count=len(mine))
+    records = shard.gather_records([rec], device=torch.device("cpu"))
+    if rank == 0:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        listing = shard.concat_list([f"clip_{r['clip']:02d}_stabilised.mp4" for r in records])
+        with open(os.path.join(ROOT, "gpurun_out", f"concat_list_{world}gpu_rehearsal.txt"), "w") as fh:
+            fh.write(listing)
+        print(json.dumps({"metric": "stabilized frames/sec at 4K NV12, 1/2/4/8 GPU; remap % HBM roofline", "value": None, "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak (unmeasured: launcher rehearsal)",
+                          "rehearsal": "launcher only: ranks, rendezvous, CPU pinning, barriers, MAX all-reduce, record all-gather and concat list ran over gloo on "
+                                       "the CPU; no GPU work was done and nothing was measured",
+                          "config": {"workload": "none (launcher rehearsal)", "clips": len(records), "parallelism": f"clip-per-gpu x{world}"},
+                          "records": len(records), "frames_per_clip": sorted({r["frames"] for r in records}), "concat_list_lines": listing.count("\n"),
+                          "rank_cpus": pinned, "rank_cpus_all": [f"{r['cpu_first']}-{r['cpu_last']} ({r['cpu_count']})" for r in records],
+                          "collectives": "gloo"}), flush=True)
+    dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -300,6 +364,8 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report {world} rank(s) as {args.gpus} GPUs", file=sys.stderr)
         return 2
+    if args.rehearse_launcher:
+        return rehearse_launcher(args, rank, local, world, torch, dist)
     if not args.share_gpu and local >= torch.cuda.device_count():
         print(f"bench.py: --gpus {args.gpus}: rank {rank} has no GPU (LOCAL_RANK {local}, {torch.cuda.device_count()} visible; "
               "use --share-gpu --dist-backend gloo to rehearse ranks on one GPU)", file=sys.stderr)
@@ -310,7 +376,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    pinned = pin_rank(local, world, torch)
+    pinned, cpu_mask = pin_rank(local, rank, world, args.share_gpu, torch)
     vs = importlib.import_module("video-annotator_amd")  # raises if libvstab.so is missing: no fallback
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where collective payloads live
     use_dist = world > 1 or args.force_dist
@@ -513,7 +579,9 @@ def main():
     last = outs[(n_warm + n_timed - 1) % args.ring]
     if nv12_out or p010_out:
         last = last[0]
-    rec = dict(rank=rank, clip=rank, frames=n_timed, elapsed_ns=int(el * 1e9), crc=shard.crc_of(last[:64].cpu().numpy()))
+    mine = sorted(os.sched_getaffinity(0))
+    rec = dict(rank=rank, clip=rank, frames=n_timed, elapsed_ns=int(el * 1e9), crc=shard.crc_of(last[:64].cpu().numpy()), cpu_first=mine[0], cpu_last=mine[-1],
+               cpu_count=len(mine))
     records = shard.gather_records([rec], device=cdev)
     if rank == 0 and world > 1:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -639,6 +707,7 @@ def main():
             "config": {"workload": workload, "mode": mode, "clips": len(records), "ring_frames": args.ring, "frames_per_step": args.batch,
                        "frame_loop": ("vstab_pull_frames: one call per step" if batched else "vstab_pull_frame per frame from Python") if mode == "pipeline" else None,
                        "preset": "GOPRO_H4B_WIDE169_MEASURED", "parallelism": f"clip-per-gpu x{world}"},
+            "rank_cpus_all": [f"{r.get('cpu_first', 0)}-{r.get('cpu_last', 0)} ({r.get('cpu_count', 0)})" for r in records] if world > 1 else None,
             "preroll": preroll, "parity_check": parity, "parity_check_against": parity_against if parity else None, "rank_cpus": pinned,
             "collectives": args.dist_backend if use_dist else None,
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1) if achieved else None,
@@ -661,6 +730,10 @@ def main():
         if stages:
             line["stages"] = stages  # every GPU stage timed (extra pass outside the timed region; chained LK launches off)
             line["stages_timed_region"] = timed_stages  # host waits + warp launches as they were in the timed region
+        try:
+            os.sched_setaffinity(0, cpu_mask)  # the CPU legs run on this GPU's share of the host, not on the few CPUs the handle's threads were kept on
+        except OSError:
+            pass
         if world == 1 and not args.no_cpu_baseline and p010:
             line["cpu_baseline"] = cpu_baseline_p010(clip[0].cpu().numpy().view(np.uint16), w, h, K, Ko, cw, ch)
         elif world == 1 and not args.no_cpu_baseline:

@@ -12,6 +12,13 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # tools/run_sanitized_tests.sh: the same tests over the sanitizer build of the library (host side under ASan + UBSan).  The
+    # package itself only ever loads lib/libvstab.so; another build has to be asked for by path, here, explicitly.
+    alt = os.environ.get("VSTAB_TEST_LIB")
+    if alt:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import devlib
+        sys.modules["video-annotator_amd"] = devlib.load(alt)
 
 
 @pytest.fixture(scope="session")

@@ -1111,6 +1111,33 @@ def test_bench_launches_its_own_ranks():
     assert line["roofline"]["kernel"] == "k_warp_fused" and line["value"] > 0
 
 
+def test_bench_four_ranks_share_one_gpu():
+    """The multi-rank path with as many ranks as one card admits: the GPU box's process guard allows six processes with the GPU
+    open, and this test process and torch.distributed.run's agent are two of them -- `bench.py --gpus 4 --share-gpu
+    --dist-backend gloo`: four pipelines side by side on one GPU, rendezvous, pinning to disjoint CPU sets, the gather of four
+    records, the 4-entry concat list, parity of rank 0's frame.  Functional only: four clips on one card say nothing about
+    scaling (N = 8 is rehearsed without GPUs in tests/test_shard_cpu.py; the real curve is the driver's)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--share-gpu", "--dist-backend", "gloo", "--workload", "1080p",
+                        "--steps", "2", "--warmup", "1", "--batch", "8", "--preroll", "40", "--ring", "8", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["config"]["clips"] == 4 and line["parity_check"] == "ok" and len(line["rank_cpus_all"]) == 4
+    sets = []
+    for txt in line["rank_cpus_all"]:
+        first, last = (int(v) for v in txt.split(" ")[0].split("-"))
+        sets.append(set(range(first, last + 1)))
+    assert all(not (a & b) for i, a in enumerate(sets) for b in sets[i + 1:]), line["rank_cpus_all"]
+    assert open(os.path.join(root, "gpurun_out", "concat_list_4gpu.txt")).read().count("file '") == 4
+
+
 @pytest.mark.gpu
 def test_bench_rccl_branch_runs_on_one_rank():
     """The `nccl` (= RCCL) branch of bench.py and shard.gather_records, executed for real: one rank on this GPU with

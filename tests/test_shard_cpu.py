@@ -100,3 +100,29 @@ def test_bench_refuses_world_size_mismatch():
     """Under torch.distributed.run WORLD_SIZE must equal --gpus."""
     r = _bench("--gpus", "4", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and "n_gpus" not in r.stdout
+
+
+def test_launcher_rehearsal_with_eight_ranks():
+    """The N = 8 plumbing, rehearsed without GPUs (a GPU box admits six processes on its card, so eight ranks cannot share one):
+    `bench.py --gpus 8 --rehearse-launcher` starts eight ranks itself (torch.distributed.run as a child process), they
+    rendezvous over gloo, pin themselves to pairwise disjoint CPU sets, run the barriers, the MAX all-reduce and the
+    all-gather of the per-clip records, and rank 0 writes the 8-entry concat list (concat.sh:248 / join.ts:51-53 is the
+    model).  A functional test: the line says that nothing was measured."""
+    import json
+    r = _bench("--gpus", "8", "--rehearse-launcher", "--steps", "2", "--batch", "8")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["records"] == 8 and line["concat_list_lines"] == 8 and line["config"]["clips"] == 8
+    assert line["value"] is None and "unmeasured" in line["scaling"] and "nothing was measured" in line["rehearsal"]
+    sets = []
+    for txt in line["rank_cpus_all"]:
+        first, last = (int(v) for v in txt.split(" ")[0].split("-"))
+        sets.append(set(range(first, last + 1)))
+    assert len(sets) == 8
+    if len(os.sched_getaffinity(0)) >= 8:                     # enough CPUs for eight shares: they do not overlap
+        assert all(not (a & b) for i, a in enumerate(sets) for b in sets[i + 1:]), line["rank_cpus_all"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    listing = open(os.path.join(root, "gpurun_out", "concat_list_8gpu_rehearsal.txt")).read().splitlines()
+    assert listing == [f"file 'clip_{i:02d}_stabilised.mp4'" for i in range(8)]

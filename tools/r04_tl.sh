@@ -1,0 +1,10 @@
+#!/bin/bash
+# tracker timeline of the development build (in the pipeline), plus three short bench lines per workload
+set -o pipefail
+mkdir -p gpurun_out
+timeout -k 10 200 python tools/lk_timeline.py 2>&1 | grep -v "^  launch\|amdgpu.ids" | tee gpurun_out/r04_lk_timeline_latest.txt
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['stages_timed_region']; print(d['value'], d['parity_check'], 'warp', d['roofline']['avg_launch_us'], 'wait', s['host_track_wait_us_per_frame'])"; }
+for wl in 1080p 4k; do for rep in 1 2 3; do
+  v=$(timeout -k 10 200 python bench.py --workload $wl --steps ${STEPS:-60} --warmup 5 --no-cpu-baseline --skip-copy-pass 2>gpurun_out/r04_ab.err | line) || { tail -5 gpurun_out/r04_ab.err; exit 1; }
+  echo "$wl rep$rep: $v"
+done; done | tee gpurun_out/r04_bench_latest.txt

@@ -1,0 +1,18 @@
+#!/bin/bash
+# The CPU test suite (-m "not gpu") over the sanitizer build of libvstab.so: host code under AddressSanitizer + UBSan (make san).
+# CPU box only -- GPU sanitizers are not available on the pool and this script never runs there.  Writes profiles/r04_sanitizer_cpu_suite.txt.
+set -o pipefail
+cd "$(dirname "$0")/.."
+make -C video-annotator_amd san -j6 > /dev/null || exit 1
+RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+LOG=${1:-profiles/r04_sanitizer_cpu_suite.txt}
+{
+  echo "# CPU suite over tools/dev/libvstab_san.so (host objects: -fsanitize=address,undefined -fno-sanitize-recover=undefined; device code unsanitized)"
+  echo "# LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1"
+  echo "# (leak checking is off: CPython itself never frees its interned objects; every test that creates a library object destroys it)"
+  VSTAB_TEST_LIB=$PWD/tools/dev/libvstab_san.so LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+    python -m pytest tests -q -m "not gpu" -p no:cacheprovider 2>&1 | grep -v "^$"
+  echo "# exit status: ${PIPESTATUS[0]}"
+} | tee "$LOG"
+grep -q "ERROR: AddressSanitizer\|runtime error:" "$LOG" && { echo "sanitizer findings above"; exit 1; }
+grep -q "exit status: 0" "$LOG"

@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include "vstab_geometry.hpp"
+#include "vstab_hostlogic.hpp"
 #include "vstab_internal.hpp"
 #include "vstab_motion.hpp"
 #include "vstab_track.hpp"
@@ -388,27 +389,20 @@ class Tracker {
         const volatile uint32_t *rec = hrec_[L.buf[idx]].as<uint32_t>();
         const auto t0 = std::chrono::steady_clock::now();
         unsigned long spins = 0;
-        // a record = two 8-byte granules {x, seq} {y, seq << 2 | status}, each valid once its own tag matches (make_record)
-        const uint32_t tag1 = seq << 2;
-        auto ready = [&](int i) {
-            return __atomic_load_n(&rec[4 * i + 1], __ATOMIC_ACQUIRE) == seq && (__atomic_load_n(&rec[4 * i + 3], __ATOMIC_ACQUIRE) & ~3u) == tag1;
-        };
-        for (int i = 0; i < n; i++) {
-            while (!ready(i)) {
+        int next = 0;
+        for (;;) {  // (vstab_hostlogic.hpp: records are decoded as they arrive; a record is valid once both of its tags are)
+            const LkParse r = lk_parse_records(rec, next, n, seq, expect_n, next_xy, status, &next);
+            if (r == LK_PARSE_OK) break;
+            if (r == LK_PARSE_BAD_CHAIN) return fail(VSTAB_ERR_DEVICE, "LK chain: a slot's predecessor record does not carry its parent's tag");
+            if (r == LK_PARSE_COUNT_MISMATCH) return fail(VSTAB_ERR_DEVICE, "tracker bookkeeping mismatch");
+            while (!lk_record_ready(rec, next, seq)) {
                 __builtin_ia32_pause();
                 if ((++spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
                     VSTAB_HIP_TRY(hipStreamSynchronize(st));  // surfaces a launch / execution error if there is one
-                    if (!ready(i)) return fail(VSTAB_ERR_DEVICE, "LK kernel did not complete");
+                    if (!lk_record_ready(rec, next, seq)) return fail(VSTAB_ERR_DEVICE, "LK kernel did not complete");
                 }
             }
-            const uint32_t x = rec[4 * i], y = rec[4 * i + 2], s = rec[4 * i + 3] & 3u;
-            if (s == 3u) return fail(VSTAB_ERR_DEVICE, "LK chain: a slot's predecessor record does not carry its parent's tag");
-            if (s == 2u) continue;  // lost in an earlier frame of the chain: not part of this frame's point list
-            float fx, fy;
-            std::memcpy(&fx, &x, 4), std::memcpy(&fy, &y, 4);
-            next_xy.push_back(fx), next_xy.push_back(fy), status.push_back((uint8_t)s);
         }
-        if (status.size() != expect_n) return fail(VSTAB_ERR_DEVICE, "tracker bookkeeping mismatch");
         if (L.timed && gpu_ms) {
             float ms = 0;
             if (hipEventSynchronize(ev_b_) == hipSuccess && hipEventElapsedTime(&ms, ev_a_, ev_b_) == hipSuccess) *gpu_ms += ms;
@@ -611,7 +605,7 @@ struct vstab_handle {
             if (e) (void)hipEventDestroy(e);
         for (hipStream_t s : {dstream, pstream, tstream})
             if (s) (void)hipStreamDestroy(s);
-        for (auto &d : dmabufs) (void)hipDestroyExternalMemory(d.ext);
+        dmabufs.clear([](hipExternalMemory_t &e) { (void)hipDestroyExternalMemory(e); });
     }
     vstab_config cfg;
     vstab_source src;
@@ -811,16 +805,7 @@ struct vstab_handle {
     unsigned marker_set = 0;
     hipStream_t dstream = nullptr;  // speculative corner detection (137 us of kernels every 21st frame) beside everything else
     // DMA-BUF objects imported so far (vstab_frame.mem == VSTAB_MEM_DMABUF), keyed by the inode of the object
-    struct DmaBuf {
-        unsigned long long ino;
-        size_t size;
-        hipExternalMemory_t ext;
-        uint8_t *base;
-        long last_use;
-    };
-    std::vector<DmaBuf> dmabufs;
-    long dmabuf_clock = 0, dmabuf_imports = 0, dmabuf_evictions = 0;
-    int dmabuf_cache_cap = 256;  // VSTAB_DMABUF_CACHE=n (tests): a smaller cache, so that eviction is reached with a few objects
+    DmaBufCache<hipExternalMemory_t> dmabufs;  // vstab_hostlogic.hpp; VSTAB_DMABUF_CACHE=n (tests) shrinks its 256 entries
     bool chain_lk = true;        // VSTAB_CHAIN_LK=0: no launches ahead of the host's frame (one frame per launch, on demand)
     int seg_max = LK_SEG_MAX;    // VSTAB_LK_SEGMENT=n: frames per tracker launch at most (1 = a launch per frame, chained one frame ahead)
     int seg_target = 4;          // a chained segment is enqueued once this many frames are waiting (fewer only at a key frame or when the tracker would idle)
@@ -927,48 +912,40 @@ static vstab_status resolve_dmabuf(vstab_handle *H, vstab_frame &f) {
     }
     struct stat sb;
     if (fstat(f.dmabuf_fd, &sb) != 0) return fail(VSTAB_ERR_INVALID, "vstab_frame: dmabuf_fd is not an open file descriptor");
-    vstab_handle::DmaBuf *hit = nullptr;
-    for (auto &d : H->dmabufs)
-        if (d.ino == (unsigned long long)sb.st_ino && d.size == f.dmabuf_size) hit = &d;
-    if (!hit) {
-        if (H->dmabufs.size() >= (size_t)H->dmabuf_cache_cap) {  // a pool larger than any decoder's: drop the entry used longest ago
-            size_t old = 0;
-            for (size_t i = 1; i < H->dmabufs.size(); i++)
-                if (H->dmabufs[i].last_use < H->dmabufs[old].last_use) old = i;
-            // A frame stays in the pipeline for at most `slots` pulls (read-ahead + look-ahead window + warp): an object used
-            // more recently than that may still be read in place, so it is never unmapped -- the cache then grows past its cap.
-            if (H->dmabuf_clock - H->dmabufs[old].last_use > (long)H->slots.size() + 2) {
-                (void)hipStreamSynchronize(H->pstream);  // (rare: a copy out of the object may only just have been enqueued)
-                (void)hipDestroyExternalMemory(H->dmabufs[old].ext);
-                H->dmabufs.erase(H->dmabufs.begin() + (long)old);
-                H->dmabuf_evictions++;
-            }
-        }
-        // ROCm's import maps the object (the kernel driver takes its own reference on the DMA-BUF) and neither consumes nor
-        // closes the descriptor -- unlike CUDA's, which takes ownership.  So the caller's fd is handed over as it is: no
-        // duplicate to leak, and the caller may close its fd as soon as the callback returns
-        // (test_dmabuf_import_leaves_no_descriptor_behind checks both on the GPU box).
+    // ROCm's import maps the object (the kernel driver takes its own reference on the DMA-BUF) and neither consumes nor closes the
+    // descriptor -- unlike CUDA's, which takes ownership.  So the caller's fd is handed over as it is: no duplicate to leak, and the
+    // caller may close its fd as soon as the callback returns (test_dmabuf_import_leaves_no_descriptor_behind checks both).
+    std::string err;
+    auto import = [&](hipExternalMemory_t &ext, uint8_t *&base) {
         hipExternalMemoryHandleDesc hd;
         std::memset(&hd, 0, sizeof(hd));
         hd.type = hipExternalMemoryHandleTypeOpaqueFd, hd.handle.fd = f.dmabuf_fd, hd.size = f.dmabuf_size;
-        hipExternalMemory_t ext = nullptr;
         hipError_t e = hipImportExternalMemory(&ext, &hd);
-        if (e != hipSuccess) return fail(VSTAB_ERR_DEVICE, std::string("hipImportExternalMemory(DMA-BUF): ") + hipGetErrorString(e));
+        if (e != hipSuccess) {
+            err = std::string("hipImportExternalMemory(DMA-BUF): ") + hipGetErrorString(e);
+            return false;
+        }
         hipExternalMemoryBufferDesc bd;
         std::memset(&bd, 0, sizeof(bd));
         bd.offset = 0, bd.size = f.dmabuf_size;
-        void *base = nullptr;
-        e = hipExternalMemoryGetMappedBuffer(&base, ext, &bd);
-        if (e != hipSuccess || !base) {
+        void *p = nullptr;
+        e = hipExternalMemoryGetMappedBuffer(&p, ext, &bd);
+        if (e != hipSuccess || !p) {
             (void)hipDestroyExternalMemory(ext);
-            return fail(VSTAB_ERR_DEVICE, std::string("hipExternalMemoryGetMappedBuffer(DMA-BUF): ") + hipGetErrorString(e));
+            err = std::string("hipExternalMemoryGetMappedBuffer(DMA-BUF): ") + hipGetErrorString(e);
+            return false;
         }
-        H->dmabufs.push_back({(unsigned long long)sb.st_ino, f.dmabuf_size, ext, static_cast<uint8_t *>(base), 0});
-        hit = &H->dmabufs.back();
-        H->dmabuf_imports++;
-    }
-    hit->last_use = ++H->dmabuf_clock;
-    f.y = hit->base + off_y, f.uv = hit->base + off_uv, f.mem = VSTAB_MEM_DEVICE;
+        base = static_cast<uint8_t *>(p);
+        return true;
+    };
+    auto destroy = [&](hipExternalMemory_t &ext) {
+        (void)hipStreamSynchronize(H->pstream);  // (rare: a copy out of the object may only just have been enqueued)
+        (void)hipDestroyExternalMemory(ext);
+    };
+    // a frame stays in the pipeline for at most `slots` pulls (read-ahead + look-ahead window + warp)
+    uint8_t *base = nullptr;
+    if (!H->dmabufs.lookup((unsigned long long)sb.st_ino, f.dmabuf_size, (long)H->slots.size() + 2, import, destroy, base)) return fail(VSTAB_ERR_DEVICE, err);
+    f.y = base + off_y, f.uv = base + off_uv, f.mem = VSTAB_MEM_DEVICE;
     return VSTAB_OK;
 }
 
@@ -1417,7 +1394,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (const char *e = getenv("VSTAB_LK_SEGMENT")) H->seg_max = std::max(1, std::min(atoi(e), LK_SEG_MAX));
     H->seg_target = std::min(H->seg_target, H->seg_max);
     if (const char *e = getenv("VSTAB_MAP_CACHE")) H->map_cache = atoi(e) != 0;
-    if (const char *e = getenv("VSTAB_DMABUF_CACHE")) H->dmabuf_cache_cap = std::max(1, atoi(e));
+    if (const char *e = getenv("VSTAB_DMABUF_CACHE")) H->dmabufs.cap = std::max(1, atoi(e));
     H->stream = static_cast<hipStream_t>(cfg->stream);  // NULL = the default stream, as for the stateless operators
     {
         // the tracking chain is the per-frame critical path; the warp only has to finish before the
@@ -1715,7 +1692,7 @@ vstab_status vstab_enable_profiling(vstab_handle *h, int enable) {
 vstab_status vstab_get_profile(vstab_handle *h, vstab_profile *out) {
     if (!h || !out) return fail(VSTAB_ERR_INVALID, "vstab_get_profile: null argument");
     h->fold_pending();
-    h->prof.dmabuf_imports = h->dmabuf_imports, h->prof.dmabuf_evictions = h->dmabuf_evictions, h->prof.dmabuf_cached = (long)h->dmabufs.size();
+    h->prof.dmabuf_imports = h->dmabufs.imports, h->prof.dmabuf_evictions = h->dmabufs.evictions, h->prof.dmabuf_cached = (long)h->dmabufs.size();
     *out = h->prof;
     return VSTAB_OK;
 }
@@ -1934,4 +1911,61 @@ vstab_status vstab_rotation_filter_filter(const vstab_rotation_filter *f, double
 }
 void vstab_rotation_filter_destroy(vstab_rotation_filter *f) { delete f; }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Test hooks (vstabx_*: not part of the ABI of include/vstab.h, no device needed): the CPU suite -- and its sanitizer build -- drive
+// the host-side bookkeeping of vstab_hostlogic.hpp with hand-made buffers (tests/test_hostlogic_cpu.py).
+// ---------------------------------------------------------------------------------------------------------------------------------
+extern "C" {
+// Decode n hand-made tracker records as Tracker::track_wait does.  Returns the LkParse code; *n_out entries in xy / status; *next =
+// the first record that was not ready (or n).
+__attribute__((visibility("default"))) int vstabx_parse_records(const uint32_t *rec, int n, uint32_t seq, int expect_n, float *xy, unsigned char *status,
+                                                                 int *n_out, int *next) {
+    std::vector<float> pts;
+    std::vector<uint8_t> st;
+    int nx = 0;
+    const LkParse r = lk_parse_records(rec, 0, n, seq, (size_t)expect_n, pts, st, &nx);
+    for (size_t i = 0; i < st.size(); i++) xy[2 * i] = pts[2 * i], xy[2 * i + 1] = pts[2 * i + 1], status[i] = st[i];
+    *n_out = (int)st.size(), *next = nx;
+    return (int)r;
+}
+// Run a sequence of n lookups (object ids = inodes, all of one size unless sizes is given) through a DmaBufCache with fake import /
+// destroy functions.  counts = {imports, evictions, mapped now, destroys seen, largest number mapped at once}; bases[i] = the base the
+// i-th lookup returned (id * 4096 for the fake import: a stale mapping would show); fail_id: the import of this id fails (-1: none).
+__attribute__((visibility("default"))) int vstabx_dmabuf_cache_sim(const unsigned long long *ids, const size_t *sizes, int n, int cap, long window,
+                                                                    long long fail_id, long *counts, unsigned long long *bases) {
+    DmaBufCache<unsigned long long> cache;
+    cache.cap = cap;
+    long destroys = 0, peak = 0;
+    std::vector<unsigned long long> live;
+    int failures = 0;
+    for (int i = 0; i < n; i++) {
+        uint8_t *base = nullptr;
+        const unsigned long long id = ids[i];
+        const bool ok = cache.lookup(id, sizes ? sizes[i] : 4096, window,
+                                     [&](unsigned long long &h, uint8_t *&b) {
+                                         if ((long long)id == fail_id) return false;
+                                         h = id, b = reinterpret_cast<uint8_t *>(static_cast<uintptr_t>(id * 4096));
+                                         live.push_back(id);
+                                         return true;
+                                     },
+                                     [&](unsigned long long &h) {
+                                         destroys++;
+                                         for (size_t k = 0; k < live.size(); k++)
+                                             if (live[k] == h) {
+                                                 live.erase(live.begin() + (long)k);
+                                                 break;
+                                             }
+                                     },
+                                     base);
+        failures += !ok;
+        bases[i] = ok ? static_cast<unsigned long long>(reinterpret_cast<uintptr_t>(base)) : ~0ull;
+        peak = std::max<long>(peak, (long)cache.size());
+    }
+    counts[0] = cache.imports, counts[1] = cache.evictions, counts[2] = (long)cache.size(), counts[3] = destroys, counts[4] = peak;
+    cache.clear([&](unsigned long long &) { destroys++; });
+    counts[5] = destroys;
+    return failures;
+}
 }  // extern "C"

@@ -750,7 +750,9 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
     __shared__ float patch_sums[LK_MAX_LEVELS][4];         // exact sums of Ix Ix, Ix Iy, Iy Iy over the window, as float
     __shared__ __attribute__((aligned(16))) int regJ[2][LKJR * LKJR];
     __shared__ LkExchange ex;
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (wave as a scalar: what is indexed with it -- the pyramid level a wave prepares -- is then read with scalar loads from the
+    // kernel arguments instead of per-lane global loads, each of which was a memory latency inside the dependent chain)
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = args.n;
     if (f >= n) return;
     unsigned long long *const clk = args.clk;
@@ -855,6 +857,7 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
         __syncthreads();  // the staged neighbourhoods are visible
         if (mine) {
             const int w = I.w[l], h = I.h[l];
+#pragma unroll  // 8 trips whose LDS reads are all in flight before the first result is needed (one wave per SIMD: latency is all there is)
             for (int e = lane; e < LKT * LKT; e += 64) {
                 const int tyy = e / LKT, txx = e - tyy * LKT;
                 const int X = ipx + txx, Y = ipy + tyy;
@@ -871,6 +874,7 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
         __syncthreads();  // (a wave reads only what it wrote itself; the barrier keeps the four waves in step for the next one)
         if (mine) {
             int pA[3] = {0, 0, 0};  // per-lane partial sums: 7 * 4080^2 < 2^27
+#pragma unroll
             for (int k = lane; k < LKW * LKW; k += 64) {
                 const int wy = k / LKW, wx = k - wy * LKW;
                 const int *c = &rI[(wy + 1) * LKR + (wx + 1)];

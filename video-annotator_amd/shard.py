@@ -11,7 +11,7 @@ import zlib
 
 import numpy as np
 
-RECORD_FIELDS = ("rank", "clip", "frames", "elapsed_ns", "crc")
+RECORD_FIELDS = ("rank", "clip", "frames", "elapsed_ns", "crc", "cpu_first", "cpu_last", "cpu_count")  # the last three: the CPUs the rank ran on (0 if not given)
 
 
 def assign_clips(n_clips, world_size):
@@ -39,7 +39,7 @@ def gather_records(records, device=None):
     cap = int(max(int(c.item()) for c in counts))
     buf = torch.zeros((max(cap, 1), len(RECORD_FIELDS)), dtype=torch.int64, device=device)
     for i, r in enumerate(records):
-        buf[i] = torch.tensor([int(r[k]) for k in RECORD_FIELDS], dtype=torch.int64)
+        buf[i] = torch.tensor([int(r.get(k, 0)) for k in RECORD_FIELDS], dtype=torch.int64)
     out = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
     allrec = []
