@@ -959,7 +959,7 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
     if (wide && f.mem != 0) return fail(VSTAB_ERR_INVALID, "16-bit frames must be in device memory");
     if (H->cfg.pixel_depth == 10 && !wide) return fail(VSTAB_ERR_INVALID, "a pixel_depth 10 handle needs P010 device frames (vstab_frame.bit_depth > 8)");
     S.y16 = S.uv16 = nullptr;  // set again below when this frame has 16-bit planes to warp from
-    if (f.mem == 0 && !wide && f.hold >= H->borrow_hold) {
+    if (f.mem == 0 && !wide && f.hold >= H->borrow_hold && f.pitch_y < (1u << 24) && f.pitch_uv < (1u << 24)) {  // (the kernels form row offsets with 24-bit multiplies)
         // zero copy: track, build the pyramid from and warp upstream's planes where they are
         S.y = static_cast<const uint8_t *>(f.y), S.uv = static_cast<const uint8_t *>(f.uv), S.pitch_y = f.pitch_y, S.pitch_uv = f.pitch_uv;
         S.borrowed = true, S.warp_pending = false, S.warped = -1;

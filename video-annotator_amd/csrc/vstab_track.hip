@@ -613,20 +613,38 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 #define LK_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+// 2^-l as a float, exactly what (float)(1.0 / (double)(1 << l)) gives -- without a double-precision division in the kernel
+__device__ __forceinline__ float lk_level_scale(int l) { return __uint_as_float((uint32_t)(127 - l) << 23); }
+// 32-bit integer multiplies run at a quarter of the rate of the 24-bit ones, and every product here has operands well inside 24 bits
+// (pixels < 2^8, weights <= 2^14, Scharr derivatives and interpolated patch values < 2^15) and a result inside 32
+__device__ __forceinline__ int lk_mul(int a, int b) { return __mul24(a, b); }
+// a * b + c with a 24-bit multiply, spelled out: where b is a constant the compiler turns __mul24 back into a full 32-bit multiply
+// (it cannot see that the LDS values are small) and the Scharr taps became v_mul_lo_u32 / v_mad_u64_u32 pairs
+__device__ __forceinline__ int lk_mad(int a, int b, int c) {
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// e / 22 and k / 21 for the indices of the 22 x 22 tap block and the 21 x 21 window (< 600): one 24-bit multiply and a shift
+// instead of the 64-bit multiply-high the compiler emits for a division by a constant
+constexpr bool lk_div_magic_ok(int d, int magic) {
+    for (int e = 0; e < 600; e++)
+        if (((e * magic) >> 16) != e / d) return false;
+    return true;
+}
+static_assert(lk_div_magic_ok(22, 2979) && lk_div_magic_ok(21, 3121), "division constants");
+__device__ __forceinline__ int lk_div22(int e) { return __mul24(e, 2979) >> 16; }
+__device__ __forceinline__ int lk_div21(int k) { return __mul24(k, 3121) >> 16; }
 
-// k_lk_track: ONE WORKGROUP OF 4 WAVES PER FEATURE.  The tracker is latency bound (<= 200 features, a
-// dependent Gauss-Newton chain of up to 4 x 30 iterations), so the 441 window pixels are spread over
-// 256 lanes (<= 2 per lane) to shorten every iteration.  Integer partial sums are reduced per wave with
-// DPP, exchanged through a double-buffered LDS array (one barrier per iteration) and added in a fixed
-// order; integer addition is associative, so the totals -- and everything derived from them -- are
-// independent of the decomposition.  Each per-lane partial is split into a signed high part and a 16-bit
-// low part so that every partial sum stays inside int32; hi * 65536 + lo is exact in double and the one
-// double -> float conversion equals (float)(int64 total).
+// k_lk_track: ONE WORKGROUP OF 4 WAVES PER FEATURE.  The tracker is latency bound (<= 200 features, a dependent
+// Gauss-Newton chain of up to 4 x 30 iterations per frame pair): a wave alone on its SIMD issues a dependent instruction
+// only every ~8 cycles, so what counts is the NUMBER of instructions on the chain, not the arithmetic in them.  Four waves
+// stage the image blocks (one memory latency for all of them) and prepare the previous image's side of the four pyramid
+// levels, one level per wave; the iterations of a level run on one wave with seven window pixels per lane (see below).
+// Integer sums are exact whatever the decomposition: per-lane partials are split into a signed high part and a 16-bit low
+// part so that every wave sum stays inside int32; hi * 65536 + lo is exact in double and the one double -> float
+// conversion equals (float)(int64 total).
 constexpr int LK_THREADS = 256, LK_WAVES = 4;
-
-struct LkExchange {
-    int part[2][LK_WAVES][6];  // [parity][wave][hi/lo of up to three quantities]
-};
 
 // The 2 * NQ wave reductions advance in lockstep: every DPP step is applied to all of them before the next one, so the
 // two wait states a DPP read needs behind the write of its source are filled by the other chains instead of s_nop
@@ -646,49 +664,30 @@ __device__ __forceinline__ void wave_sums_i32(int (&t)[N]) {
     for (int i = 0; i < N; i++) t[i] = __builtin_amdgcn_readlane(t[i], 63);
 }
 
-template <int NQ>
-__device__ __forceinline__ void lk_block_sums(LkExchange &ex, int parity, int wave, int lane, const int (&v)[NQ], float (&out)[NQ]) {
-    int t[2 * NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) t[2 * q] = v[q] >> 16, t[2 * q + 1] = v[q] & 0xffff;
-    wave_sums_i32(t);  // uniform (SGPR) results
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 2 * NQ; i++) ex.part[parity][wave][i] = t[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        int hi = 0, lo = 0;
-#pragma unroll
-        for (int wv = 0; wv < LK_WAVES; wv++) hi += ex.part[parity][wv][2 * q], lo += ex.part[parity][wv][2 * q + 1];
-        out[q] = (float)__builtin_fma((double)hi, 65536.0, (double)lo);
-    }
-}
-
 // Staging in two phases -- every global load of a block is issued before the first LDS store waits for one -- so
 // a block costs ONE memory latency instead of one per loop trip.  The tracker is a dependent chain at one
 // workgroup per CU: exposed latency is what it is made of (measured: staging was half of a workgroup's time).
-template <int SIDE>
+template <int SIDE, int THREADS = LK_THREADS>
 struct LkStage {
     // SIDE x SIDE bytes as SIDE * SIDE / 4 dwords: a thread fetches FOUR consecutive pixels of a row with one (unaligned)
     // dword load and writes them to LDS as four ints with one 16-byte store -- a quarter of the loads, index arithmetic and LDS
     // stores of the byte-by-byte form it replaces (which is kept for blocks that touch the image border: REFLECT_101 per byte).
     static_assert(SIDE % 4 == 0, "rows are split into dwords");
-    static constexpr int ROWW = SIDE / 4, NW = SIDE * ROWW, N = (NW + LK_THREADS - 1) / LK_THREADS;
+    static constexpr int ROWW = SIDE / 4, NW = SIDE * ROWW, N = (NW + THREADS - 1) / THREADS;
     uint32_t v[N];
     __device__ __forceinline__ void load(const uint8_t *img, uint32_t pitch, int w, int h, int x0, int y0, int tid) {
         const bool interior = x0 >= 0 && y0 >= 0 && x0 + SIDE <= w && y0 + SIDE <= h;  // uniform
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            const int e = tid + LK_THREADS * k;
+            const int e = tid + THREADS * k;
             v[k] = 0;
             if (e < NW) {
                 const int ry = e / ROWW, rx = 4 * (e - ry * ROWW);
                 if (interior) {
-                    __builtin_memcpy(&v[k], img + (uint32_t)(y0 + ry) * pitch + (uint32_t)(x0 + rx), 4);  // one global_load_dword (any alignment)
+                    // (row * pitch with the 24-bit multiplier: rows < 2^15, pitches < 2^24 -- launch_lk checks -- and planes < 4 GiB)
+                    __builtin_memcpy(&v[k], img + __umul24((uint32_t)(y0 + ry), pitch) + (uint32_t)(x0 + rx), 4);  // one global_load_dword (any alignment)
                 } else {
-                    const uint8_t *row = img + (uint32_t)reflect101(y0 + ry, h) * pitch;
+                    const uint8_t *row = img + __umul24((uint32_t)reflect101(y0 + ry, h), pitch);
                     v[k] = (uint32_t)row[reflect101(x0 + rx, w)] | ((uint32_t)row[reflect101(x0 + rx + 1, w)] << 8) |
                            ((uint32_t)row[reflect101(x0 + rx + 2, w)] << 16) | ((uint32_t)row[reflect101(x0 + rx + 3, w)] << 24);
                 }
@@ -698,7 +697,7 @@ struct LkStage {
     __device__ __forceinline__ void store(int *dst, int tid) const {  // dst 16-byte aligned
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            const int e = tid + LK_THREADS * k;
+            const int e = tid + THREADS * k;
             if (e < NW) *reinterpret_cast<int4 *>(dst + 4 * e) = make_int4((int)(v[k] & 255u), (int)((v[k] >> 8) & 255u), (int)((v[k] >> 16) & 255u), (int)(v[k] >> 24));
         }
     }
@@ -749,7 +748,6 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
     __shared__ short patch[LK_MAX_LEVELS][3][LKW * LKW];   // the interpolated window of every level: I, Ix, Iy
     __shared__ float patch_sums[LK_MAX_LEVELS][4];         // exact sums of Ix Ix, Ix Iy, Iy Iy over the window, as float
     __shared__ __attribute__((aligned(16))) int regJ[2][LKJR * LKJR];
-    __shared__ LkExchange ex;
     // (wave as a scalar: what is indexed with it -- the pyramid level a wave prepares -- is then read with scalar loads from the
     // kernel arguments instead of per-lane global loads, each of which was a memory latency inside the dependent chain)
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -784,16 +782,23 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
     } else {
         pp = args.prev_pts[f];
     }
-    int parity = 0;
     const float half = (LKW - 1) * 0.5f;
-    // this thread's window pixels: k = tid and tid + 256 (441 pixels in all)
-    int woff[2];
+    // The Gauss-Newton iterations of a level run on ONE wave (wave 0), seven window pixels per lane: k = lane + 64 m (441 pixels;
+    // the last 7 lanes have six).  With the window spread over four waves (two pixels per lane) an iteration was ~300 instructions of
+    // splitting, reducing, exchanging through LDS and a barrier around eight tap reads -- and a wave alone on its SIMD issues a
+    // dependent instruction every ~8 cycles whatever it does (the measured 0.8 - 1.1 us per iteration).  Seven independent pixels per
+    // lane pipeline at the issue rate, one DPP reduction gives the total, nothing is exchanged and nobody waits at a barrier; the
+    // other three waves stage the next level's block and sleep at the level's barrier.  The sums are exact integers either way.
+    constexpr int LK_PPL = (LKW * LKW + 63) / 64;  // 7
+    int koff[LK_PPL];  // offset of window pixel k inside a staged next-image block (a pixel the lane does not have: 0, with a zero patch)
 #pragma unroll
-    for (int m = 0; m < 2; m++) {
-        const int k = tid + LK_THREADS * m;
-        const int wy = k / LKW, wx = k - wy * LKW;
-        woff[m] = k < LKW * LKW ? (wy << 8) | wx : -1;
+    for (int m = 0; m < LK_PPL; m++) {
+        const int k = lane + 64 * m;
+        const int wy = lk_div21(k), wx = k - lk_mul(wy, LKW);
+        koff[m] = k < LKW * LKW ? lk_mul(wy, LKJR) + wx : 0;
     }
+    __shared__ float s_result[4];  // wave 0 -> all: the point the frame pair ended on and its status
+    __shared__ float s_est[2][2];  // wave 0 -> all, by level parity: where the feature stands in the next image after that level
 #pragma unroll 1
     for (int fi = 0; fi < args.n_frames; fi++) {
     const LkPyramid &I = args.pyr[fi], &J = args.pyr[fi + 1];
@@ -818,7 +823,7 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
         for (int l = 0; l < LK_MAX_LEVELS; l++) {
             iok[l] = false;
             if (l > max_level) continue;
-            const float lscale = (float)(1.0 / (double)(1 << l));
+            const float lscale = lk_level_scale(l);
             const int ipx = (int)floorf(pp.x * lscale - half), ipy = (int)floorf(pp.y * lscale - half);
             if (ipx < -LKW || ipx >= I.w[l] || ipy < -LKW || ipy >= I.h[l]) continue;  // the level loop skips it too
             iok[l] = true;
@@ -834,88 +839,134 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
         if (jorg_x != INT_MIN / 2) sj.store(regJ[0], tid);
     }
     LK_STAMP(2, LK_NOW());
-    // ---- the previous image's side of EVERY level, one wave per level, before the level loop -------------------------------
-    // Derivatives, interpolated window (I, Ix, Iy) and the sums of the 2 x 2 matrix depend on the feature's position in the
-    // previous image only -- not on anything the Gauss-Newton iterations produce -- yet they used to run level by level inside
-    // the dependent chain (2.7 - 3.1 us each: 10.7 us of a 27.7 us median feature).  Now wave l does level l on its own: 8
-    // derivative taps and 7 window pixels per lane instead of 2 + 2 on all four waves, wave-local DPP sums, two barriers in
-    // all.  The sums are exact integers whatever the decomposition, so every float derived from them is unchanged.
-    {
-        static_assert(LK_MAX_LEVELS == LK_WAVES, "one wave per pyramid level");
-        const int l = wave;
-        const float ls = (float)(1.0 / (double)(1 << l));
+    // ---- the previous image's side of every level: derivatives, interpolated window (I, Ix, Iy), sums of the 2 x 2 matrix ---------
+    // They depend on the feature's position in the previous image only -- not on anything the Gauss-Newton iterations produce.
+    // The TOP level is needed first: all four waves prepare it together (two derivative taps and two window pixels per lane, the
+    // matrix sums joined through LDS), which takes a quarter of the time one wave needs for a level.  Then wave 0 starts iterating
+    // on it while waves 1 .. 3 prepare the lower levels, one level each, in its shadow (inside the level loop below) -- before,
+    // every level was prepared up front, one wave per level, and the top level's iterations waited for all of them (3.8 of a
+    // feature's ~19 us).  The sums are exact integers whatever the decomposition, so every float derived from them is unchanged.
+    struct LevelGeom {
+        int ipx, ipy, iw00, iw01, iw10, iw11;
+        bool ok;
+    };
+    auto level_geom = [&](int l) {
+        const float ls = lk_level_scale(l);
         float qx = pp.x * ls, qy = pp.y * ls;
         qx -= half, qy -= half;
-        const int ipx = (int)floorf(qx), ipy = (int)floorf(qy);
-        const bool mine = l <= max_level && !(ipx < -LKW || ipx >= I.w[l] || ipy < -LKW || ipy >= I.h[l]);  // the level loop skips it too
-        const float a = qx - (float)ipx, b = qy - (float)ipy;
-        const int iw00 = (int)rintf((1.f - a) * (1.f - b) * 16384.f);
-        const int iw01 = (int)rintf(a * (1.f - b) * 16384.f);
-        const int iw10 = (int)rintf((1.f - a) * b * 16384.f);
-        const int iw11 = 16384 - iw00 - iw01 - iw10;
+        LevelGeom g;
+        g.ipx = (int)floorf(qx), g.ipy = (int)floorf(qy);
+        g.ok = l >= 0 && l <= max_level && !(g.ipx < -LKW || g.ipx >= I.w[l] || g.ipy < -LKW || g.ipy >= I.h[l]);  // the level loop skips it too
+        const float a = qx - (float)g.ipx, b = qy - (float)g.ipy;
+        g.iw00 = (int)rintf((1.f - a) * (1.f - b) * 16384.f);
+        g.iw01 = (int)rintf(a * (1.f - b) * 16384.f);
+        g.iw10 = (int)rintf((1.f - a) * b * 16384.f);
+        g.iw11 = 16384 - g.iw00 - g.iw01 - g.iw10;
+        return g;
+    };
+    // Scharr derivative pairs of taps e = first, first + stride, ... of level l's 22 x 22 tap block (zero outside the image)
+    auto level_derivatives = [&](int l, const LevelGeom &g, int first, int stride) {
         const int *rI = regI[l];
+        const int w = I.w[l], h = I.h[l];
+        for (int e = first; e < LKT * LKT; e += stride) {
+            const int tyy = lk_div22(e), txx = e - lk_mul(tyy, LKT);
+            const int X = g.ipx + txx, Y = g.ipy + tyy;
+            int dx = 0, dy = 0;
+            if (X >= 0 && Y >= 0 && X < w && Y < h) {
+                const int *c = &rI[lk_mul(tyy + 1, LKR) + (txx + 1)];
+                const int t0m = lk_mad(c[-1], 10, lk_mad(c[-LKR - 1] + c[LKR - 1], 3, 0)), t0p = lk_mad(c[1], 10, lk_mad(c[-LKR + 1] + c[LKR + 1], 3, 0));
+                const int t1m = c[LKR - 1] - c[-LKR - 1], t1c = c[LKR] - c[-LKR], t1p = c[LKR + 1] - c[-LKR + 1];
+                dx = (short)(t0p - t0m), dy = (short)lk_mad(t1c, 10, lk_mad(t1p + t1m, 3, 0));
+            }
+            dpk[l][e] = ((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16);
+        }
+    };
+    // window pixels k = first, first + stride, ... of level l -> patch[l]; this lane's share of the matrix sums -> t (hi / lo parts)
+    auto level_window = [&](int l, const LevelGeom &g, int first, int stride, int (&t)[6]) {
+        const int *rI = regI[l];
+        int pA[3] = {0, 0, 0};  // per-lane partial sums: 7 * 4080^2 < 2^27
+        for (int k = first; k < LKW * LKW; k += stride) {
+            const int wy = lk_div21(k), wx = k - lk_mul(wy, LKW);
+            const int *c = &rI[lk_mul(wy + 1, LKR) + (wx + 1)];
+            const int ival = LK_DESCALE(lk_mul(c[0], g.iw00) + lk_mul(c[1], g.iw01) + lk_mul(c[LKR], g.iw10) + lk_mul(c[LKR + 1], g.iw11), 9);
+            const uint32_t *d = &dpk[l][lk_mul(wy, LKT) + wx];
+            const uint32_t d00 = d[0], d01 = d[1], d10 = d[LKT], d11 = d[LKT + 1];
+            const int ixval = LK_DESCALE(lk_mul((int)(short)(d00 & 0xffffu), g.iw00) + lk_mul((int)(short)(d01 & 0xffffu), g.iw01) +
+                                             lk_mul((int)(short)(d10 & 0xffffu), g.iw10) + lk_mul((int)(short)(d11 & 0xffffu), g.iw11), 14);
+            const int iyval = LK_DESCALE(lk_mul((int)d00 >> 16, g.iw00) + lk_mul((int)d01 >> 16, g.iw01) + lk_mul((int)d10 >> 16, g.iw10) +
+                                             lk_mul((int)d11 >> 16, g.iw11), 14);
+            patch[l][0][k] = (short)ival, patch[l][1][k] = (short)ixval, patch[l][2][k] = (short)iyval;
+            pA[0] += lk_mul(ixval, ixval), pA[1] += lk_mul(ixval, iyval), pA[2] += lk_mul(iyval, iyval);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) t[2 * q] = pA[q] >> 16, t[2 * q + 1] = pA[q] & 0xffff;
+        wave_sums_i32(t);  // uniform; hi * 65536 + lo is the exact total of this wave's pixels
+    };
+    __shared__ int s_top[LK_WAVES][6];  // the waves' shares of the top level's matrix sums
+    static_assert(LK_MAX_LEVELS <= LK_WAVES, "wave 0 iterates, waves 1 .. prepare one lower level each");
+    {
+        const LevelGeom gt = level_geom(max_level);
         __syncthreads();  // the staged neighbourhoods are visible
-        if (mine) {
-            const int w = I.w[l], h = I.h[l];
-#pragma unroll  // 8 trips whose LDS reads are all in flight before the first result is needed (one wave per SIMD: latency is all there is)
-            for (int e = lane; e < LKT * LKT; e += 64) {
-                const int tyy = e / LKT, txx = e - tyy * LKT;
-                const int X = ipx + txx, Y = ipy + tyy;
-                int dx = 0, dy = 0;
-                if (X >= 0 && Y >= 0 && X < w && Y < h) {
-                    const int *c = &rI[(tyy + 1) * LKR + (txx + 1)];
-                    const int t0m = (c[-LKR - 1] + c[LKR - 1]) * 3 + c[-1] * 10, t0p = (c[-LKR + 1] + c[LKR + 1]) * 3 + c[1] * 10;
-                    const int t1m = c[LKR - 1] - c[-LKR - 1], t1c = c[LKR] - c[-LKR], t1p = c[LKR + 1] - c[-LKR + 1];
-                    dx = (short)(t0p - t0m), dy = (short)((t1p + t1m) * 3 + t1c * 10);
-                }
-                dpk[l][e] = ((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16);
+        if (gt.ok) level_derivatives(max_level, gt, tid, LK_THREADS);
+        __syncthreads();  // the top level's derivative pairs are visible to every wave
+        int t[6] = {0, 0, 0, 0, 0, 0};
+        if (gt.ok) level_window(max_level, gt, tid, LK_THREADS, t);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) s_top[wave][i] = t[i];
+        }
+        __syncthreads();  // the top level's window and sums, the block staged for it: wave 0 can start iterating
+        if (tid == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                int hi = 0, lo = 0;
+#pragma unroll
+                for (int wv = 0; wv < LK_WAVES; wv++) hi += s_top[wv][2 * q], lo += s_top[wv][2 * q + 1];
+                patch_sums[max_level][q] = (float)__builtin_fma((double)hi, 65536.0, (double)lo);  // (read back by this wave only)
             }
         }
-        __syncthreads();  // (a wave reads only what it wrote itself; the barrier keeps the four waves in step for the next one)
-        if (mine) {
-            int pA[3] = {0, 0, 0};  // per-lane partial sums: 7 * 4080^2 < 2^27
-#pragma unroll
-            for (int k = lane; k < LKW * LKW; k += 64) {
-                const int wy = k / LKW, wx = k - wy * LKW;
-                const int *c = &rI[(wy + 1) * LKR + (wx + 1)];
-                const int ival = LK_DESCALE(c[0] * iw00 + c[1] * iw01 + c[LKR] * iw10 + c[LKR + 1] * iw11, 9);
-                const uint32_t *d = &dpk[l][wy * LKT + wx];
-                const uint32_t d00 = d[0], d01 = d[1], d10 = d[LKT], d11 = d[LKT + 1];
-                const int ixval = LK_DESCALE((int)(short)(d00 & 0xffffu) * iw00 + (int)(short)(d01 & 0xffffu) * iw01 + (int)(short)(d10 & 0xffffu) * iw10 +
-                                                 (int)(short)(d11 & 0xffffu) * iw11, 14);
-                const int iyval = LK_DESCALE(((int)d00 >> 16) * iw00 + ((int)d01 >> 16) * iw01 + ((int)d10 >> 16) * iw10 + ((int)d11 >> 16) * iw11, 14);
-                patch[l][0][k] = (short)ival, patch[l][1][k] = (short)ixval, patch[l][2][k] = (short)iyval;
-                pA[0] += ixval * ixval, pA[1] += ixval * iyval, pA[2] += iyval * iyval;
-            }
-            int t[6];
-#pragma unroll
-            for (int q = 0; q < 3; q++) t[2 * q] = pA[q] >> 16, t[2 * q + 1] = pA[q] & 0xffff;
-            wave_sums_i32(t);  // uniform; hi * 65536 + lo is the exact total
-            if (lane == 0) {
-#pragma unroll
-                for (int q = 0; q < 3; q++) patch_sums[l][q] = (float)__builtin_fma((double)t[2 * q], 65536.0, (double)t[2 * q + 1]);
-            }
-        }
-        // (published by the first barrier of the level loop)
     }
     for (int level = max_level; level >= 0; level--) {
         int n_iter = 0;
         const uint8_t *jmg = J.img[level];
         const int w = I.w[level], h = I.h[level];
         const uint32_t jpitch = (uint32_t)J.pitch[level];
-        const float lscale = (float)(1.0 / (double)(1 << level));
-        // fetch the next (finer) level's next-image block now; it lands while this level computes
+        const float lscale = lk_level_scale(level);
+        // the block staged for this level, wave 0's estimate after the level above and the level's window are visible (the top level:
+        // behind the barrier above)
+        if (level != max_level) __syncthreads();
+        // Fetch the next (finer) level's next-image block now (all four waves); it lands while this level iterates.  It is centred on
+        // where the feature is EXPECTED there -- the estimate this level starts from, doubled -- not on the zero-flow position: with
+        // the block around the previous frame's position a frame-to-frame motion of more than LKJM pixels at that level (the 4K bench
+        // clip moves 4 - 12) meant staging the block again inside the iteration loop, a global-memory latency on the dependent chain.
+        // Where a block sits never changes a value: it holds image bytes either way, and a window that leaves it is staged afresh.
         LkStage<LKJR> sn;
         int nx0 = INT_MIN / 2, ny0 = INT_MIN / 2;
         if (level > 0) {
-            const float ls1 = (float)(1.0 / (double)(1 << (level - 1)));
-            const int nipx = (int)floorf(pp.x * ls1 - half), nipy = (int)floorf(pp.y * ls1 - half);
-            if (!(nipx < -LKW || nipx >= I.w[level - 1] || nipy < -LKW || nipy >= I.h[level - 1])) {
-                nx0 = nipx - LKJM, ny0 = nipy - LKJM;
-                sn.load(J.img[level - 1], (uint32_t)J.pitch[level - 1], I.w[level - 1], I.h[level - 1], nx0, ny0, tid);
+            const int w1 = I.w[level - 1], h1 = I.h[level - 1];
+            const float ex = level == max_level ? pp.x * lscale : s_est[(level + 1) & 1][0] * 2.0f, ey = level == max_level ? pp.y * lscale : s_est[(level + 1) & 1][1] * 2.0f;
+            const float cx = ex * 2.0f - half, cy = ey * 2.0f - half;
+            if (cx > -(float)(LKW + 1) && cx < (float)w1 && cy > -(float)(LKW + 1) && cy < (float)h1) {  // (false for NaN: a diverged estimate is not chased)
+                nx0 = (int)floorf(cx) - LKJM, ny0 = (int)floorf(cy) - LKJM;
+                sn.load(J.img[level - 1], (uint32_t)J.pitch[level - 1], w1, h1, nx0, ny0, tid);
             }
         }
-        do {  // one pyramid level ("break" = the reference's "continue")
+        if (level == max_level && wave >= 1 && wave <= max_level) {
+            // in the shadow of the top level's iterations: wave w prepares level max_level - w on its own (a wave reads back only
+            // what it wrote itself: LDS operations of one wave execute in order); published by that level's barrier
+            const int l = max_level - wave;
+            const LevelGeom g = level_geom(l);
+            if (g.ok) {
+                level_derivatives(l, g, lane, 64);
+                int t[6];
+                level_window(l, g, lane, 64, t);
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) patch_sums[l][q] = (float)__builtin_fma((double)t[2 * q], 65536.0, (double)t[2 * q + 1]);
+                }
+            }
+        }
+        if (wave == 0) do {  // one pyramid level on one wave ("break" = the reference's "continue")
             float ppx = pp.x * lscale, ppy = pp.y * lscale;
             float npx, npy;
             if (level == max_level)
@@ -929,22 +980,16 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
                 if (level == 0) st = 0;
                 break;
             }
-            float a = ppx - (float)ipx, b = ppy - (float)ipy;
-            int iw00 = (int)rintf((1.f - a) * (1.f - b) * 16384.f);
-            int iw01 = (int)rintf(a * (1.f - b) * 16384.f);
-            int iw10 = (int)rintf((1.f - a) * b * 16384.f);
-            int iw11 = 16384 - iw00 - iw01 - iw10;
             int *rJ = regJ[jb];
             int jx0 = jorg_x, jy0 = jorg_y;  // origin of the next-image block staged for this level
-            __syncthreads();  // staged blocks and (first level) the patches of all levels are visible
-            short Iw[2], Ixw[2], Iyw[2];
+            int Iw[LK_PPL], Ixy[LK_PPL];     // this lane's pixels of the interpolated window: I, and Ix | Iy << 16
 #pragma unroll
-            for (int m = 0; m < 2; m++) {
-                Iw[m] = Ixw[m] = Iyw[m] = 0;
-                if (woff[m] >= 0) {
-                    const int k = tid + LK_THREADS * m;
-                    Iw[m] = patch[level][0][k], Ixw[m] = patch[level][1][k], Iyw[m] = patch[level][2][k];
-                }
+            for (int m = 0; m < LK_PPL; m++) {
+                const int k = lane + 64 * m;
+                const bool have = k < LKW * LKW;
+                const int kk = have ? k : 0;
+                Iw[m] = have ? (int)patch[level][0][kk] : 0;
+                Ixy[m] = have ? (int)(((uint32_t)(uint16_t)patch[level][1][kk]) | ((uint32_t)(uint16_t)patch[level][2][kk] << 16)) : 0;
             }
             const float sA[3] = {patch_sums[level][0], patch_sums[level][1], patch_sums[level][2]};
             const float FLT_SCALE = 1.0f / (1 << 20);
@@ -966,34 +1011,32 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
                     if (level == 0) st = 0;
                     break;
                 }
-                a = npx - (float)inx, b = npy - (float)iny;
-                iw00 = (int)rintf((1.f - a) * (1.f - b) * 16384.f);
-                iw01 = (int)rintf(a * (1.f - b) * 16384.f);
-                iw10 = (int)rintf((1.f - a) * b * 16384.f);
-                iw11 = 16384 - iw00 - iw01 - iw10;
+                const float a = npx - (float)inx, b = npy - (float)iny;
+                const int iw00 = (int)rintf((1.f - a) * (1.f - b) * 16384.f);
+                const int iw01 = (int)rintf(a * (1.f - b) * 16384.f);
+                const int iw10 = (int)rintf((1.f - a) * b * 16384.f);
+                const int iw11 = 16384 - iw00 - iw01 - iw10;
                 if (inx < jx0 || iny < jy0 || inx + LKT > jx0 + LKJR || iny + LKT > jy0 + LKJR) {
-                    // the window is outside the staged block: stage a block centred on the window; block-uniform branch
+                    // the window is outside the staged block: this wave stages a block centred on the window (wave-uniform branch;
+                    // LDS operations of one wave execute in order, and the other waves write the OTHER buffer)
                     jx0 = inx - LKJM, jy0 = iny - LKJM;
-                    LkStage<LKJR> sj;
-                    sj.load(jmg, jpitch, w, h, jx0, jy0, tid);
-                    __syncthreads();
-                    sj.store(rJ, tid);
-                    __syncthreads();
+                    LkStage<LKJR, 64> sj;
+                    sj.load(jmg, jpitch, w, h, jx0, jy0, lane);
+                    sj.store(rJ, lane);
                 }
-                const int jbase = (iny - jy0) * LKJR + (inx - jx0);
-                int pb[2] = {0, 0};  // per-lane partial sums: 2 * 16320 * 4080 < 2^28
+                const int jbase = lk_mul(iny - jy0, LKJR) + (inx - jx0);
+                int pb0 = 0, pb1 = 0;  // per-lane partial sums: 7 * 16320 * 4080 < 2^29
 #pragma unroll
-                for (int m = 0; m < 2; m++) {
-                    if (woff[m] >= 0) {
-                        const int *c = &rJ[jbase + (woff[m] >> 8) * LKJR + (woff[m] & 255)];
-                        const int diff = LK_DESCALE(c[0] * iw00 + c[1] * iw01 + c[LKJR] * iw10 + c[LKJR + 1] * iw11, 9) - Iw[m];
-                        pb[0] += diff * Ixw[m], pb[1] += diff * Iyw[m];
-                    }
+                for (int m = 0; m < LK_PPL; m++) {
+                    const int *c = &rJ[jbase + koff[m]];
+                    const int diff = LK_DESCALE(lk_mul(c[0], iw00) + lk_mul(c[1], iw01) + lk_mul(c[LKJR], iw10) + lk_mul(c[LKJR + 1], iw11), 9) - Iw[m];
+                    pb0 += lk_mul(diff, (int)(short)(Ixy[m] & 0xffff)), pb1 += lk_mul(diff, Ixy[m] >> 16);
                 }
-                float sb[2];
-                lk_block_sums<2>(ex, parity, wave, lane, pb, sb);
-                parity ^= 1;
-                const float b1 = sb[0] * FLT_SCALE, b2 = sb[1] * FLT_SCALE;
+                // exact totals: signed high part and 16-bit low part summed separately (each stays inside int32), joined in double
+                int t[4] = {pb0 >> 16, pb0 & 0xffff, pb1 >> 16, pb1 & 0xffff};
+                wave_sums_i32(t);  // uniform (SGPR) results
+                const float sb0 = (float)__builtin_fma((double)t[0], 65536.0, (double)t[1]), sb1 = (float)__builtin_fma((double)t[2], 65536.0, (double)t[3]);
+                const float b1 = sb0 * FLT_SCALE, b2 = sb1 * FLT_SCALE;
                 const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
                 npx += dx, npy += dy;
                 np = make_float2(npx + half, npy + half);
@@ -1012,8 +1055,9 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
                 if (fnx < -LKW || fnx >= w || fny < -LKW || fny >= h) st = 0;
             }
         } while (false);
-        // the block fetched for the next level goes into the other buffer (its last readers left at the barrier of
-        // the level before this one; the next level's first barrier publishes it)
+        if (tid == 0) s_est[level & 1][0] = np.x, s_est[level & 1][1] = np.y;  // (a skipped level leaves np at its start value, as the reference does)
+        // the block fetched for the next level goes into the other buffer: nobody reads that one now (wave 0 left it before this
+        // level's barrier), so waves 1 - 3 store at once and wave 0 when its iterations are over; the next barrier publishes it
         LK_STAMP(4 + 3 * (max_level - level), LK_NOW());
         LK_STAMP(5 + 3 * (max_level - level), (unsigned long long)n_iter);
         (void)n_iter;  // read by the development build's stamps only
@@ -1021,6 +1065,10 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
         jorg_x = nx0, jorg_y = ny0;
         if (nx0 != INT_MIN / 2) sn.store(regJ[jb], tid);
     }
+    // wave 0 holds the result: hand it to the other waves (the next frame pair starts from it; a lost slot ends here)
+    if (tid == 0) s_result[0] = np.x, s_result[1] = np.y, s_result[2] = __int_as_float(st);
+    __syncthreads();
+    np = make_float2(s_result[0], s_result[1]), st = __float_as_int(s_result[2]);
     LK_STAMP(15, LK_NOW());
     if (tid == 0) {
         // one 16-byte record per feature and frame pair in coherent host memory (make_record); the host polls the tags.  The
@@ -1128,6 +1176,10 @@ vstab_status launch_lk(const LkSegArgs &a, hipStream_t s) {
     if (a.n <= 0 || a.n_frames <= 0) return VSTAB_OK;
     if (a.n_frames > LK_SEG_MAX) return fail(VSTAB_ERR_INVALID, "launch_lk: too many frame pairs in one launch");
     if (!a.prev_pts && !a.chain_in) return fail(VSTAB_ERR_INVALID, "launch_lk: no input points");
+    for (int i = 0; i <= a.n_frames; i++)
+        for (int l = 0; l < a.pyr[i].levels; l++)
+            if (a.pyr[i].pitch[l] >= (1u << 24) || (uint64_t)a.pyr[i].pitch[l] * (uint64_t)a.pyr[i].h[l] >= (1ull << 32))
+                return fail(VSTAB_ERR_INVALID, "launch_lk: image pitch must be below 2^24 and planes below 4 GiB");
     hipLaunchKernelGGL(k_lk_track, dim3(a.n), dim3(LK_THREADS), 0, s, a);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
