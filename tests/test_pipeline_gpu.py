@@ -1044,12 +1044,15 @@ def test_bench_shaped_run_4k_config_3(vs, cuda):
     _bench_shaped_run(vs, cuda, 3840, 2160, 30, 52, 2)
 
 
-def _bench_shaped_run(vs, cuda, w, h, r, n, min_keys):
+def _bench_shaped_run(vs, cuda, w, h, r, n, min_keys, transform=None):
     import torch
     import bench
     K = oracle.get_preset_camera(4, w, h)
     Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
     dev_frames, _ = bench.shaky_ring(torch, cuda, w, h, K, n, seed=5)
+    if transform:
+        dev_frames = transform(dev_frames)
+        n = len(dev_frames)
     stab = vs.Stabilizer(dev_frames, total=n, smooth_radius=r, seed=77)
     outs = {}
     i = 0
@@ -1089,6 +1092,46 @@ def _bench_shaped_run(vs, cuda, w, h, r, n, min_keys):
         assert np.allclose(stab.warp_rotation(k), warp_rots[k], atol=1e-9), k
     for k, got in outs.items():
         assert np.array_equal(got, expect.warp(exp[k], oracle.map_params(K, Ko, stab.warp_rotation(k)), cw, ch)), k
+    return log
+
+
+def test_unplanned_key_frames_drop_the_tracker_launches_enqueued_ahead(vs, cuda, monkeypatch):
+    """The tracker runs ahead of the host in launches that cover several frames each, assuming that the only key frames are the
+    ones the counter predicts (:415, every 21st frame).  Here the clip fades to a low-contrast version of itself for a few
+    frames (1080p, 200 corners): half of the features fail the tracker's eigenvalue test there, so the COUNT half of the rule
+    (< 150 survivors) fires at frames nobody planned for -- what was enqueued ahead must be dropped, corners re-detected and
+    tracking restarted from them, with every decision, count, rotation and pixel equal to the oracle's state machine, which
+    knows nothing of launches.  Then the same clip with one frame per launch, with short segments, and with no launches
+    ahead at all: the same log."""
+    w, h = 1920, 1080
+
+    def fade(frames):
+        out = list(frames[:25])
+        for f in frames[25:31]:
+            g = f.clone()
+            g[:h] = (96 + torch_floor_div(g[:h].to(torch_int32()) - 96, 12)).to(g.dtype)
+            out.append(g)
+        return out + list(frames[31:52])
+
+    import torch
+
+    def torch_int32():
+        return torch.int32
+
+    def torch_floor_div(a, b):
+        return torch.div(a, b, rounding_mode="floor")
+    log = _bench_shaped_run(vs, cuda, w, h, 5, 64, 3, transform=fade)
+    keys = [i for i, l in enumerate(log) if l["key"]]
+    assert keys[0] == 20                                        # log index i is frame i + 1: the counter's key frame (frame 21)
+    assert sum(24 <= k <= 34 for k in keys) >= 2, keys          # and key frames nobody planned for: into the fade and out of it
+    ref = [(l["key"], l["n_corners"], l["n_tracked"], l["inliers"]) for l in log]
+    for env in ({"VSTAB_LK_SEGMENT": "1"}, {"VSTAB_CHAIN_LK": "0"}, {"VSTAB_LK_SEGMENT": "3", "VSTAB_LK_SEG_TARGET": "2"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        log2 = _bench_shaped_run(vs, cuda, w, h, 5, 64, 3, transform=fade)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert [(l["key"], l["n_corners"], l["n_tracked"], l["inliers"]) for l in log2] == ref, env
 
 
 @pytest.mark.gpu

@@ -75,10 +75,11 @@ struct PinnedBuf {  // host memory the device can read and write directly (mappe
 // ---------------------------------------------------------------------------------------------
 // Tracker: device workspace for goodFeaturesToTrack + calcOpticalFlowPyrLK
 // ---------------------------------------------------------------------------------------------
-constexpr int PYR_SETS = 10;       // previous + current (in flight) + the prefetched frames
+constexpr int PREFETCH_MAX = 16;             // upper bound of the read-ahead (the ring and the pyramid sets are sized for it)
+constexpr int PYR_SETS = PREFETCH_MAX + 2;  // previous + current (in flight) + the prefetched frames
 // frames pulled from upstream ahead of the one being tracked: deep enough that the speculative corner detection of a
 // key frame (137 us of kernels beside everything else + the host selection) is finished before its turn comes
-constexpr int PREFETCH_DEPTH = 8;
+constexpr int PREFETCH_DEPTH = 8;  // default; VSTAB_PREFETCH=n (1 .. PREFETCH_MAX) for experiments
 
 class Tracker {
   public:
@@ -808,6 +809,7 @@ struct vstab_handle {
     DmaBufCache<hipExternalMemory_t> dmabufs;  // vstab_hostlogic.hpp; VSTAB_DMABUF_CACHE=n (tests) shrinks its 256 entries
     bool chain_lk = true;        // VSTAB_CHAIN_LK=0: no launches ahead of the host's frame (one frame per launch, on demand)
     int seg_max = LK_SEG_MAX;    // VSTAB_LK_SEGMENT=n: frames per tracker launch at most (1 = a launch per frame, chained one frame ahead)
+    int prefetch_depth = PREFETCH_DEPTH;  // frames pulled from upstream ahead of the one being tracked
     int seg_target = 4;          // a chained segment is enqueued once this many frames are waiting (fewer only at a key frame or when the tracker would idle)
     long chained_adopted = 0, chained_discarded = 0, key_prelaunched = 0;
     // a frame that has been pulled from upstream, copied into the ring and whose pyramid is being built
@@ -1440,12 +1442,14 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (H->ow <= 0 || H->oh <= 0 || H->ow > 32767 || H->oh > 32767) return fail(VSTAB_ERR_INVALID, "vstab_create: output size out of range");
     if (cfg->smoother == VSTAB_SMOOTHER_SG) H->sg.reset(new RotationFilterSG(cfg->smooth_radius));
     // queue (r+1) + ready + in flight + first/last gray + 2 spare for stream overlap + the slots that wait for a shared warp event
-    H->slots.resize((size_t)cfg->smooth_radius + 5 + PREFETCH_DEPTH + vstab_handle::WARP_EVENT_STRIDE);
+    if (const char *e = getenv("VSTAB_PREFETCH")) H->prefetch_depth = std::max(1, std::min(atoi(e), PREFETCH_MAX));
+    if (const char *e = getenv("VSTAB_LK_SEG_TARGET")) H->seg_target = std::max(1, std::min(atoi(e), H->seg_max));
+    H->slots.resize((size_t)cfg->smooth_radius + 5 + H->prefetch_depth + vstab_handle::WARP_EVENT_STRIDE);
     for (auto &s : H->slots) {
         VSTAB_HIP_TRY(hipEventCreateWithFlags(&s.ingested, hipEventDisableTiming));
     }
     // a frame stays in the pipeline from its pull until its warp: read-ahead + look-ahead queue + the frames in between
-    H->borrow_hold = getenv("VSTAB_ALWAYS_COPY") ? (1 << 30) + 1 : cfg->smooth_radius + PREFETCH_DEPTH + 6;
+    H->borrow_hold = getenv("VSTAB_ALWAYS_COPY") ? (1 << 30) + 1 : cfg->smooth_radius + H->prefetch_depth + 6;
     if (cfg->tracking) VSTAB_TRY(H->tracker.init(H->w, H->h));
     *out = H.release();
     return VSTAB_OK;
@@ -1495,7 +1499,7 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
             if (H->queue.size() != queued) continue;  // (tracking off: the frame is queued at once) re-check :453 before :456
         }
         // 4. read ahead: pull + copy + pyramid of the following frames (prefetch stream)
-        while ((int)H->prefetched.size() < PREFETCH_DEPTH && !H->src_eof) {
+        while ((int)H->prefetched.size() < H->prefetch_depth && !H->src_eof) {
             const vstab_status st = prefetch_next(H);
             if (st != VSTAB_OK && st != VSTAB_EOF) return st;
         }
