@@ -93,6 +93,41 @@ __device__ __forceinline__ uint32_t blend_bgr10(uint32_t t00, uint32_t t01, uint
     }
     return out;
 }
+// ---- the LDS-tiled kernel's pixel for the fp16 blend: three binary16 values, B | G << 16 and R | 0 << 16 (8 bytes) ----------------
+// The taps of VSTAB_BLEND_FP16 enter the fused multiply-adds as binary16 numbers.  Converting them there costs twelve int -> half
+// conversions (and twelve field extracts) per OUTPUT pixel; staged as halves they are converted once per SOURCE pixel, and the
+// blend is eight packed fused multiply-adds (B and G together, R beside a zero lane).  0 .. 1023 are exact in binary16.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 pack_bgr10h(int yv, const ChromaTerm &c) {
+    const int t = __mul24(max(yv, 64), CY);
+    const int b = sat10(__builtin_elementwise_add_sat(t, c.buv) >> 20), g = sat10(__builtin_elementwise_add_sat(t, c.guv) >> 20),
+              r = sat10(__builtin_elementwise_add_sat(t, c.ruv) >> 20);
+    const half2v bg = {(_Float16)(unsigned short)b, (_Float16)(unsigned short)g}, r0 = {(_Float16)(unsigned short)r, (_Float16)0.0f};
+    return make_uint2(__builtin_bit_cast(uint32_t, bg), __builtin_bit_cast(uint32_t, r0));
+}
+// the definition's four fused multiply-adds per channel (taps 00, 01, 10, 11; weights w / 1024, exact in binary16), packed; then
+// round to nearest even and clamp: min(acc, 1023) + 1024 has ulp 1, so the adder does the rounding and the integer is the low ten
+// bits of the sum's pattern (0x6400 + n).  Returns B | G << 10 | R << 20 like blend_bgr10.
+__device__ __forceinline__ uint32_t blend_bgr10h(uint2 t00, uint2 t01, uint2 t10, uint2 t11, int fx, int fy) {
+    // the weights w / 1024 = (gx / 32) (gy / 32) etc.: the factors are multiples of 1/32 up to 1 and every product a multiple of 1/1024 up
+    // to 1 -- all exact in binary16 -- so two packed multiplies give the four weights the definition writes as (_Float16)w * 2^-10
+    const _Float16 k = (_Float16)(1.0f / 32.0f);
+    const _Float16 fxh = (_Float16)(short)fx * k, fyh = (_Float16)(short)fy * k;
+    const half2v wx = {(_Float16)1.0f - fxh, fxh};                                    // (gx, fx) / 32
+    const half2v wt = wx * (half2v){(_Float16)1.0f - fyh, (_Float16)1.0f - fyh};      // (w00, w01)
+    const half2v wb = wx * (half2v){fyh, fyh};                                        // (w10, w11)
+    const half2v w00 = {wt.x, wt.x}, w01 = {wt.y, wt.y}, w10 = {wb.x, wb.x}, w11 = {wb.y, wb.y}, zero = {(_Float16)0.0f, (_Float16)0.0f};
+    auto h2 = [](uint32_t v) { return __builtin_bit_cast(half2v, v); };
+    half2v bg = __builtin_elementwise_fma(h2(t00.x), w00, zero), r = __builtin_elementwise_fma(h2(t00.y), w00, zero);
+    bg = __builtin_elementwise_fma(h2(t01.x), w01, bg), r = __builtin_elementwise_fma(h2(t01.y), w01, r);
+    bg = __builtin_elementwise_fma(h2(t10.x), w10, bg), r = __builtin_elementwise_fma(h2(t10.y), w10, r);
+    bg = __builtin_elementwise_fma(h2(t11.x), w11, bg), r = __builtin_elementwise_fma(h2(t11.y), w11, r);
+    const half2v top = {(_Float16)1023.0f, (_Float16)1023.0f}, magic = {(_Float16)1024.0f, (_Float16)1024.0f};
+    const uint32_t bgi = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(bg, top) + magic) & 0x03ff03ffu;
+    const uint32_t ri = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(r, top) + magic) & 0x000003ffu;
+    return (bgi & 0x3ffu) | ((bgi >> 6) & 0xffc00u) | (ri << 20);
+}
+
 // One output pixel straight from global memory (the rare path of the tiled kernel): the direct kernel's arithmetic.
 template <int BLEND, typename Args>
 __device__ __forceinline__ uint32_t gather_pixel10(const Args &a, int sx, int sy) {

@@ -318,6 +318,10 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
     constexpr int TH = 4 * RW;
     constexpr int STAGE_MAX = StageTrips<RWB, RW>::value;
     constexpr int QB = CACHED ? 0 : QMAGIC_BITS;  // offset of the quantised-coordinate representation kept in registers
+    // LDS pixel: one dword (BGRx bytes, or B | G << 10 | R << 20), or -- 10-bit pixels with the fp16 blend -- two: the three channels
+    // as binary16 numbers, so that the blend's taps are converted once per source pixel (vstab_device10.hpp)
+    constexpr bool PIX8 = DEPTH == 10 && BLEND == VSTAB_BLEND_FP16;
+    constexpr int PD = PIX8 ? 2 : 1;
     constexpr bool RS = map_mode_is_rs(MODE);    // per-row rotation (BASELINE config 5)
     constexpr int BASE = map_mode_base(MODE);    // the projection pair and its arithmetic
     uint32_t *const tile = smem + 8;  // smem[0..4]: the tile header (box, flag), written by wave 0
@@ -346,9 +350,9 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
     // ---- load: this thread's 8x2 blocks of the box, all loads in flight at once --------------------------------
     const int ux_n = wb >> 3, units = use_lds ? ux_n * (hb >> 1) : 0;
 #ifdef VSTAB_DEV
-    const int pw = wb + ta.lds_pad;  // LDS row pitch in dwords (development experiment: pad against bank conflicts)
+    const int pw = (wb + ta.lds_pad) * PD;  // LDS row pitch in dwords (development experiment: pad against bank conflicts)
 #else
-    const int pw = wb;               // LDS row pitch in dwords
+    const int pw = wb * PD;                 // LDS row pitch in dwords
 #endif
     SrcVec y0w[STAGE_MAX], y1w[STAGE_MAX], uvw[STAGE_MAX];
     int ldsoff[STAGE_MAX];  // dword offset of the block in the LDS tile (| ZERO_BLOCK: outside the source); -1 = no block
@@ -382,7 +386,7 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
             y0w[it] = *reinterpret_cast<const SrcVec *>(a.y + oy);
             y1w[it] = *reinterpret_cast<const SrcVec *>(a.y + oy + pitch_y);
             uvw[it] = *reinterpret_cast<const SrcVec *>(a.uv + ouv);
-            ldsoff[it] = valid ? (__mul24(2 * uy, pw) + 8 * ux) | (inside ? 0 : ZERO_BLOCK) : -1;
+            ldsoff[it] = valid ? (__mul24(2 * uy, pw) + 8 * PD * ux) | (inside ? 0 : ZERO_BLOCK) : -1;
             ux += sx_, uy += sy_;
             if (ux >= ux_n) ux -= ux_n, uy++;
         }
@@ -531,8 +535,8 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
             if (ldsoff[it] >= ZERO_BLOCK) {
                 uint32_t *d = tile + (ldsoff[it] - ZERO_BLOCK);
                 const uint4 z = make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4 *>(d) = z, *reinterpret_cast<uint4 *>(d + 4) = z;
-                *reinterpret_cast<uint4 *>(d + pw) = z, *reinterpret_cast<uint4 *>(d + pw + 4) = z;
+#pragma unroll
+                for (int q = 0; q < 2 * PD; q++) *reinterpret_cast<uint4 *>(d + 4 * q) = z, *reinterpret_cast<uint4 *>(d + pw + 4 * q) = z;
 #ifdef VSTAB_DEV
             } else if (DEPTH == 8 && ldsoff[it] >= 0 && (ta.ablate & 4)) {
                 uint32_t *d = tile + ldsoff[it];
@@ -550,6 +554,18 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
 #pragma unroll
                     for (int half = 0; half < 2; half++) {
                         const ChromaTerm c0 = chroma_term10(cw[2 * half]), c1 = chroma_term10(cw[2 * half + 1]);
+                        if constexpr (PIX8) {  // four pixels of each row as halves: two 16-byte stores per row
+                            const uint32_t la = ya[2 * half], lb = ya[2 * half + 1], ma = yb[2 * half], mb = yb[2 * half + 1];
+                            const uint2 a0 = pack_bgr10h((int)((la & 0xffffu) >> 6), c0), a1 = pack_bgr10h((int)(la >> 22), c0);
+                            const uint2 a2 = pack_bgr10h((int)((lb & 0xffffu) >> 6), c1), a3 = pack_bgr10h((int)(lb >> 22), c1);
+                            const uint2 b0 = pack_bgr10h((int)((ma & 0xffffu) >> 6), c0), b1 = pack_bgr10h((int)(ma >> 22), c0);
+                            const uint2 b2 = pack_bgr10h((int)((mb & 0xffffu) >> 6), c1), b3 = pack_bgr10h((int)(mb >> 22), c1);
+                            *reinterpret_cast<uint4 *>(d + 8 * half) = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                            *reinterpret_cast<uint4 *>(d + 8 * half + 4) = make_uint4(a2.x, a2.y, a3.x, a3.y);
+                            *reinterpret_cast<uint4 *>(d + pw + 8 * half) = make_uint4(b0.x, b0.y, b1.x, b1.y);
+                            *reinterpret_cast<uint4 *>(d + pw + 8 * half + 4) = make_uint4(b2.x, b2.y, b3.x, b3.y);
+                            continue;
+                        }
                         uint4 r0, r1;
                         r0.x = pack_bgr10((int)((ya[2 * half] & 0xffffu) >> 6), c0), r0.y = pack_bgr10((int)(ya[2 * half] >> 22), c0);
                         r0.z = pack_bgr10((int)((ya[2 * half + 1] & 0xffffu) >> 6), c1), r0.w = pack_bgr10((int)(ya[2 * half + 1] >> 22), c1);
@@ -596,6 +612,21 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
         if (!__builtin_amdgcn_ballot_w64(mxx >= wlim || mxy >= hlim)) {
             // every footprint of the wave lies in the staged box: all tap reads first, then the blends
             constexpr int TG = RW < TAP_GROUP ? RW : TAP_GROUP;  // rows whose tap reads are in flight together
+            if constexpr (PIX8) {
+#pragma unroll
+                for (int j0 = 0; j0 < RW; j0 += TG) {
+                    uint2 t0[TG], t1[TG], t2[TG], t3[TG];
+#pragma unroll
+                    for (int j = 0; j < TG; j++) {
+                        const uint32_t off = __umul24((uint32_t)Yr[j0 + j], wb4) + ((uint32_t)Xr[j0 + j] << 3);
+                        const uint2 *u = reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(tile) + off);
+                        const uint2 *l = reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(tile) + (off + wb4));
+                        t0[j] = u[0], t1[j] = u[1], t2[j] = l[0], t3[j] = l[1];
+                    }
+#pragma unroll
+                    for (int j = 0; j < TG; j++) out[j0 + j] = blend_bgr10h(t0[j], t1[j], t2[j], t3[j], qxb[j0 + j] & 31, qyb[j0 + j] & 31);
+                }
+            } else
 #pragma unroll
             for (int j0 = 0; j0 < RW; j0 += TG) {
                 uint32_t t0[TG], t1[TG], t2[TG], t3[TG];
@@ -626,9 +657,13 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
                 const bool inbox = (uint32_t)Xr[j] < wlim && (uint32_t)Yr[j] < hlim;
                 uint32_t v = 0;
                 if (inbox) {
-                    const uint32_t *t = tile + (__mul24(Yr[j], pw) + Xr[j]);
-                    v = DEPTH == 10 ? blend_bgr10<BLEND>(t[0], t[1], t[pw], t[pw + 1], qxb[j] & 31, qyb[j] & 31)
-                                    : blend_bgrx(t[0], t[1], t[pw], t[pw + 1], qxb[j] & 31, qyb[j] & 31);
+                    const uint32_t *t = tile + (__mul24(Yr[j], pw) + PD * Xr[j]);
+                    if constexpr (PIX8)
+                        v = blend_bgr10h(make_uint2(t[0], t[1]), make_uint2(t[2], t[3]), make_uint2(t[pw], t[pw + 1]), make_uint2(t[pw + 2], t[pw + 3]), qxb[j] & 31,
+                                         qyb[j] & 31);
+                    else
+                        v = DEPTH == 10 ? blend_bgr10<BLEND>(t[0], t[1], t[pw], t[pw + 1], qxb[j] & 31, qyb[j] & 31)
+                                        : blend_bgrx(t[0], t[1], t[pw], t[pw + 1], qxb[j] & 31, qyb[j] & 31);
                 }
                 out[j] = v;
                 const bool live = col_live && y0 + wave * RW + j < a.dh;
@@ -869,23 +904,28 @@ vstab_status launch_warp_fused10(const WarpArgs &a, const float params[17], int 
 #ifdef VSTAB_DEV
     ta.timing = nullptr, ta.ablate = 0, ta.lds_pad = 0;
 #endif
+    // 64 x 32 tiles, 40 KB of LDS.  The fp16 blend stages 8-byte pixels (three halves): half as many fit, and a tall tile whose box is
+    // over that is done as two half-height tiles (SPLIT) -- measured faster than 64 x 16 tiles throughout (47.3 against 49.1 us at 4K).
     const int lds_kb = 40;
-    const long tiles = (long)div_up(a.dw, 64) * div_up(a.dh, 32);
-    const dim3 grid(tile_schedule(ta, 8, lds_kb, tiles > 1024 ? 0.5 : 0.0));
+    const bool half = blend == VSTAB_BLEND_FP16;
+    const int rwb = 8;
+    const long tiles = (long)div_up(a.dw, 64) * div_up(a.dh, 4 * rwb);
+    const dim3 grid(tile_schedule(ta, rwb, lds_kb, tiles > 1024 ? 0.5 : 0.0));
+    if (half) ta.lds_capacity_px /= 2;
     const size_t lds_bytes = (size_t)lds_kb * 1024;
     const LaunchEvents ev = take_launch_events();
-#define VSTAB_LAUNCH10(M, B, F)                                                                                                     \
+#define VSTAB_LAUNCH10(R, M, B, F)                                                                                                  \
     do {                                                                                                                            \
-        if (ev.start) hipExtLaunchKernelGGL((k_warp_fused<8, M, F, false, 10, B>), grid, dim3(256), lds_bytes, st, ev.start, ev.stop, 0, ta); \
-        else hipLaunchKernelGGL((k_warp_fused<8, M, F, false, 10, B>), grid, dim3(256), lds_bytes, st, ta);                            \
+        if (ev.start) hipExtLaunchKernelGGL((k_warp_fused<R, M, F, false, 10, B>), grid, dim3(256), lds_bytes, st, ev.start, ev.stop, 0, ta); \
+        else hipLaunchKernelGGL((k_warp_fused<R, M, F, false, 10, B>), grid, dim3(256), lds_bytes, st, ta);                            \
     } while (0)
 #define VSTAB_LAUNCH10_M(M)                                                      \
     do {                                                                         \
         if (p010_out) {                                                          \
-            if (blend == VSTAB_BLEND_FP16) VSTAB_LAUNCH10(M, VSTAB_BLEND_FP16, 3); \
-            else VSTAB_LAUNCH10(M, VSTAB_BLEND_EXACT, 3);                        \
-        } else if (blend == VSTAB_BLEND_FP16) VSTAB_LAUNCH10(M, VSTAB_BLEND_FP16, 2); \
-        else VSTAB_LAUNCH10(M, VSTAB_BLEND_EXACT, 2);                            \
+            if (half) VSTAB_LAUNCH10(8, M, VSTAB_BLEND_FP16, 3);                 \
+            else VSTAB_LAUNCH10(8, M, VSTAB_BLEND_EXACT, 3);                     \
+        } else if (half) VSTAB_LAUNCH10(8, M, VSTAB_BLEND_FP16, 2);              \
+        else VSTAB_LAUNCH10(8, M, VSTAB_BLEND_EXACT, 2);                         \
     } while (0)
     if (rot_bottom) {
         if (map_mode == VSTAB_MAP_CREATEMAP_CL) VSTAB_LAUNCH10_M(MAP_RS_CREATEMAP_CL);
