@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4, help="untimed steps ahead of the timed region")
     ap.add_argument("--batch", type=int, default=64, help="frames per step (one pass over the input ring by default)")
     ap.add_argument("--preroll", type=int, default=1024, help="untimed frames ahead of --warmup (pipeline mode): steady state before the driver's window")
+    ap.add_argument("--fixed-preroll", action="store_true", help="exactly --preroll untimed frames (default: at least that many, then until the rate is steady)")
     ap.add_argument("--workload", default="4k", choices=["4k", "1080p", "4k-p010"],
                     help="4k-p010 = BASELINE config 5: P010 frames, 10-bit pixel path with fp16 blend, a read-out rotation per frame")
     ap.add_argument("--mode", default="auto", choices=["auto", "warp", "pipeline"])
@@ -474,7 +475,7 @@ def main():
             extra = dict(bit_depth=10, readouts=readouts, pixel_depth=10, blend=vs.BLEND_FP16)
         extra["map_precision"] = vs.MAP_PRECISION_OPENCL if opencl else vs.MAP_PRECISION_IEEE
         ring_hold = 0 if args.ingest == "copy" else None
-        stab = vs.Stabilizer(clip, total=preroll + (args.warmup + args.steps) * args.batch + 1000, preset=preset, smooth_radius=30, seed=1234 + rank,
+        stab = vs.Stabilizer(clip, total=preroll + 32 * 256 + (args.warmup + args.steps) * args.batch + 1000, preset=preset, smooth_radius=30, seed=1234 + rank,
                              tracking=0 if args.no_tracking else 1, ring_hold=ring_hold, **extra)
         assert stab.out_size == (cw, ch)
 
@@ -517,6 +518,23 @@ def main():
                 step(i, timed)
     for i in range(preroll):  # pipeline mode: untimed, ahead of the warm-up the driver asks for
         assert pull(i)
+    if mode == "pipeline" and preroll and not args.fixed_preroll:
+        # still untimed: on a box that has just been started the first seconds run slower (clocks, page-in of the runtime) -- a 4K
+        # run that opened its 51 ms window right behind 1024 frames read 22 k where the next run read 26.4 k.  Keep pulling in
+        # windows of 256 frames until two consecutive windows agree within 3 % (at most 32 windows); the frames are counted in `preroll`.
+        prev, more = None, 0
+        for _ in range(32):
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            for i in range(256):
+                assert pull(preroll + more + i)
+            torch.cuda.synchronize()
+            rate = 256 / (time.perf_counter() - tw)
+            more += 256
+            if prev is not None and abs(rate - prev) <= 0.03 * prev:
+                break
+            prev = rate
+        preroll += more
     run_steps(0, args.warmup, False)
     torch.cuda.synchronize()
     if use_dist:
@@ -539,6 +557,16 @@ def main():
     parity, parity_against = None, None
     if mode == "pipeline" and rank == 0:
         import oracle
+        # the checker's OpenMP threads are created on first use and keep the CPU mask of that moment for good: give them this GPU's
+        # whole share of the host (the CPU baseline legs below run on the same pool), then go back to the handle's few CPUs
+        pinned_mask = sorted(os.sched_getaffinity(0))
+        try:
+            os.sched_setaffinity(0, cpu_mask)
+            oracle.lib().vo_set_num_threads(box_cpu_share())
+            oracle.cvt_nv12_bgr(np.zeros((96, 64), np.uint8))  # a first parallel region: the pool exists from here on
+            os.sched_setaffinity(0, pinned_mask)
+        except OSError:
+            pass
         n_emit = preroll + n_warm + n_timed  # index of the frame pulled now; frame 0 of the clip is never emitted
         assert pull(n_emit)
         torch.cuda.synchronize()

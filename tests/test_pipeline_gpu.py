@@ -1144,7 +1144,7 @@ def test_bench_launches_its_own_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--workload", "1080p",
-                        "--steps", "20", "--warmup", "5", "--batch", "8", "--preroll", "40", "--ring", "16", "--no-cpu-baseline"],
+                        "--steps", "20", "--warmup", "5", "--batch", "8", "--preroll", "40", "--fixed-preroll", "--ring", "16", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -1166,7 +1166,7 @@ def test_bench_four_ranks_share_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--share-gpu", "--dist-backend", "gloo", "--workload", "1080p",
-                        "--steps", "2", "--warmup", "1", "--batch", "8", "--preroll", "40", "--ring", "8", "--no-cpu-baseline"],
+                        "--steps", "2", "--warmup", "1", "--batch", "8", "--preroll", "40", "--fixed-preroll", "--ring", "8", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -1194,7 +1194,7 @@ def test_bench_rccl_branch_runs_on_one_rank():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--workload", "1080p",
-                        "--steps", "2", "--batch", "8", "--preroll", "40", "--ring", "16", "--no-cpu-baseline"],
+                        "--steps", "2", "--batch", "8", "--preroll", "40", "--fixed-preroll", "--ring", "16", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]

@@ -164,7 +164,7 @@ def test_ieee_mode_deviation_from_the_reference_kernel_on_gfx950_is_pinned(refcl
         json.dump(table, f, indent=1)
     for i in range(3):
         for t in (table[f"params_{i}"]["x"], table[f"params_{i}"]["y"]):
-            # measured (profiles/r03_a9_ieee_vs_reference_gfx950.json): 51-58 % of the entries identical, 9-16 % differ by more
+            # measured (profiles/history/r03_a9_ieee_vs_reference_gfx950.json): 51-58 % of the entries identical, 9-16 % differ by more
             # than one ULP, at most 21; <= 4.1 x 2^-23 of the (map - centre) term; 0.19-0.31 % of the 1/32-px buckets flip
             assert t["identical"] > 0.45 and t["gt1ulp"] < 0.20 and t["max_ulp"] <= 28 and t["rel_max_x2p23"] <= 5.5 and t["bucket_flips"] < 0.004, (i, t)
         grey = table[f"params_{i}"]["grey"]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): tools/r03_evidence.sh  -- everything profiles/r03_* is made of (copied there by hand afterwards)
+# usage (GPU box): tools/r03_evidence.sh  -- everything profiles/history/r03_* is made of (copied there by hand afterwards)
 O=gpurun_out/r03ev; mkdir -p $O
 python bench.py --steps 20 --warmup 5 > $O/bench_pipeline_4k.json 2> $O/bench_4k.err
 python bench.py --steps 20 --warmup 5 --map-precision opencl --no-cpu-baseline > $O/bench_pipeline_4k_opencl_precision.json 2>> $O/bench_4k.err

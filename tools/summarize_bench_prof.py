@@ -29,7 +29,7 @@ cal4 = find("cal_fetch", "k_pack_nv12<unsigned int>", "FETCH_SIZE")
 cal8 = find("cal_fetch", ", 2u>", "FETCH_SIZE") or find("cal_fetch", "uint2", "FETCH_SIZE")
 calw16 = find("cal_write", ", 4u>", "WRITE_SIZE") or find("cal_write", "uint4", "WRITE_SIZE")
 wf, ww = find("pmc_fetch", "k_warp_fused", "FETCH_SIZE"), find("pmc_write", "k_warp_fused", "WRITE_SIZE")
-summary = {"known_copy_bytes": known, "round": os.environ.get("ROUND", "r03")}
+summary = {"known_copy_bytes": known, "round": os.environ.get("ROUND", "r04"), "map_precision": os.environ.get("MAP_PRECISION", "opencl")}
 if cal16: summary["fetch_factor_16B_per_lane"] = known / (cal16 * 1024)
 if cal4: summary["fetch_factor_4B_per_lane"] = known / (cal4 * 1024)
 if cal8: summary["fetch_factor_8B_per_lane"] = known / (cal8 * 1024)

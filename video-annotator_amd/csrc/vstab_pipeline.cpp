@@ -1441,10 +1441,11 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     }
     if (H->ow <= 0 || H->oh <= 0 || H->ow > 32767 || H->oh > 32767) return fail(VSTAB_ERR_INVALID, "vstab_create: output size out of range");
     if (cfg->smoother == VSTAB_SMOOTHER_SG) H->sg.reset(new RotationFilterSG(cfg->smooth_radius));
-    // queue (r+1) + ready + in flight + first/last gray + 2 spare for stream overlap + the slots that wait for a shared warp event
     if (const char *e = getenv("VSTAB_PREFETCH")) H->prefetch_depth = std::max(1, std::min(atoi(e), PREFETCH_MAX));
     if (const char *e = getenv("VSTAB_LK_SEG_TARGET")) H->seg_target = std::max(1, std::min(atoi(e), H->seg_max));
-    H->slots.resize((size_t)cfg->smooth_radius + 5 + H->prefetch_depth + vstab_handle::WARP_EVENT_STRIDE);
+    // queue (r + 1) + the frame whose estimate runs + the one whose results are read + the one in flight + first/last gray + 1 spare
+    // + the read-ahead + the slots that wait for a shared warp event
+    H->slots.resize((size_t)cfg->smooth_radius + 6 + H->prefetch_depth + vstab_handle::WARP_EVENT_STRIDE);
     for (auto &s : H->slots) {
         VSTAB_HIP_TRY(hipEventCreateWithFlags(&s.ingested, hipEventDisableTiming));
     }
