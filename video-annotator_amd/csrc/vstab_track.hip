@@ -169,9 +169,29 @@ __global__ void __launch_bounds__(256) k_pyr_down_x2(const uint8_t *__restrict__
     const int mx0 = 2 * x0 - 4, my0 = 2 * y0 - 2;                 // first-level origin of the region
     const int sx0 = 2 * mx0 - 4, sy0 = 2 * my0 - 2;               // source origin of the region (a multiple of 4)
     // ---- stage the source region, reflected -----------------------------------------------------------------------------
-    for (int e = tid; e < P2_SH * (P2_SW / 4); e += 256) {
-        const int ry = e / (P2_SW / 4), rd = e - ry * (P2_SW / 4);
-        reinterpret_cast<uint32_t *>(&ssrc[ry][0])[rd] = load4_reflect(src, spitch, sw, sh, sx0 + 4 * rd, sy0 + ry, vec_ok != 0);
+    // (a workgroup whose whole region lies inside the image -- all but the border ones -- loads aligned dwords, all in flight
+    // together, and needs no reflection in any phase: the kernel's instruction count is a quarter of the generic path's)
+    const bool interior = vec_ok && sx0 >= 0 && sy0 >= 0 && sx0 + P2_SW <= sw && sy0 + P2_SH <= sh;  // uniform
+    if (interior) {
+        constexpr int ND = P2_SH * (P2_SW / 4), NT = (ND + 255) / 256;
+        static_assert(P2_SW / 4 == 20, "the index split below divides by 20");
+        uint32_t v[NT];
+        const uint8_t *base = src + (uint32_t)sy0 * spitch + (uint32_t)sx0;
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const int e = min(tid + 256 * k, ND - 1), ry = __mul24(e, 3277) >> 16, rd = e - __mul24(ry, 20);
+            v[k] = *reinterpret_cast<const uint32_t *>(base + __umul24((uint32_t)ry, spitch) + 4 * rd);
+        }
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const int e = tid + 256 * k, ry = __mul24(e, 3277) >> 16, rd = e - __mul24(ry, 20);
+            if (e < ND) reinterpret_cast<uint32_t *>(&ssrc[ry][0])[rd] = v[k];
+        }
+    } else {
+        for (int e = tid; e < P2_SH * (P2_SW / 4); e += 256) {
+            const int ry = e / (P2_SW / 4), rd = e - ry * (P2_SW / 4);
+            reinterpret_cast<uint32_t *>(&ssrc[ry][0])[rd] = load4_reflect(src, spitch, sw, sh, sx0 + 4 * rd, sy0 + ry, vec_ok != 0);
+        }
     }
     __syncthreads();
     // ---- first level: 9 groups of 4 outputs x 27 rows, one group per thread ---------------------------------------------
@@ -211,7 +231,22 @@ __global__ void __launch_bounds__(256) k_pyr_down_x2(const uint8_t *__restrict__
     if (tid < P2_TW * P2_TH) {
         const int ty = tid / P2_TW, tx = tid - ty * P2_TW;
         const int x = x0 + tx, y = y0 + ty;
-        if (x < dw && y < dh) {
+        if (interior && x < dw && y < dh) {
+            // no reflection: the five taps of a row are bytes 2 tx + 2 .. 2 tx + 6 of region row 2 ty + j -- two aligned dwords, the
+            // first four taps shifted into place (v_alignbyte) for one dot product with (k, 4k, 6k, 4k), the fifth in byte 0 of the rest
+            const int c0 = 2 * tx + 2, sh8 = (c0 & 3), a0 = c0 >> 2;
+            uint32_t acc = 128u;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const uint32_t *r = reinterpret_cast<const uint32_t *>(&smid[2 * ty + j][0]) + a0;
+                const uint32_t A = r[0], B = r[1];
+                const uint32_t k = j == 0 || j == 4 ? 1u : j == 2 ? 6u : 4u;
+                const uint32_t w_all = k | (4 * k << 8) | (6 * k << 16) | (4 * k << 24);
+                acc = udot4(__builtin_amdgcn_alignbyte(B, A, sh8), w_all, acc);
+                acc = udot4(B >> (8 * sh8), k, acc);
+            }
+            dst[(uint32_t)y * dpitch + x] = (uint8_t)(acc >> 8);
+        } else if (x < dw && y < dh) {
             int col[5];
 #pragma unroll
             for (int i = 0; i < 5; i++) col[i] = reflect101(2 * x - 2 + i, mw) - mx0;
