@@ -455,7 +455,7 @@ VSTAB_API vstab_status vstab_get_output_info(const vstab_handle *h, int *width, 
  * dst is complete once vstab_config.stream is synchronised.  Upstream frames handed to the callbacks
  * must already be complete in memory when the callback returns (they are read on an internal stream).
  * Read-ahead: to overlap copy, pyramid, corner detection and tracking with the host work, the library pulls
- * upstream up to nine frames earlier than the reference's loop would (same frames, same order, same outputs). */
+ * upstream up to ten frames earlier than the reference's loop would (same frames, same order, same outputs). */
 VSTAB_API vstab_status vstab_pull_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
 /* The consumer's loop (DisplayImage.cpp:60-70: `while (true) { frame = source.pull_frame(); ... }`) as one call: n consecutive
  * vstab_pull_frame calls, frame i into dst[(first + i) % n_dst] with pitch[(first + i) % n_dst] -- an encoder's ring of output
