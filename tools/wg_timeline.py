@@ -23,6 +23,7 @@ torch.cuda.synchronize()
 vs._L.vstab_dev_set_timing(ctypes.c_void_p(0))
 t = buf.cpu().numpy().astype(np.float64)
 live = t[:, 0, 7] != 0
+blk = np.nonzero(live)[0]  # blockIdx.x of every workgroup that ran a tile
 t = t[live] / 100.0  # microseconds
 t0 = t[:, :, 0].min()
 t -= t0
@@ -39,3 +40,15 @@ edges = np.linspace(0, end.max(), 25)
 for a, b in zip(edges[:-1], edges[1:]):
     m = (a + b) / 2
     print(f"  t={m:6.1f} us  resident {int(((start <= m) & (end > m)).sum()):5d}  started {int(((start >= a) & (start < b)).sum()):5d}")
+# per XCD (blockIdx.x % 8: one band of output rows each): when its first / last workgroup ran, and how much work it had
+print("per XCD: workgroups, first start, last end, sum of workgroup durations (us)")
+for k in range(8):
+    m = (blk & 7) == k
+    print(f"  xcd {k}: {int(m.sum()):5d}  {start[m].min():6.2f}  {end[m].max():6.2f}  {dur[m].sum():8.1f}   median tile {np.median(dur[m]):.2f}")
+print("residency per XCD over time (128 workgroup slots each):")
+for m_ in np.linspace(0, end.max(), 13)[1:-1]:
+    print(f"  t={m_:5.1f} us  " + " ".join(f"{int((((blk & 7) == k) & (start <= m_) & (end > m_)).sum()):4d}" for k in range(8)))
+# dispatch order: is workgroup b ever started before workgroup b - 8 * 128 ... (in-order dispatch across the XCDs?)
+order = np.argsort(blk)
+st_sorted = start[order]
+print(f"start times in blockIdx order: non-decreasing steps {int((np.diff(st_sorted) >= -0.02).sum())} of {len(st_sorted) - 1}; largest step back {(-np.diff(st_sorted)).max():.2f} us")

@@ -59,6 +59,9 @@ constexpr float QMAGIC = 12582912.0f;
 constexpr int QMAGIC_BITS = 0x4B400000;
 
 typedef short short2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uint32_t LdsWord;  // a dword in LDS, addressed by its 32-bit LDS address
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2 LdsPair;     // an 8-byte pixel (three halves) there
 
 __device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
@@ -259,16 +262,17 @@ __device__ __forceinline__ void map_pairs_ieee(float icx32, float icy32, float i
     }
 }
 
-// The same for MAP_CREATEMAP_CL_OPENCL: map_pixel_ocl_fast (vstab_device.hpp) on NP row pairs in lock-step.  Returns
-// non-zero when some intermediate may have left the normal range: the caller then re-evaluates the wave's pixels with the
-// code object's literal instruction stream.  q in [2^-80, 2^80] is the whole test: a rotated ray has a component >= 1/2,
-// so a reciprocal, quotient or square that over- or underflows shows up as q = inf / NaN / tiny (q's bits as unsigned).
+// The same for MAP_CREATEMAP_CL_OPENCL: map_pixel_ocl_fast (vstab_device.hpp) on NP row pairs in lock-step.  qmin / qmax
+// collect the range of q (its bits as unsigned) over all the caller's pixels: when some intermediate may have left the
+// normal range the caller re-evaluates the wave's pixels with the code object's literal instruction stream.
+// q in [2^-80, 2^80] is the whole test (map_q_irregular): a rotated ray has a component >= 1/2, so a reciprocal, quotient
+// or square that over- or underflows shows up as q = inf / NaN / tiny.
+__device__ __forceinline__ bool map_q_irregular(uint32_t qmin, uint32_t qmax) { return qmin < 0x17800000u /* 2^-80 */ || qmax > 0x67800000u /* 2^80 */; }
 template <int NP>
-__device__ __forceinline__ uint32_t map_pairs_ocl(float icx32, float icy32, float ifx32, float ify32, const f32x2 (&wx)[NP], const f32x2 (&wy)[NP],
-                                                  const f32x2 (&wz)[NP], f32x2 (&ax)[NP], f32x2 (&ay)[NP]) {
+__device__ __forceinline__ void map_pairs_ocl(float icx32, float icy32, float ifx32, float ify32, const f32x2 (&wx)[NP], const f32x2 (&wy)[NP],
+                                              const f32x2 (&wz)[NP], f32x2 (&ax)[NP], f32x2 (&ay)[NP], uint32_t &qmin, uint32_t &qmax) {
     f32x2 rz[NP], px[NP], py[NP], q[NP], rad[NP], rr[NP], t[NP], s[NP], p[NP], r[NP], k[NP];
     i32x2 inv[NP];
-    uint32_t qmin = 0xffffffffu, qmax = 0u;
     VSTAB_EACH rz[c] = (f32x2){__builtin_amdgcn_rcpf(wz[c].x), __builtin_amdgcn_rcpf(wz[c].y)};
     VSTAB_EACH px[c] = wx[c] * rz[c], py[c] = wy[c] * rz[c];
     VSTAB_EACH q[c] = fma2(py[c], py[c], px[c] * px[c]);
@@ -291,7 +295,6 @@ __device__ __forceinline__ uint32_t map_pairs_ocl(float icx32, float icy32, floa
     VSTAB_EACH r[c] = inv[c] ? splat2(f32_bits(0x3fc90fdbu)) - r[c] : r[c];
     VSTAB_EACH k[c] = r[c] * rr[c];
     VSTAB_EACH ax[c] = fma2(splat2(ifx32), px[c] * k[c], splat2(icx32)), ay[c] = fma2(splat2(ify32), py[c] * k[c], splat2(icy32));
-    return (qmin < 0x17800000u /* 2^-80 */ || qmax > 0x67800000u /* 2^80 */) ? 1u : 0u;
 }
 #undef VSTAB_EACH
 
@@ -384,7 +387,7 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
             const uint32_t cx = (uint32_t)min(max(gx, 0), (a.sw & ~7) - 8), cy = (uint32_t)min(max(gy, 0), a.sh - 2);
             const uint32_t oy = __umul24(cy, pitch_y) + cx * BPS, ouv = __umul24(cy >> 1, pitch_uv) + cx * BPS;
             y0w[it] = *reinterpret_cast<const SrcVec *>(a.y + oy);
-            y1w[it] = *reinterpret_cast<const SrcVec *>(a.y + oy + pitch_y);
+            y1w[it] = *reinterpret_cast<const SrcVec *>(a.y + (oy + pitch_y));  // (a 32-bit offset: one add, not a 64-bit pointer step)
             uvw[it] = *reinterpret_cast<const SrcVec *>(a.uv + ouv);
             ldsoff[it] = valid ? (__mul24(2 * uy, pw) + 8 * PD * ux) | (inside ? 0 : ZERO_BLOCK) : -1;
             ux += sx_, uy += sy_;
@@ -469,7 +472,7 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
             }
         } else if constexpr (BASE == MAP_CREATEMAP_CL_OPENCL) {
             constexpr int NP = RW / 2 < MAP_GROUP ? RW / 2 : MAP_GROUP;
-            uint32_t irregular = 0;
+            uint32_t qmin = 0xffffffffu, qmax = 0u;  // one range test for all RW pixels (min3 / max3: half an instruction per pixel)
 #pragma unroll
             for (int g0 = 0; g0 < RW / 2; g0 += NP) {
                 f32x2 wx[NP], wy[NP], wz[NP], ax[NP], ay[NP];
@@ -487,7 +490,7 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
                         wy[c] = fma2(splat2(a.p.r[4]), vy2, splat2(ct.a1)) + splat2(a.p.r[5]);
                     }
                 }
-                irregular |= map_pairs_ocl<NP>(icx32, icy32, ifx32, ify32, wx, wy, wz, ax, ay);
+                map_pairs_ocl<NP>(icx32, icy32, ifx32, ify32, wx, wy, wz, ax, ay, qmin, qmax);
 #pragma unroll
                 for (int c = 0; c < NP; c++) {
                     const int j = 2 * (g0 + c);
@@ -496,7 +499,7 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
                     qyb[j] = __float_as_int(ay[c].x), qyb[j + 1] = __float_as_int(ay[c].y);
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(irregular != 0)) {  // practically never: the code object's literal stream
+            if (__builtin_amdgcn_ballot_w64(map_q_irregular(qmin, qmax))) {  // practically never: the code object's literal stream
 #pragma unroll 1
                 for (int j = 0; j < RW; j++) {
                     float fx, fy;
@@ -599,10 +602,16 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
     const bool col_live = x < a.dw;
     uint32_t out[RW];
     {
-        const int cx = bx0 + (QB >> 5), cy = by0 + (QB >> 5);
+        // box origin in the registers' representation, each ONE scalar (left to itself the compiler subtracts the origin and the
+        // representation's offset from every coordinate separately: 16 vector instructions per thread)
+        int cx = bx0 + (QB >> 5), cy = by0 + (QB >> 5);
+        asm("" : "+s"(cx), "+s"(cy));
         const uint32_t wlim = use_lds ? (uint32_t)(wb - 1) : 0u, hlim = (uint32_t)(hb - 1);  // both taps of each axis inside the staged box
         int Xr[RW], Yr[RW];
         const uint32_t wb4 = (uint32_t)pw << 2;
+        // LDS byte address of the tile, as a scalar: tap addresses are formed from it by hand (shift-add, multiply-add, add)
+        uint32_t tile_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)tile;
+        asm("" : "+s"(tile_lds));
         uint32_t mxx = 0, mxy = 0;  // as unsigned: a coordinate left of / above the box is huge
 #pragma unroll
         for (int j = 0; j < RW; j++) {
@@ -618,10 +627,12 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
                     uint2 t0[TG], t1[TG], t2[TG], t3[TG];
 #pragma unroll
                     for (int j = 0; j < TG; j++) {
-                        const uint32_t off = __umul24((uint32_t)Yr[j0 + j], wb4) + ((uint32_t)Xr[j0 + j] << 3);
-                        const uint2 *u = reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(tile) + off);
-                        const uint2 *l = reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(tile) + (off + wb4));
-                        t0[j] = u[0], t1[j] = u[1], t2[j] = l[0], t3[j] = l[1];
+                        uint32_t ax8, au;  // (as below: shift-add, multiply-add, add)
+                        asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(ax8) : "v"(Xr[j0 + j]), "s"(tile_lds));
+                        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(au) : "v"(Yr[j0 + j]), "s"(wb4), "v"(ax8));
+                        const LdsPair *u = reinterpret_cast<const LdsPair *>(au), *l = reinterpret_cast<const LdsPair *>(au + wb4);
+                        const u32x2 v0 = u[0], v1 = u[1], v2 = l[0], v3 = l[1];
+                        t0[j] = make_uint2(v0.x, v0.y), t1[j] = make_uint2(v1.x, v1.y), t2[j] = make_uint2(v2.x, v2.y), t3[j] = make_uint2(v3.x, v3.y);
                     }
 #pragma unroll
                     for (int j = 0; j < TG; j++) out[j0 + j] = blend_bgr10h(t0[j], t1[j], t2[j], t3[j], qxb[j0 + j] & 31, qyb[j0 + j] & 31);
@@ -632,10 +643,12 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
                 uint32_t t0[TG], t1[TG], t2[TG], t3[TG];
 #pragma unroll
                 for (int j = 0; j < TG; j++) {
-                    // byte offsets by hand: one multiply-add for the upper tap row, one add for the lower
-                    const uint32_t off = __umul24((uint32_t)Yr[j0 + j], wb4) + ((uint32_t)Xr[j0 + j] << 2);
-                    const uint32_t *u = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tile) + off);
-                    const uint32_t *l = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tile) + (off + wb4));
+                    // LDS addresses by hand: shift-add and multiply-add for the upper tap row, one add for the lower (written as
+                    // instructions: the compiler re-associates the expression into four)
+                    uint32_t ax4, au;
+                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ax4) : "v"(Xr[j0 + j]), "s"(tile_lds));
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(au) : "v"(Yr[j0 + j]), "s"(wb4), "v"(ax4));
+                    const LdsWord *u = reinterpret_cast<const LdsWord *>(au), *l = reinterpret_cast<const LdsWord *>(au + wb4);
                     t0[j] = u[0], t1[j] = u[1], t2[j] = l[0], t3[j] = l[1];
                 }
 #pragma unroll
@@ -834,9 +847,10 @@ template <int RWB, int MODE, int FMT, bool CACHED, int DEPTH = 8, int BLEND = 0>
 __global__ void __launch_bounds__(256, DEPTH == 10 ? 5 : VSTAB_WARP_WAVES) k_warp_fused(FusedArgs ta) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int TH = 4 * RWB, TS = TH / 2;
-    const int k = (int)(blockIdx.x & 7u), idx = (int)(blockIdx.x >> 3);
+    const int k = (int)(blockIdx.x & 7u);
     const int y_lo = ta.band_y[k], y_sp = ta.split_y[k], y_hi = ta.band_y[k + 1];
     const int n_tall = ((y_sp - y_lo) / TH) * ta.tiles_x;  // y_sp - y_lo is a multiple of TH
+    const int idx = (int)(blockIdx.x >> 3);
     int x0, ys, n_half;
     if (idx < n_tall) {
         const int row = idx / ta.tiles_x;
