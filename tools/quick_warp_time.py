@@ -27,7 +27,12 @@ if fmt == 0:
 else:
     outs = [vs.nv12_out_planes(cw, ch) for _ in range(nf)]
     out_bytes = cw * ch + 2 * ((cw + 1) // 2) * ((ch + 1) // 2)
-run = lambda i: vs.warp_nv12(frames[i % nf], p, cw, ch, mode, fmt, out=outs[i % nf])
+if os.environ.get("QRS"):   # a rotation per output row (rolling shutter): the last row turned by 0.4 degrees about y
+    a = np.deg2rad(0.4)
+    rb = (np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]) @ np.asarray(p[8:17], np.float64).reshape(3, 3)).astype(np.float32)
+    run = lambda i: vs.warp_nv12_rs(frames[i % nf], p, rb, cw, ch, mode, fmt, out=outs[i % nf])
+else:
+    run = lambda i: vs.warp_nv12(frames[i % nf], p, cw, ch, mode, fmt, out=outs[i % nf])
 for i in range(nf): run(i)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -843,8 +843,10 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
 // the 128-B lines their source and output rows straddle move once.  Inside its band an XCD first works through tiles of
 // 4 RWB rows, then -- from row split_y[k] on -- through tiles of half that height (the last, partly filled round of
 // workgroups then lasts half as long).  Placement and tile height only affect speed, never results.
+// Register budgets: the 8-bit per-row kernels (nine matrix entries per row on top of everything else) get one wave per SIMD less to
+// leave room for: at 72 registers they spill inside the map phase (4K, reference arithmetic: 36.1 -> 33.2 us with 80).
 template <int RWB, int MODE, int FMT, bool CACHED, int DEPTH = 8, int BLEND = 0>
-__global__ void __launch_bounds__(256, DEPTH == 10 ? 5 : VSTAB_WARP_WAVES) k_warp_fused(FusedArgs ta) {
+__global__ void __launch_bounds__(256, DEPTH == 10 ? 5 : map_mode_is_rs(MODE) ? VSTAB_WARP_WAVES - 1 : VSTAB_WARP_WAVES) k_warp_fused(FusedArgs ta) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int TH = 4 * RWB, TS = TH / 2;
     const int k = (int)(blockIdx.x & 7u);
