@@ -31,6 +31,11 @@ namespace vstab {
         if (st_ != VSTAB_OK) return st_;  \
     } while (0)
 
+static bool debug_spec() {  // VSTAB_DEBUG_SPEC=1: the key-frame speculation narrated on stderr (development aid)
+    static const bool on = getenv("VSTAB_DEBUG_SPEC") != nullptr;
+    return on;
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t n = 0;
@@ -285,7 +290,7 @@ class Tracker {
                             select_corners(reinterpret_cast<unsigned long long *>(spec_host_.as<uint8_t>() + 64), n, spec_max_, spec_dist_, spec_xy_);
                             result = 2;
                         }
-                        if (getenv("VSTAB_DEBUG_SPEC"))
+                        if (debug_spec())
                             std::fprintf(stderr, "async selection: waited %.0f us for the detection, selected %zu of %u candidates in %.0f us\n",
                                          std::chrono::duration<double, std::micro>(t1 - t0).count(), spec_xy_.size() / 2, n,
                                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count());
@@ -1100,7 +1105,7 @@ static vstab_status prefetch_next(vstab_handle *H) {
     // one frame for which it is false for every pending frame and true for the next.)
     if (H->cfg.tracking && H->speculate && H->last_key != -1 && (H->prefetch_count + 1) - H->last_key == 21)
     {
-        if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "spec launch for frame %ld (last_key %ld)\n", H->prefetch_count, H->last_key);
+        if (debug_spec()) std::fprintf(stderr, "spec launch for frame %ld (last_key %ld)\n", H->prefetch_count, H->last_key);
         HT t(HostTimers::SPEC_DETECT);
         hipStream_t ds = H->dstream ? H->dstream : H->pstream;
         if (ds != H->pstream) VSTAB_HIP_TRY(hipStreamWaitEvent(ds, H->slots[slot].ingested, 0));
@@ -1162,7 +1167,10 @@ static vstab_status launch_tracking(vstab_handle *H) {
         // frame pulled a moment ago would hold all its earlier frames back (measured: segments of 8 were slower than of 1)
         long reach = F;
         for (size_t j = 0; j < H->prefetched.size(); j++) {
-            if (hipEventQuery(H->slots[H->prefetched[j].first].ingested) != hipSuccess) break;
+            if (hipEventQuery(H->slots[H->prefetched[j].first].ingested) != hipSuccess) {
+                (void)hipGetLastError();  // "not ready" is an answer, not an error the next launch check should find
+                break;
+            }
             reach = F + 1 + (long)j;
         }
         auto drop_segments = [&]() {
@@ -1207,7 +1215,7 @@ static vstab_status launch_tracking(vstab_handle *H) {
             } else {
                 // the previous frame is F - 1: use its speculative detection if there is one
                 const bool spec = H->tracker.spec_tag() == F - 1 && H->tracker.spec_finish(200, 30.0, H->corners);
-                if (getenv("VSTAB_DEBUG_SPEC")) std::fprintf(stderr, "key frame at %ld: spec_tag %ld used %d\n", F, H->tracker.spec_tag(), (int)spec);
+                if (debug_spec()) std::fprintf(stderr, "key frame at %ld: spec_tag %ld used %d\n", F, H->tracker.spec_tag(), (int)spec);
                 if (!spec) VSTAB_TRY(H->tracker.good_features(pg, ppitch, 200, 0.01, 30.0, H->corners, H->tstream));
             }
             T.lg.key_frame = 1;
@@ -1243,7 +1251,7 @@ static vstab_status launch_tracking(vstab_handle *H) {
             const long kc = back.last_key_after + 21;  // next planned key frame
             if (next == kc) {
                 if (H->tracker.spec_tag() != tail || H->tracker.spec_state() != 2) {
-                    if (getenv("VSTAB_DEBUG_SPEC") && H->tracker.spec_tag() == tail)
+                    if (debug_spec() && H->tracker.spec_tag() == tail)
                         std::fprintf(stderr, "frame %ld: corners for key frame %ld not selected yet (state %d)\n", F, next, H->tracker.spec_state());
                     break;  // not detected / selected yet: next pull, or on demand when the host gets there
                 }
@@ -1711,10 +1719,10 @@ void vstab_destroy(vstab_handle *h) {
     }
     h->fold_pending();
     h->tracker.report_clock();
-    if (getenv("VSTAB_DEBUG_SPEC"))
+    if (debug_spec())
         std::fprintf(stderr, "frames used in place %ld, copied into the ring %ld; warps from the cached map %ld\n", h->frames_borrowed, h->frames_copied,
                      h->warps_from_cache);
-    if (getenv("VSTAB_DEBUG_SPEC"))
+    if (debug_spec())
         std::fprintf(stderr, "tracker launches: %ld segments covering %ld frames (%ld of them dropped); frames taken from a launch enqueued ahead %ld, "
                              "replaced on demand %ld, of %ld; key frames pre-launched %ld of %ld\n",
                      h->segs_launched, h->seg_frames_launched, h->seg_frames_dropped, h->chained_adopted, h->chained_discarded, h->frame_index,
