@@ -42,8 +42,9 @@ namespace vstab {
 // Every other input (|a| >= 2^22, +-inf, NaN) yields an integer >= 2^22 in magnitude, which lands far outside any
 // source <= 32767 wide -- the same "outside" cv::remap reaches through cvRound -> INT_MIN.  QMAGIC_BITS is a multiple
 // of 32, so (bits >> 5) - (QMAGIC_BITS >> 5) is the tap column and bits & 31 the fraction.
-// Register budget of the kernel as waves per SIMD it must leave room for: 7 -> at most 72 registers.  The kernel itself is
-// held to 4 waves per SIMD by its LDS; what it leaves free is what the tracker and pyramid kernels beside it run in.
+// Register budget of the kernel as waves per SIMD it must leave room for: 7 -> at most 72 registers (see k_warp_fused for the
+// kernels that get 80).  The kernel itself is held to 4 waves per SIMD by its LDS; what it leaves free is what the tracker and
+// pyramid kernels beside it run in.
 #ifndef VSTAB_WARP_WAVES
 #define VSTAB_WARP_WAVES 7
 #endif
@@ -843,10 +844,13 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
 // the 128-B lines their source and output rows straddle move once.  Inside its band an XCD first works through tiles of
 // 4 RWB rows, then -- from row split_y[k] on -- through tiles of half that height (the last, partly filled round of
 // workgroups then lasts half as long).  Placement and tile height only affect speed, never results.
-// Register budgets: the 8-bit per-row kernels (nine matrix entries per row on top of everything else) get one wave per SIMD less to
-// leave room for: at 72 registers they spill inside the map phase (4K, reference arithmetic: 36.1 -> 33.2 us with 80).
+// Register budgets.  The 64 x 16-tile kernels (small outputs, eight workgroups per CU) stay within 72 registers.  The 64 x 32-tile
+// kernels get 80: at 72 the per-frame kernels kept ten scratch instructions (ragged-edge stores, the half-height tile's prologue) and
+// the per-row kernels (nine matrix entries per row on top of everything else) spilled inside the map phase (4K, reference
+// arithmetic, per row: 36.1 -> 33.2 us; per frame in the pipeline 26.8 -> 27.0 k frames/s, three alternating runs on one box).
+// Their LDS holds them to four waves per SIMD anyway; 80 registers still leave room for a tracker wave (123) beside them.
 template <int RWB, int MODE, int FMT, bool CACHED, int DEPTH = 8, int BLEND = 0>
-__global__ void __launch_bounds__(256, DEPTH == 10 ? 5 : map_mode_is_rs(MODE) ? VSTAB_WARP_WAVES - 1 : VSTAB_WARP_WAVES) k_warp_fused(FusedArgs ta) {
+__global__ void __launch_bounds__(256, DEPTH == 10 ? 5 : (RWB == 8 || map_mode_is_rs(MODE)) ? VSTAB_WARP_WAVES - 1 : VSTAB_WARP_WAVES) k_warp_fused(FusedArgs ta) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int TH = 4 * RWB, TS = TH / 2;
     const int k = (int)(blockIdx.x & 7u);
