@@ -535,6 +535,9 @@ def main():
                 break
             prev = rate
         preroll += more
+    import gc
+    gc.collect()
+    gc.disable()  # no collector pause of the Python frame loop inside the ~50 ms window (nothing is skipped: the loop allocates a few small objects per frame)
     run_steps(0, args.warmup, False)
     torch.cuda.synchronize()
     if use_dist:
@@ -547,6 +550,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    gc.enable()
     if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
