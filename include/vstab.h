@@ -405,7 +405,8 @@ typedef struct vstab_config {
     double scale;        /* 1 */
     int crop_borders;    /* 0 */
     double zoom;         /* 1 */
-    int smooth_radius;   /* 30 */
+    int smooth_radius;   /* 30.  >= 1 is the reference's filter; 0 (where gram_sg's weights divide by zero) is defined here as
+                            "no smoothing": the single weight is 1 and every frame is warped by the identity correction */
     int interpolation;   /* cv::InterpolationFlags: 1 = INTER_LINEAR (the only mode the reference ever passes), 0 = INTER_NEAREST
                             (lens_mode 0, 8-bit BGR output, no read-out rotations); others are refused */
     int smoother;        /* VSTAB_SMOOTHER_SG (reference behaviour) */

@@ -944,6 +944,24 @@ def test_pipeline_degenerate_clips(vs, cuda):
     _check_against_oracle_state_machine(vs, cuda, frames[:1], K, w, h, 3, 5)
 
 
+@pytest.mark.parametrize("env", [{}, {"VSTAB_LK_SEGMENT": "1"}, {"VSTAB_LK_SEGMENT": "3", "VSTAB_PREFETCH": "2"}, {"VSTAB_PREFETCH": "16", "VSTAB_LK_SEG_TARGET": "8"},
+                                 {"VSTAB_CHAIN_LK": "0", "VSTAB_PREFETCH": "1"}])
+def test_every_clip_length_and_radius_against_the_state_machine(vs, cuda, monkeypatch, env):
+    """Clips of 1 .. 26 frames (shorter than, equal to and longer than the look-ahead; across the 21-frame key-frame counter) with
+    smoothing radii 1, 2, 5 (radius 0 has no reference behaviour: gram_sg divides by zero there), under the launch-ahead settings a handle can be created with (frames per tracker launch, read-ahead depth,
+    no launches ahead at all): the end-of-stream padding, the key-frame rule and the tracker segments meet in every combination, and
+    every decision, count, rotation and pixel has to be the oracle state machine's."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    w, h = 322, 182
+    K = oracle.get_preset_camera(4, w, h)
+    frames, _ = synth.shaky_clip(17, K, w, h, 26, sigma=0.004)
+    lengths = [1, 2, 3, 4, 5, 6, 9, 21, 22, 23, 26] if not env else [1, 2, 5, 9, 22, 26]
+    for r in (1, 2, 5):
+        for n in lengths:
+            _check_against_oracle_state_machine(vs, cuda, frames[:n], K, w, h, r, 100 + n)
+
+
 def test_pull_into_host_memory_equals_device_pull(vs, cuda, clip):
     import torch
     K, frames, _ = clip
