@@ -16,7 +16,7 @@ alone = bool(int(os.environ.get("LK_ALONE", "0")))   # 1: pull without the warp'
 stab = vs.Stabilizer(clip, total=5000, preset=4, smooth_radius=30, seed=1234)
 outs = [torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(8)]
 for i in range(600): assert stab.pull_into(outs[i % 8])
-buf = torch.zeros((64, 256, 16), dtype=torch.int64, device=dev)
+buf = torch.zeros((64, 256, 32), dtype=torch.int64, device=dev)
 vs._L.vstab_dev_set_lk_timing.argtypes = [ctypes.c_void_p]
 vs._L.vstab_dev_set_lk_timing(ctypes.c_void_p(buf.data_ptr()))
 for i in range(48): assert stab.pull_into(outs[i % 8])
@@ -48,3 +48,21 @@ for L in range(64):
         r = t[L][live[L]]
         d = us(r[:, 15].max() - r[:, 0].min())
         print(f"  launch {L}: {int(live[L].sum())} features, span {d:.1f} us, slowest feature {us(r[:, 15] - r[:, 0]).max():.1f} us, median feature {np.median(us(r[:, 15] - r[:, 0])):.1f}") if L % 8 == 0 else None
+
+# sub-phase stamps of the development build (slots 16 .. 31): pair index inside the segment, blocks fetched ahead that were used, and per
+# level the barrier at its top and the end of the fetch code
+if rows.shape[1] >= 32:
+    fi = rows[:, 16]
+    for sel, name in ((fi == 0, "first pair of a segment"), (fi > 0, "later pairs")):
+        r = rows[sel]
+        if not len(r): continue
+        print(f"{name}: {len(r)} feature-frames, median {np.median(us(r[:, 15] - r[:, 0])):.1f} us; staging {np.median(us(r[:, 2] - r[:, 1])):.2f}; "
+              f"top neighbourhood ahead used {int((r[:, 17].astype(np.int64) & 1).sum())}, top block ahead {int(((r[:, 17].astype(np.int64) >> 1) & 1).sum())}")
+        prev = r[:, 2]
+        for i, lvl in enumerate((3, 2, 1, 0)):
+            a, b = r[:, 3 + 3 * i], r[:, 4 + 3 * i]
+            bar, fetch, ahead = r[:, 18 + 3 * i], r[:, 19 + 3 * i], r[:, 20 + 3 * i]
+            ok = (a != 0) & (bar != 0)
+            print(f"   level {lvl}: previous level end -> barrier passed {np.median(us(bar - prev)[ok]):.2f}, fetch code {np.median(us(fetch - bar)[ok]):.2f}, "
+                  f"-> iterations start {np.median(us(a - fetch)[ok]):.2f}; finer block ahead used {int(ahead[ok].sum())} of {int(ok.sum())}")
+            prev = np.where(b != 0, b, prev)

@@ -680,6 +680,20 @@ __device__ __forceinline__ int lk_div21(int k) { return __mul24(k, 3121) >> 16; 
 // part so that every wave sum stays inside int32; hi * 65536 + lo is exact in double and the one double -> float
 // conversion equals (float)(int64 total).
 constexpr int LK_THREADS = 256, LK_WAVES = 4;
+constexpr int LK_WPAD = (LKW * LKW + 63) & ~63;  // window pixels rounded up to whole waves
+
+// The 2 x 2 matrix of a level from the exact sums of Ix Ix, Ix Iy, Iy Iy (as floats): A11, A12, A22, 1 / D and whether the level is
+// rejected (minEig < 1e-4 or D < FLT_EPSILON), in the reference's float operation order.  Evaluated by whoever prepared the level --
+// for the lower levels a wave in the shadow of the top level's iterations -- so that the square root and the two divisions are not
+// on the iterating wave's dependent chain; the same instructions give the same bits wherever they run.
+__device__ __forceinline__ void lk_level_matrix(float s0, float s1, float s2, float *out) {
+    const float FLT_SCALE = 1.0f / (1 << 20);
+    const float A11 = s0 * FLT_SCALE, A12 = s1 * FLT_SCALE, A22 = s2 * FLT_SCALE;
+    const float D = A11 * A22 - A12 * A12;
+    const float minEig = ((A22 + A11) - sqrtf((A11 - A22) * (A11 - A22) + (4.f * A12) * A12)) / (float)(2 * LKW * LKW);
+    out[0] = A11, out[1] = A12, out[2] = A22, out[3] = 1.f / D;
+    out[4] = minEig < 1e-4f || D < 1.1920928955078125e-7f ? 1.0f : 0.0f;
+}
 
 // The 2 * NQ wave reductions advance in lockstep: every DPP step is applied to all of them before the next one, so the
 // two wait states a DPP read needs behind the write of its source are filled by the other chains instead of s_nop
@@ -729,6 +743,32 @@ struct LkStage {
             }
         }
     }
+    // a block that lies inside the image (the caller checked): no border handling, a handful of instructions per dword
+    __device__ __forceinline__ void load_interior(const uint8_t *img, uint32_t pitch, int x0, int y0, int tid) {
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const int e = min(tid + THREADS * k, NW - 1);  // (a thread past the end loads the last dword again and never stores it)
+            const int ry = e / ROWW, rx = 4 * (e - ry * ROWW);
+            __builtin_memcpy(&v[k], img + __umul24((uint32_t)(y0 + ry), pitch) + (uint32_t)(x0 + rx), 4);
+        }
+    }
+    // the OUT x OUT window of the block whose corner sits at (dx, dy) of it, as a row-major OUT x OUT int array (the window's place in the
+    // block is only known after the block was fetched: the previous-image neighbourhoods fetched ahead, k_lk_track)
+    template <int OUT>
+    __device__ __forceinline__ void store_window(int *dst, int tid, int dx, int dy) const {
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const int e = tid + THREADS * k;
+            const int ry = e / ROWW, rx = 4 * (e - ry * ROWW);
+            const int Y = ry - dy, X = rx - dx;
+            if (e < NW && (unsigned)Y < (unsigned)OUT) {
+                int *o = dst + lk_mul(Y, OUT) + X;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if ((unsigned)(X + i) < (unsigned)OUT) o[i] = (int)((v[k] >> (8 * i)) & 255u);
+            }
+        }
+    }
     __device__ __forceinline__ void store(int *dst, int tid) const {  // dst 16-byte aligned
 #pragma unroll
         for (int k = 0; k < N; k++) {
@@ -763,10 +803,13 @@ extern "C" __attribute__((visibility("default"))) void vstab_dev_set_lk_timing(v
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lk_timing), &p, sizeof(p));
 }
 #define LK_STAMP(k, v) \
-    if (g_lk_timing && tid == 0) g_lk_timing[(((size_t)(seq & 63u) * 256 + (size_t)f) << 4) + (k)] = (v)
+    if (g_lk_timing && tid == 0) g_lk_timing[(((size_t)(seq & 63u) * 256 + (size_t)f) << 5) + (k)] = (v)
+#define LK_STAMP1(k, v) \
+    if (g_lk_timing && tid == 64) g_lk_timing[(((size_t)(seq & 63u) * 256 + (size_t)f) << 5) + (k)] = (v)
 #define LK_NOW() __builtin_amdgcn_s_memrealtime()
 #else
 #define LK_STAMP(k, v)
+#define LK_STAMP1(k, v)
 #define LK_NOW() 0ull
 #endif
 
@@ -777,11 +820,12 @@ extern "C" __attribute__((visibility("default"))) void vstab_dev_set_lk_timing(v
 // lasts as long as the slowest slot's SUM over the frames instead of the sum over the frames of each frame's slowest slot, and
 // the gap between launches is paid once per segment.  Results leave per frame pair (host_rec[i], dev_rec[i]) as soon as the
 // slot has them.  A slot that loses its feature reports status 0 for that pair and status 2 ("lost earlier") for the rest.
-__global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
+__global__ void __launch_bounds__(LK_THREADS, 3) k_lk_track(LkSegArgs args) {
     __shared__ __attribute__((aligned(16))) int regI[LK_MAX_LEVELS][LKR * LKR];
     __shared__ uint32_t dpk[LK_MAX_LEVELS][LKT * LKT];     // Scharr derivative pairs of the 22 x 22 taps: dx | dy << 16 (int16 each)
-    __shared__ short patch[LK_MAX_LEVELS][3][LKW * LKW];   // the interpolated window of every level: I, Ix, Iy
-    __shared__ float patch_sums[LK_MAX_LEVELS][4];         // exact sums of Ix Ix, Ix Iy, Iy Iy over the window, as float
+    __shared__ short patch_i[LK_MAX_LEVELS][LK_WPAD];      // the interpolated window of every level: I ...
+    __shared__ uint32_t patch_xy[LK_MAX_LEVELS][LK_WPAD];  // ... and Ix | Iy << 16 (int16 each), as the iterations hold them in registers
+    __shared__ float level_mat[LK_MAX_LEVELS][8];          // A11, A12, A22, 1 / D of the level's 2 x 2 matrix and its rejection flag (lk_level_matrix)
     __shared__ __attribute__((aligned(16))) int regJ[2][LKJR * LKJR];
     // (wave as a scalar: what is indexed with it -- the pyramid level a wave prepares -- is then read with scalar loads from the
     // kernel arguments instead of per-lane global loads, each of which was a memory latency inside the dependent chain)
@@ -834,6 +878,21 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
     }
     __shared__ float s_result[4];  // wave 0 -> all: the point the frame pair ended on and its status
     __shared__ float s_est[2][2];  // wave 0 -> all, by level parity: where the feature stands in the next image after that level
+    // Fetched AHEAD, during the last level of a frame pair, for the NEXT pair of the segment -- by waves 1 - 3, in the shadow of wave 0's
+    // iterations; the dwords wait in registers: (a) the previous-image neighbourhoods of all levels -- blocks of the current next image
+    // around where the feature stands now, wide enough (32 x 32 for a 24 x 24 neighbourhood) to hold the neighbourhood of the point the
+    // pair finally ends on: the top level's by the three waves together (it is needed first), every lower level's by the wave that will
+    // prepare that level (it alone writes the neighbourhood to LDS, right before it reads it) -- and (b) the next-image blocks of all
+    // levels around the position PREDICTED there: this pair's end plus this pair's motion.  Without them a pair began with one exposed
+    // memory latency (2.2 - 2.9 of a feature's 18 us in the 4K pipeline).  A block that turns out not to hold what is needed -- the
+    // motion changed by more than the slack -- is fetched again as before.  Where a block sits never changes a value: it holds image
+    // bytes either way.  The origins travel through LDS (s_pf), so that wave 0 spends no instruction on any of it.
+    LkStage<LKJR, LK_THREADS - 64> pfIt, pfJt;
+    LkStage<LKJR, 64> pfIo;
+    constexpr int PF_NONE = INT_MIN / 2;
+    constexpr int PF_SLACK = (LKJR - LKR) / 2;  // 4 pixels each side
+    __shared__ int s_pf[LK_MAX_LEVELS][4];      // origins of the blocks fetched ahead: neighbourhood x, y, next-image block x, y (PF_NONE: no block)
+    __shared__ int s_jorg[2][2];                // waves 1 - 3 -> wave 0, by buffer: origin of the next-image block staged for the coming level
 #pragma unroll 1
     for (int fi = 0; fi < args.n_frames; fi++) {
     const LkPyramid &I = args.pyr[fi], &J = args.pyr[fi + 1];
@@ -843,37 +902,58 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
     float2 np = make_float2(0.f, 0.f);
     int st = 1;
     const int max_level = I.levels - 1;
-    // Everything whose address is known now is loaded now, in one exposed latency: the previous-image neighbourhood
-    // of EVERY level (it depends on the feature position only) and the top level's next-image block.  The block of
-    // each lower level is fetched one level ahead, while the level above computes, around the zero-flow position;
-    // if the Gauss-Newton window ends up outside it, the block is staged again around the window (as before).
-    // Where a block is staged never changes a value: it holds image bytes either way.
+    // What was not fetched ahead (the first pair of a launch; a block that does not hold what is needed) is loaded now, in one
+    // exposed latency: the previous-image neighbourhood of EVERY level (it depends on the feature position only) and the top
+    // level's next-image block.  The block of each lower level is fetched one level ahead, while the level above computes, around
+    // the position the feature is expected at; if the Gauss-Newton window ends up outside it, the block is staged again around
+    // the window.
     int jb = 0;                                   // regJ[jb] holds the block staged for the level about to run
-    int jorg_x = INT_MIN / 2, jorg_y = INT_MIN / 2;  // its origin (none yet)
+    int jorg_x = PF_NONE, jorg_y = PF_NONE;       // its origin (none yet)
+    int own_dx = -1, own_dy = -1;  // waves 1 - 3: the neighbourhood of the level this wave prepares lies in pfIo, at this offset
     {
         LkStage<LKR> si[LK_MAX_LEVELS];
         LkStage<LKJR> sj;
-        bool iok[LK_MAX_LEVELS];
+        bool iok[LK_MAX_LEVELS];  // the level's neighbourhood is loaded now
+        int top_dx = -1, top_dy = -1;
+        bool top_ahead = false;
 #pragma unroll
         for (int l = 0; l < LK_MAX_LEVELS; l++) {
             iok[l] = false;
             if (l > max_level) continue;
+            int ax = PF_NONE, ay = PF_NONE;
+            if (fi) ax = __builtin_amdgcn_readfirstlane(s_pf[l][0]), ay = __builtin_amdgcn_readfirstlane(s_pf[l][1]);  // (published by the previous pair's last level)
             const float lscale = lk_level_scale(l);
             const int ipx = (int)floorf(pp.x * lscale - half), ipy = (int)floorf(pp.y * lscale - half);
             if (ipx < -LKW || ipx >= I.w[l] || ipy < -LKW || ipy >= I.h[l]) continue;  // the level loop skips it too
-            iok[l] = true;
-            si[l].load(I.img[l], (uint32_t)I.pitch[l], I.w[l], I.h[l], ipx - 1, ipy - 1, tid);
+            const int dx = ipx - 1 - ax, dy = ipy - 1 - ay;  // (huge without a block)
+            if ((unsigned)dx <= (unsigned)(2 * PF_SLACK) && (unsigned)dy <= (unsigned)(2 * PF_SLACK)) {
+                if (l == max_level) top_dx = dx, top_dy = dy;
+                else if (l == max_level - wave) own_dx = dx, own_dy = dy;
+            } else {
+                iok[l] = true;
+                si[l].load(I.img[l], (uint32_t)I.pitch[l], I.w[l], I.h[l], ipx - 1, ipy - 1, tid);
+            }
             if (l == max_level) {  // the top level starts at the feature position itself
-                jorg_x = ipx - LKJM, jorg_y = ipy - LKJM;
-                sj.load(J.img[l], (uint32_t)J.pitch[l], I.w[l], I.h[l], jorg_x, jorg_y, tid);
+                int bx = PF_NONE, by = PF_NONE;
+                if (fi) bx = __builtin_amdgcn_readfirstlane(s_pf[l][2]), by = __builtin_amdgcn_readfirstlane(s_pf[l][3]);
+                if (ipx - 2 >= bx && ipy - 2 >= by && ipx + LKT + 2 <= bx + LKJR && ipy + LKT + 2 <= by + LKJR) {
+                    jorg_x = bx, jorg_y = by, top_ahead = true;
+                } else {
+                    jorg_x = ipx - LKJM, jorg_y = ipy - LKJM;
+                    sj.load(J.img[l], (uint32_t)J.pitch[l], I.w[l], I.h[l], jorg_x, jorg_y, tid);
+                }
             }
         }
 #pragma unroll
         for (int l = 0; l < LK_MAX_LEVELS; l++)
             if (iok[l]) si[l].store(regI[l], tid);
-        if (jorg_x != INT_MIN / 2) sj.store(regJ[0], tid);
+        if (top_ahead && wave != 0) pfJt.store(regJ[0], tid - 64);
+        if (top_dx >= 0 && wave != 0) pfIt.template store_window<LKR>(regI[max_level], tid - 64, top_dx, top_dy);
+        if (jorg_x != PF_NONE && !top_ahead) sj.store(regJ[0], tid);
+        LK_STAMP(17, (unsigned long long)((top_dx >= 0 ? 1 : 0) | (top_ahead ? 2 : 0)));
     }
     LK_STAMP(2, LK_NOW());
+    LK_STAMP(16, (unsigned long long)fi);
     // ---- the previous image's side of every level: derivatives, interpolated window (I, Ix, Iy), sums of the 2 x 2 matrix ---------
     // They depend on the feature's position in the previous image only -- not on anything the Gauss-Newton iterations produce.
     // The TOP level is needed first: all four waves prepare it together (two derivative taps and two window pixels per lane, the
@@ -930,7 +1010,7 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
                                              lk_mul((int)(short)(d10 & 0xffffu), g.iw10) + lk_mul((int)(short)(d11 & 0xffffu), g.iw11), 14);
             const int iyval = LK_DESCALE(lk_mul((int)d00 >> 16, g.iw00) + lk_mul((int)d01 >> 16, g.iw01) + lk_mul((int)d10 >> 16, g.iw10) +
                                              lk_mul((int)d11 >> 16, g.iw11), 14);
-            patch[l][0][k] = (short)ival, patch[l][1][k] = (short)ixval, patch[l][2][k] = (short)iyval;
+            patch_i[l][k] = (short)ival, patch_xy[l][k] = ((uint32_t)ixval & 0xffffu) | ((uint32_t)iyval << 16);
             pA[0] += lk_mul(ixval, ixval), pA[1] += lk_mul(ixval, iyval), pA[2] += lk_mul(iyval, iyval);
         }
 #pragma unroll
@@ -952,13 +1032,15 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
         }
         __syncthreads();  // the top level's window and sums, the block staged for it: wave 0 can start iterating
         if (tid == 0) {
+            float sums[3];
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 int hi = 0, lo = 0;
 #pragma unroll
                 for (int wv = 0; wv < LK_WAVES; wv++) hi += s_top[wv][2 * q], lo += s_top[wv][2 * q + 1];
-                patch_sums[max_level][q] = (float)__builtin_fma((double)hi, 65536.0, (double)lo);  // (read back by this wave only)
+                sums[q] = (float)__builtin_fma((double)hi, 65536.0, (double)lo);
             }
+            lk_level_matrix(sums[0], sums[1], sums[2], level_mat[max_level]);  // (read back by this wave only)
         }
     }
     for (int level = max_level; level >= 0; level--) {
@@ -970,37 +1052,92 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
         // the block staged for this level, wave 0's estimate after the level above and the level's window are visible (the top level:
         // behind the barrier above)
         if (level != max_level) __syncthreads();
-        // Fetch the next (finer) level's next-image block now (all four waves); it lands while this level iterates.  It is centred on
-        // where the feature is EXPECTED there -- the estimate this level starts from, doubled -- not on the zero-flow position: with
-        // the block around the previous frame's position a frame-to-frame motion of more than LKJM pixels at that level (the 4K bench
-        // clip moves 4 - 12) meant staging the block again inside the iteration loop, a global-memory latency on the dependent chain.
-        // Where a block sits never changes a value: it holds image bytes either way, and a window that leaves it is staged afresh.
-        LkStage<LKJR> sn;
-        int nx0 = INT_MIN / 2, ny0 = INT_MIN / 2;
-        if (level > 0) {
-            const int w1 = I.w[level - 1], h1 = I.h[level - 1];
-            const float ex = level == max_level ? pp.x * lscale : s_est[(level + 1) & 1][0] * 2.0f, ey = level == max_level ? pp.y * lscale : s_est[(level + 1) & 1][1] * 2.0f;
-            const float cx = ex * 2.0f - half, cy = ey * 2.0f - half;
-            if (cx > -(float)(LKW + 1) && cx < (float)w1 && cy > -(float)(LKW + 1) && cy < (float)h1) {  // (false for NaN: a diverged estimate is not chased)
-                nx0 = (int)floorf(cx) - LKJM, ny0 = (int)floorf(cy) - LKJM;
-                sn.load(J.img[level - 1], (uint32_t)J.pitch[level - 1], w1, h1, nx0, ny0, tid);
-            }
-        }
-        if (level == max_level && wave >= 1 && wave <= max_level) {
-            // in the shadow of the top level's iterations: wave w prepares level max_level - w on its own (a wave reads back only
-            // what it wrote itself: LDS operations of one wave execute in order); published by that level's barrier
-            const int l = max_level - wave;
-            const LevelGeom g = level_geom(l);
-            if (g.ok) {
-                level_derivatives(l, g, lane, 64);
-                int t[6];
-                level_window(l, g, lane, 64, t);
-                if (lane == 0) {
+        LK_STAMP(18 + 3 * (max_level - level), LK_NOW());
+        if (wave != 0) {
+            // ---- waves 1 - 3: everything around the iterations, so that the iterating wave spends no instruction on it and never waits
+            // for global memory.
+            // The next (finer) level's next-image block; it lands while this level iterates.  It is centred on where the feature is
+            // EXPECTED there -- the estimate this level starts from, doubled -- not on the zero-flow position: with the block around the
+            // previous frame's position a frame-to-frame motion of more than LKJM pixels at that level (the 4K bench clip moves 4 - 12)
+            // meant staging the block again inside the iteration loop, a global-memory latency on the dependent chain.  The block fetched
+            // ahead for that level (pfJ) serves if it holds the expected window with two pixels to spare.  A window that leaves its block
+            // is staged afresh by wave 0.
+            LkStage<LKJR, LK_THREADS - 64> sn;
+            int nx0 = PF_NONE, ny0 = PF_NONE;
+            if (level > 0) {
+                const int w1 = I.w[level - 1], h1 = I.h[level - 1];
+                const float ex = level == max_level ? pp.x * lscale : s_est[(level + 1) & 1][0] * 2.0f, ey = level == max_level ? pp.y * lscale : s_est[(level + 1) & 1][1] * 2.0f;
+                const float cx = ex * 2.0f - half, cy = ey * 2.0f - half;
+                if (cx > -(float)(LKW + 1) && cx < (float)w1 && cy > -(float)(LKW + 1) && cy < (float)h1) {  // (false for NaN: a diverged estimate is not chased)
+                    nx0 = __builtin_amdgcn_readfirstlane((int)floorf(cx)) - LKJM, ny0 = __builtin_amdgcn_readfirstlane((int)floorf(cy)) - LKJM;
+                    sn.load(J.img[level - 1], (uint32_t)J.pitch[level - 1], w1, h1, nx0, ny0, tid - 64);
+                }
+                if (tid == 64) s_jorg[jb ^ 1][0] = nx0, s_jorg[jb ^ 1][1] = ny0;
+            } else {
+                // the last level of the pair: fetch ahead for the next pair (pfIt / pfIo / pfJ above).  Where the feature stands now: level
+                // 1's result, doubled; its motion in this pair: that minus the pair's start point.
+                const bool ahead = fi + 1 < args.n_frames && max_level >= 1;  // uniform
+                const LkPyramid &J2 = args.pyr[ahead ? fi + 2 : fi + 1];
+                const float e0x = s_est[1][0] * 2.0f, e0y = s_est[1][1] * 2.0f;
+                const float p0x = e0x + (e0x - pp.x), p0y = e0y + (e0y - pp.y);
+                int oix[LK_MAX_LEVELS], oiy[LK_MAX_LEVELS], ojx[LK_MAX_LEVELS], ojy[LK_MAX_LEVELS];
 #pragma unroll
-                    for (int q = 0; q < 3; q++) patch_sums[l][q] = (float)__builtin_fma((double)t[2 * q], 65536.0, (double)t[2 * q + 1]);
+                for (int l = LK_MAX_LEVELS - 1; l >= 0; l--) {  // needed first: the neighbourhoods in what is now the next image, top level first
+                    oix[l] = oiy[l] = PF_NONE;
+                    if (!ahead || l > max_level) continue;
+                    const float ls = lk_level_scale(l);
+                    const float cx = e0x * ls - half, cy = e0y * ls - half;
+                    if (cx > -(float)(LKW + 1) && cx < (float)I.w[l] && cy > -(float)(LKW + 1) && cy < (float)I.h[l]) {
+                        const int ox = __builtin_amdgcn_readfirstlane((int)floorf(cx)) - 1 - PF_SLACK, oy = __builtin_amdgcn_readfirstlane((int)floorf(cy)) - 1 - PF_SLACK;
+                        if (ox >= 0 && oy >= 0 && ox + LKJR <= I.w[l] && oy + LKJR <= I.h[l]) {  // (a block across the image border is left to the pair's own staging)
+                            oix[l] = ox, oiy[l] = oy;
+                            if (l == max_level) pfIt.load_interior(J.img[l], (uint32_t)J.pitch[l], ox, oy, tid - 64);
+                            else if (l == max_level - wave) pfIo.load_interior(J.img[l], (uint32_t)J.pitch[l], ox, oy, lane);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int l = 0; l < LK_MAX_LEVELS; l++) ojx[l] = ojy[l] = PF_NONE;
+                if (ahead) {  // then the top-level block of the image after it, around the predicted position
+                    const float ls = lk_level_scale(max_level);
+                    const float cx = p0x * ls - half, cy = p0y * ls - half;
+                    const int wt = I.w[max_level], ht = I.h[max_level];
+                    if (cx > -(float)(LKW + 1) && cx < (float)wt && cy > -(float)(LKW + 1) && cy < (float)ht) {
+                        const int ox = __builtin_amdgcn_readfirstlane((int)floorf(cx)) - LKJM, oy = __builtin_amdgcn_readfirstlane((int)floorf(cy)) - LKJM;
+                        if (ox >= 0 && oy >= 0 && ox + LKJR <= wt && oy + LKJR <= ht) {
+#pragma unroll
+                            for (int l = 0; l < LK_MAX_LEVELS; l++)
+                                if (l == max_level) ojx[l] = ox, ojy[l] = oy;
+                            pfJt.load_interior(J2.img[max_level], (uint32_t)J2.pitch[max_level], ox, oy, tid - 64);
+                        }
+                    }
+                }
+                if (tid == 64) {
+#pragma unroll
+                    for (int l = 0; l < LK_MAX_LEVELS; l++) s_pf[l][0] = oix[l], s_pf[l][1] = oiy[l], s_pf[l][2] = ojx[l], s_pf[l][3] = ojy[l];
                 }
             }
+            if (level == max_level && wave <= max_level) {
+                // in the shadow of the top level's iterations: wave w prepares level max_level - w on its own (a wave reads back only
+                // what it wrote itself: LDS operations of one wave execute in order); published by that level's barrier
+                const int l = max_level - wave;
+                const LevelGeom g = level_geom(l);
+                if (g.ok) {
+                    if (own_dx >= 0) pfIo.template store_window<LKR>(regI[l], lane, own_dx, own_dy);  // fetched ahead by this wave
+                    level_derivatives(l, g, lane, 64);
+                    int t[6];
+                    level_window(l, g, lane, 64, t);
+                    if (lane == 0)
+                        lk_level_matrix((float)__builtin_fma((double)t[0], 65536.0, (double)t[1]), (float)__builtin_fma((double)t[2], 65536.0, (double)t[3]),
+                                        (float)__builtin_fma((double)t[4], 65536.0, (double)t[5]), level_mat[l]);
+                }
+            }
+            // the finer level's block goes into the other buffer: nobody reads that one now (wave 0 left it before this level's
+            // barrier); the next barrier publishes it
+            if (nx0 != PF_NONE) sn.store(regJ[jb ^ 1], tid - 64);
         }
+        if (wave == 0 && level != max_level) jorg_x = s_jorg[jb][0], jorg_y = s_jorg[jb][1];  // (published by this level's barrier)
+        LK_STAMP(19 + 3 * (max_level - level), LK_NOW());
         if (wave == 0) do {  // one pyramid level on one wave ("break" = the reference's "continue")
             float ppx = pp.x * lscale, ppy = pp.y * lscale;
             float npx, npy;
@@ -1021,21 +1158,16 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
 #pragma unroll
             for (int m = 0; m < LK_PPL; m++) {
                 const int k = lane + 64 * m;
-                const bool have = k < LKW * LKW;
-                const int kk = have ? k : 0;
-                Iw[m] = have ? (int)patch[level][0][kk] : 0;
-                Ixy[m] = have ? (int)(((uint32_t)(uint16_t)patch[level][1][kk]) | ((uint32_t)(uint16_t)patch[level][2][kk] << 16)) : 0;
+                const bool have = k < LKW * LKW;  // (the pad entries of the last row of lanes are never written)
+                Iw[m] = have ? (int)patch_i[level][k] : 0;
+                Ixy[m] = have ? (int)patch_xy[level][k] : 0;
             }
-            const float sA[3] = {patch_sums[level][0], patch_sums[level][1], patch_sums[level][2]};
             const float FLT_SCALE = 1.0f / (1 << 20);
-            const float A11 = sA[0] * FLT_SCALE, A12 = sA[1] * FLT_SCALE, A22 = sA[2] * FLT_SCALE;
-            float D = A11 * A22 - A12 * A12;
-            const float minEig = ((A22 + A11) - sqrtf((A11 - A22) * (A11 - A22) + (4.f * A12) * A12)) / (float)(2 * LKW * LKW);
-            if (minEig < 1e-4f || D < 1.1920928955078125e-7f) {
+            const float A11 = level_mat[level][0], A12 = level_mat[level][1], A22 = level_mat[level][2], D = level_mat[level][3];
+            if (level_mat[level][4] != 0.0f) {  // minEig < 1e-4 || D < FLT_EPSILON
                 if (level == 0) st = 0;
                 break;
             }
-            D = 1.f / D;
             npx -= half, npy -= half;
             float pdx = 0.f, pdy = 0.f;
             LK_STAMP(3 + 3 * (max_level - level), LK_NOW());
@@ -1091,14 +1223,10 @@ __global__ void __launch_bounds__(LK_THREADS, 4) k_lk_track(LkSegArgs args) {
             }
         } while (false);
         if (tid == 0) s_est[level & 1][0] = np.x, s_est[level & 1][1] = np.y;  // (a skipped level leaves np at its start value, as the reference does)
-        // the block fetched for the next level goes into the other buffer: nobody reads that one now (wave 0 left it before this
-        // level's barrier), so waves 1 - 3 store at once and wave 0 when its iterations are over; the next barrier publishes it
         LK_STAMP(4 + 3 * (max_level - level), LK_NOW());
         LK_STAMP(5 + 3 * (max_level - level), (unsigned long long)n_iter);
         (void)n_iter;  // read by the development build's stamps only
         jb ^= 1;
-        jorg_x = nx0, jorg_y = ny0;
-        if (nx0 != INT_MIN / 2) sn.store(regJ[jb], tid);
     }
     // wave 0 holds the result: hand it to the other waves (the next frame pair starts from it; a lost slot ends here)
     if (tid == 0) s_result[0] = np.x, s_result[1] = np.y, s_result[2] = __int_as_float(st);
