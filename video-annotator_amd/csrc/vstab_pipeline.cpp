@@ -82,6 +82,11 @@ struct PinnedBuf {  // host memory the device can read and write directly (mappe
 // ---------------------------------------------------------------------------------------------
 constexpr int PREFETCH_MAX = 16;             // upper bound of the read-ahead (the ring and the pyramid sets are sized for it)
 constexpr int PYR_SETS = PREFETCH_MAX + 2;  // previous + current (in flight) + the prefetched frames
+#ifdef VSTAB_DEV
+constexpr int PYR_DEV_EXTRA = 1;  // a set nobody reads: VSTAB_DEV_PYR_TWICE=1 builds every pyramid a second time into it (sensitivity of the frame rate to the pyramid kernels)
+#else
+constexpr int PYR_DEV_EXTRA = 0;
+#endif
 // frames pulled from upstream ahead of the one being tracked: deep enough that the speculative corner detection of a
 // key frame (137 us of kernels beside everything else + the host selection) is finished before its turn comes
 constexpr int PREFETCH_DEPTH = 8;  // default; VSTAB_PREFETCH=n (1 .. PREFETCH_MAX) for experiments
@@ -98,7 +103,7 @@ class Tracker {
         for (int l = 1; l < levels_; l++) {
             lw = (lw + 1) / 2, lh = (lh + 1) / 2;
             lvl_w_[l] = lw, lvl_h_[l] = lh;
-            for (int s = 0; s < PYR_SETS; s++) VSTAB_TRY(pyr_[s][l].ensure((size_t)lw * lh));
+            for (int s = 0; s < PYR_SETS + PYR_DEV_EXTRA; s++) VSTAB_TRY(pyr_[s][l].ensure((size_t)lw * lh));
         }
         lvl_w_[0] = w, lvl_h_[0] = h;
         VSTAB_TRY(small_.ensure(256));
@@ -115,16 +120,26 @@ class Tracker {
     }
 
     // levels 1.. of the pyramid of `gray` into slot s (level 0 is the frame itself)
-    vstab_status build_pyramid(int s, const uint8_t *gray, size_t pitch, hipStream_t st) {
+    // `done` (optional) completes with the LAST kernel of the pyramid, bound to that launch (launch_pyr_down); *done_bound says whether a kernel
+    // took it (an image too small for a second level has no pyramid kernel: the caller records the event itself)
+    vstab_status build_pyramid(int s, const uint8_t *gray, size_t pitch, hipStream_t st, hipEvent_t done = nullptr, bool *done_bound = nullptr) {
+#ifdef VSTAB_DEV
+        static const bool twice = getenv("VSTAB_DEV_PYR_TWICE") != nullptr;
+        if (twice && s != PYR_SETS) VSTAB_TRY(build_pyramid(PYR_SETS, gray, pitch, st));
+#endif
         const uint8_t *src = gray;
         size_t sp = pitch;
+        if (done_bound) *done_bound = false;
         for (int l = 1; l < levels_; l++) {
             // levels 2 and 3 in ONE launch (k_pyr_down_x2): as kernels of their own the small levels are launch- and latency-bound
             if (l == 2 && levels_ == 4 && pyr_down_x2_ok(lvl_w_[1], lvl_h_[1]) && !single_level_pyramid_) {
-                VSTAB_TRY(launch_pyr_down_x2(src, sp, lvl_w_[1], lvl_h_[1], pyr_[s][2].as<uint8_t>(), (size_t)lvl_w_[2], pyr_[s][3].as<uint8_t>(), (size_t)lvl_w_[3], st));
+                VSTAB_TRY(launch_pyr_down_x2(src, sp, lvl_w_[1], lvl_h_[1], pyr_[s][2].as<uint8_t>(), (size_t)lvl_w_[2], pyr_[s][3].as<uint8_t>(), (size_t)lvl_w_[3], st, done));
+                if (done_bound) *done_bound = done != nullptr;
                 break;
             }
-            VSTAB_TRY(launch_pyr_down(src, sp, lvl_w_[l - 1], lvl_h_[l - 1], pyr_[s][l].as<uint8_t>(), (size_t)lvl_w_[l], st));
+            const bool last = l == levels_ - 1;
+            VSTAB_TRY(launch_pyr_down(src, sp, lvl_w_[l - 1], lvl_h_[l - 1], pyr_[s][l].as<uint8_t>(), (size_t)lvl_w_[l], st, last ? done : nullptr));
+            if (last && done_bound) *done_bound = done != nullptr;
             src = pyr_[s][l].as<uint8_t>(), sp = (size_t)lvl_w_[l];
         }
         return VSTAB_OK;
@@ -200,6 +215,9 @@ class Tracker {
         if (!eig_out && !two_pass_detector_) {
             // one pass: eigenvalue, threshold and 3x3 maximum test fused, the eigenvalue map never stored
             VSTAB_TRY(raw_keys_.ensure(corners_fused_scratch_bytes(w_, h_)));
+#ifdef VSTAB_DEV
+            if (getenv("VSTAB_DEV_DET_TWICE")) VSTAB_TRY(launch_corners_fused(gray, pitch, w_, h_, quality, raw_keys_.p, keys_.as<unsigned long long>(), cap_, small_.as<unsigned int>(), st));
+#endif
             VSTAB_TRY(launch_corners_fused(gray, pitch, w_, h_, quality, raw_keys_.p, keys_.as<unsigned long long>(), cap_, small_.as<unsigned int>(), st));
             VSTAB_HIP_TRY(hipMemcpyAsync(hsmall_.p, count, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
             VSTAB_HIP_TRY(hipStreamSynchronize(st));
@@ -247,6 +265,10 @@ class Tracker {
         VSTAB_TRY(spec_host_.ensure(64 + sizeof(unsigned long long) * SPEC_CAP));
         if (!spec_ev_) VSTAB_HIP_TRY(hipEventCreateWithFlags(&spec_ev_, hipEventDisableTiming));
         unsigned int *count = spec_small_.as<unsigned int>() + 4;
+#ifdef VSTAB_DEV
+        static const bool det_twice = getenv("VSTAB_DEV_DET_TWICE") != nullptr;  // sensitivity of the frame rate to the detector: everything twice, same result
+        if (det_twice) VSTAB_TRY(launch_corners_fused(gray, pitch, w_, h_, quality, spec_raw_.p, spec_keys_.as<unsigned long long>(), SPEC_CAP, spec_small_.as<unsigned int>(), st));
+#endif
         VSTAB_TRY(launch_corners_fused(gray, pitch, w_, h_, quality, spec_raw_.p, spec_keys_.as<unsigned long long>(), SPEC_CAP, spec_small_.as<unsigned int>(), st));
         VSTAB_HIP_TRY(hipMemcpyAsync(spec_host_.p, count, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));  // {keys kept, tiles that spilled}
         VSTAB_HIP_TRY(hipMemcpyAsync(spec_host_.as<uint8_t>() + 64, spec_keys_.p, sizeof(unsigned long long) * SPEC_CAP, hipMemcpyDeviceToHost, st));
@@ -493,7 +515,7 @@ class Tracker {
 
     int w_ = 0, h_ = 0, levels_ = 1;
     int lvl_w_[LK_MAX_LEVELS] = {0}, lvl_h_[LK_MAX_LEVELS] = {0};
-    DevBuf pyr_[PYR_SETS][LK_MAX_LEVELS], eig_, keys_, small_;  // pyramid sets: previous, current, prefetched x2
+    DevBuf pyr_[PYR_SETS + PYR_DEV_EXTRA][LK_MAX_LEVELS], eig_, keys_, small_;  // pyramid sets: previous, current, prefetched x2
     DevBuf spec_raw_, spec_keys_, spec_small_, raw_keys_;
     bool two_pass_detector_ = false;
     const bool single_level_pyramid_ = getenv("VSTAB_PYR_SINGLE") != nullptr;  // development: one launch per pyramid level
@@ -1094,8 +1116,11 @@ static vstab_status prefetch_next(vstab_handle *H) {
     if (H->cfg.tracking) {
         HT t(HostTimers::PYRAMID);
         GpuStage gs(H, vstab_handle::ST_PYRAMID);
-        VSTAB_TRY(H->tracker.build_pyramid(pyr, H->gray(slot), H->gpitch(slot), H->pstream));
-        VSTAB_HIP_TRY(hipEventRecord(H->slots[slot].ingested, H->pstream));  // copy AND pyramid of this frame
+        // `ingested` = copy AND pyramid of this frame: the event completes with the pyramid's last kernel (no marker packet on the stream)
+        static const bool bind_event = getenv("VSTAB_PYR_EVENT_RECORD") == nullptr;  // development: =1 records the event behind the kernels instead
+        bool bound = false;
+        VSTAB_TRY(H->tracker.build_pyramid(pyr, H->gray(slot), H->gpitch(slot), H->pstream, bind_event ? H->slots[slot].ingested : nullptr, &bound));
+        if (!bound) VSTAB_HIP_TRY(hipEventRecord(H->slots[slot].ingested, H->pstream));
     }
     // Key-frame rule, counter half (:415): the frame after this one re-detects corners on THIS frame when
     // (index + 1) - last_key > 20.  That is known now, so the detector runs here, on the prefetch stream,

@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <climits>
 
+#include <hip/hip_ext.h>
+
 #include "vstab_internal.hpp"
 #include "vstab_track.hpp"
 
@@ -1257,8 +1259,11 @@ __global__ void __launch_bounds__(LK_THREADS, 3) k_lk_track(LkSegArgs args) {
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
+// `done` (optional): an event that completes with this kernel -- bound to the launch itself (hipExtLaunchKernelGGL's stop event), so that the
+// stream carries no marker packet of its own behind the kernel: a hipEventRecord after every frame's pyramid cost the prefetch stream ~6 us
+// per frame (rocprofv3 kernel trace: the next frame's first kernel started 6.5 us after this frame's last one ended, 0.0 us between two kernels)
 vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *dst, size_t dpitch,
-                             hipStream_t s) {
+                             hipStream_t s, hipEvent_t done) {
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
     // the kernel forms row offsets as 32-bit products
     if ((uint64_t)spitch * (uint64_t)sh >= (1ull << 32) || (uint64_t)dpitch * (uint64_t)dh >= (1ull << 32))
@@ -1270,8 +1275,8 @@ vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, 
     const int g_lo = 1, g_hi = vec_ok && near ? std::max(g_lo, std::min(sw >= 12 ? (sw - 12) / 8 + 1 : 0, dw / 4)) : g_lo;
     const int nbx = div_up(g_hi - g_lo, 64), nb_int = nbx * div_up(dh, 4);
     const int nb_edge = div_up(dh * (n_groups - (g_hi - g_lo)), 256);
-    hipLaunchKernelGGL(k_pyr_down, dim3(nb_edge + nb_int), dim3(256), 0, s, src, spitch, sw, sh, dst, dpitch, dw, dh, vec_ok, g_lo, g_hi, nbx, nb_edge, n_groups,
-                       near);
+    hipExtLaunchKernelGGL(k_pyr_down, dim3(nb_edge + nb_int), dim3(256), 0, s, nullptr, done, 0, src, spitch, sw, sh, dst, dpitch, dw, dh, vec_ok, g_lo, g_hi, nbx, nb_edge,
+                          n_groups, near);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }
@@ -1279,14 +1284,15 @@ vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, 
 // Two levels in one launch (k_pyr_down_x2): mid = pyrDown(src), dst = pyrDown(mid).  Needs an image a reflected tap never leaves
 // twice (>= 4 x 4 at the middle level); the caller falls back to two single-level launches otherwise.
 bool pyr_down_x2_ok(int sw, int sh) { return (sw + 1) / 2 >= 8 && (sh + 1) / 2 >= 8; }
-vstab_status launch_pyr_down_x2(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *mid, size_t mpitch, uint8_t *dst, size_t dpitch, hipStream_t s) {
+vstab_status launch_pyr_down_x2(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *mid, size_t mpitch, uint8_t *dst, size_t dpitch, hipStream_t s,
+                                hipEvent_t done) {
     const int mw = (sw + 1) / 2, mh = (sh + 1) / 2, dw = (mw + 1) / 2, dh = (mh + 1) / 2;
     if (!pyr_down_x2_ok(sw, sh)) return fail(VSTAB_ERR_INVALID, "pyr_down_x2: image too small");
     if ((uint64_t)spitch * (uint64_t)sh >= (1ull << 32) || (uint64_t)mpitch * (uint64_t)mh >= (1ull << 32) || (uint64_t)dpitch * (uint64_t)dh >= (1ull << 32))
         return fail(VSTAB_ERR_INVALID, "pyr_down_x2: planes of 4 GiB or more are not supported");
     const int vec_ok = reinterpret_cast<uintptr_t>(src) % 4 == 0 && spitch % 4 == 0 && reinterpret_cast<uintptr_t>(mid) % 4 == 0 && mpitch % 4 == 0;
-    hipLaunchKernelGGL(k_pyr_down_x2, dim3(div_up(dw, P2_TW), div_up(dh, P2_TH)), dim3(256), 0, s, src, (uint32_t)spitch, sw, sh, mid, (uint32_t)mpitch, mw, mh, dst,
-                       (uint32_t)dpitch, dw, dh, vec_ok);
+    hipExtLaunchKernelGGL(k_pyr_down_x2, dim3(div_up(dw, P2_TW), div_up(dh, P2_TH)), dim3(256), 0, s, nullptr, done, 0, src, (uint32_t)spitch, sw, sh, mid,
+                          (uint32_t)mpitch, mw, mh, dst, (uint32_t)dpitch, dw, dh, vec_ok);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }

@@ -28,10 +28,12 @@ inline int lk_levels(int w, int h) {
     return n;
 }
 
-vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *dst, size_t dpitch, hipStream_t s);
+// done (optional): an event that completes with the kernel, bound to the launch itself (no marker packet of its own on the stream)
+vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *dst, size_t dpitch, hipStream_t s, hipEvent_t done = nullptr);
 // two levels in one launch: mid = pyrDown(src) ((sw+1)/2 x (sh+1)/2), dst = pyrDown(mid); only where pyr_down_x2_ok(sw, sh)
 bool pyr_down_x2_ok(int sw, int sh);
-vstab_status launch_pyr_down_x2(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *mid, size_t mpitch, uint8_t *dst, size_t dpitch, hipStream_t s);
+vstab_status launch_pyr_down_x2(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *mid, size_t mpitch, uint8_t *dst, size_t dpitch, hipStream_t s,
+                                hipEvent_t done = nullptr);
 vstab_status launch_min_eig(const uint8_t *src, size_t pitch, int w, int h, float *eig, int *max_bits, hipStream_t s);
 vstab_status launch_corner_candidates(const float *eig, int w, int h, const int *max_bits, double quality,
                                       unsigned long long *keys, unsigned int *count, unsigned int cap, hipStream_t s);
