@@ -45,12 +45,12 @@ def test_pyr_down_size_sweep_and_unaligned_views(vs, cuda):
 
 def test_pyr_down_two_levels_in_one_launch(vs, cuda):
     """vstab_pyr_down_x2 (levels 2 and 3 of the LK pyramid in one launch): both levels equal two pyrDown calls of the oracle --
-    the pipeline's level sizes (1920x1080 and 960x540 are what a 4K / 1080p frame hands it), every residue of the 28 x 24 /
-    14 x 12 tile sizes, odd sizes, images smaller than a tile, the smallest ones (which fall back to two launches), views whose
+    the pipeline's level sizes (1920x1080 and 960x540 are what a 4K / 1080p frame hands it), every residue of the tile sizes,
+    odd sizes, images smaller than a tile, the smallest ones (which fall back to two launches), views whose
     base or pitch is not 4-byte aligned."""
     rng = np.random.default_rng(12)
     sizes = [(1920, 1080), (960, 540), (640, 360), (333, 181), (57, 49), (56, 48), (55, 47), (29, 25), (28, 24), (27, 23), (16, 16), (15, 15), (9, 7), (5, 3)]
-    sizes += [(w, 33) for w in range(100, 130)] + [(61, h) for h in range(40, 66)]
+    sizes += [(w, 33) for w in range(100, 196)] + [(61, h) for h in range(40, 124)]   # every residue of the 16 x 10 tile (64 x 40 source pixels) and of the former 14 x 12
     for w, h in sizes:
         img = synth.luma(w + h, w, h) if w >= 320 else rng.integers(0, 256, (h, w), dtype=np.uint8)
         mid, dst = vs.pyr_down_x2(dev(img, cuda))

@@ -52,11 +52,31 @@ __device__ __forceinline__ uint32_t load4_reflect(const uint8_t *__restrict__ sr
 // =============================================================================================
 __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
 
-// outputs x0 .. x0+3 of row y.  EDGE = false: the 16-byte window lies inside the row and everything is dword aligned.
+// Four adjacent outputs from the five 16-byte row segments that hold their taps (output c uses bytes 2c+2 .. 2c+6 of a segment), packed into
+// one dword: the weight dword of row j holds k_j * (1 4 6 4 1) at the byte positions of the taps, two dot products per output and row.
+__device__ __forceinline__ uint32_t pyr_down_dot4x4(const uint32_t (&d)[5][4]) {
+    uint32_t acc[4] = {128u, 128u, 128u, 128u};
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const uint32_t k = j == 0 || j == 4 ? 1u : j == 2 ? 6u : 4u;
+        // weight dwords (byte 0 = lowest address): taps 1 4 | 6 4 1 split over two dwords, or 1 4 6 4 | 1
+        const uint32_t w_hi2 = (k << 16) | (4 * k << 24);          // (0, 0, k, 4k)
+        const uint32_t w_lo3 = 6 * k | (4 * k << 8) | (k << 16);   // (6k, 4k, k, 0)
+        const uint32_t w_all = k | (4 * k << 8) | (6 * k << 16) | (4 * k << 24);  // (k, 4k, 6k, 4k)
+        acc[0] = udot4(d[j][1], w_lo3, udot4(d[j][0], w_hi2, acc[0]));
+        acc[1] = udot4(d[j][2], k, udot4(d[j][1], w_all, acc[1]));
+        acc[2] = udot4(d[j][2], w_lo3, udot4(d[j][1], w_hi2, acc[2]));
+        acc[3] = udot4(d[j][3], k, udot4(d[j][2], w_all, acc[3]));
+    }
+    // result byte c = bits 8..15 of acc[c] (sum + 128 <= 255 * 256 + 128 < 2^16)
+    const uint32_t p01 = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0501u), p23 = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0501u);
+    return __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+}
+
+// outputs x0 .. x0+3 of row y, packed.  EDGE = false: the 16-byte window lies inside the row and everything is dword aligned.
 // NEAR: sw >= 16 and sh >= 4, so that every tap is within one reflection of the image.
 template <bool EDGE, bool NEAR>
-__device__ __forceinline__ void pyr_down_group(const uint8_t *__restrict__ src, uint32_t spitch, int sw, int sh, uint8_t *__restrict__ dst, size_t dpitch,
-                                               int dw, int x0, int y, bool vec_ok) {
+__device__ __forceinline__ uint32_t pyr_down_group4(const uint8_t *__restrict__ src, uint32_t spitch, int sw, int sh, int x0, int y, bool vec_ok) {
     const int sx0 = 2 * x0 - 4;  // the 16 bytes [sx0, sx0+16) hold the taps of outputs x0..x0+3: output c uses bytes 2c+2 .. 2c+6
     const uint8_t *row[5];
 #pragma unroll
@@ -102,26 +122,18 @@ __device__ __forceinline__ void pyr_down_group(const uint8_t *__restrict__ src, 
             }
         }
     }
-    uint32_t acc[4] = {128u, 128u, 128u, 128u};
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const uint32_t k = j == 0 || j == 4 ? 1u : j == 2 ? 6u : 4u;
-        // weight dwords (byte 0 = lowest address): taps 1 4 | 6 4 1 split over two dwords, or 1 4 6 4 | 1
-        const uint32_t w_hi2 = (k << 16) | (4 * k << 24);          // (0, 0, k, 4k)
-        const uint32_t w_lo3 = 6 * k | (4 * k << 8) | (k << 16);   // (6k, 4k, k, 0)
-        const uint32_t w_all = k | (4 * k << 8) | (6 * k << 16) | (4 * k << 24);  // (k, 4k, 6k, 4k)
-        acc[0] = udot4(d[j][1], w_lo3, udot4(d[j][0], w_hi2, acc[0]));
-        acc[1] = udot4(d[j][2], k, udot4(d[j][1], w_all, acc[1]));
-        acc[2] = udot4(d[j][2], w_lo3, udot4(d[j][1], w_hi2, acc[2]));
-        acc[3] = udot4(d[j][3], k, udot4(d[j][2], w_all, acc[3]));
-    }
-    // result byte c = bits 8..15 of acc[c] (sum + 128 <= 255 * 256 + 128 < 2^16)
+    return pyr_down_dot4x4(d);
+}
+
+template <bool EDGE, bool NEAR>
+__device__ __forceinline__ void pyr_down_group(const uint8_t *__restrict__ src, uint32_t spitch, int sw, int sh, uint8_t *__restrict__ dst, size_t dpitch,
+                                               int dw, int x0, int y, bool vec_ok) {
+    const uint32_t out = pyr_down_group4<EDGE, NEAR>(src, spitch, sw, sh, x0, y, vec_ok);
     uint8_t *o = dst + (size_t)((uint32_t)y * (uint32_t)dpitch) + x0;  // one 32-bit multiply (images are at most 32767 x 32767 bytes)
     if (!EDGE) {
-        const uint32_t p01 = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0501u), p23 = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0501u);
-        *reinterpret_cast<uint32_t *>(o) = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+        *reinterpret_cast<uint32_t *>(o) = out;
     } else {
-        for (int c = 0; c < 4 && x0 + c < dw; c++) o[c] = (uint8_t)(acc[c] >> 8);
+        for (int c = 0; c < 4 && x0 + c < dw; c++) o[c] = (uint8_t)(out >> (8 * c));
     }
 }
 
@@ -153,74 +165,67 @@ __global__ void __launch_bounds__(256) k_pyr_down(const uint8_t *__restrict__ sr
 // =============================================================================================
 // k_pyr_down_x2 -- TWO pyramid levels in one launch (levels 2 and 3 of the LK pyramid from level 1): the small levels are
 // launch- and latency-bound as kernels of their own (a 4K frame's level 3 is 480 x 270), and the prefetch stream paid three
-// launches per frame.  A workgroup owns 14 x 12 outputs of the SECOND level: it stages the source region they depend on
-// (80 x 57 bytes, REFLECT_101 applied while staging), computes the 36 x 27 first-level outputs around them with the same
-// v_dot4 arithmetic as k_pyr_down (into LDS, and to global memory for the 28 x 24 of them it owns), then the second level
-// from those -- reflecting FIRST-LEVEL coordinates, as pyrDown of the stored first level does.  Integer sums: exact in any order.
+// launches per frame.  A workgroup owns 16 x 10 outputs of the SECOND level: it computes the 40 x 23 first-level outputs around
+// them straight from global memory with the arithmetic of k_pyr_down (four outputs per thread: 230 of the 256 threads, all
+// loads of the workgroup in flight at once; into LDS, and to global memory for the 32 x 20 of them it owns), then the second
+// level from those, four outputs per thread with the same dot products on the LDS dwords -- reflecting FIRST-LEVEL coordinates,
+// as pyrDown of the stored first level does.  Integer sums: exact in any order.
+// (The first version staged the 80 x 57 source bytes of a 14 x 12 tile in LDS, index arithmetic included, and produced one
+// second-level output per thread: 0.58 M vector instructions per 4K frame and 6.3 us alone; this one 5.2 us (4.1 at 1080p).
+// Tiles of 28 x 22 with three groups per thread need fewer instructions still but leave a 1080p frame 63 workgroups: 9 us.)
 // =============================================================================================
-constexpr int P2_TW = 14, P2_TH = 12;                   // second-level outputs per workgroup
-constexpr int P2_MW = 36, P2_MH = 2 * P2_TH + 3;        // first-level region: columns 2 x0 - 4 .. 2 x0 + 31 (9 groups of 4), rows 2 y0 - 2 .. 2 y0 + 24
-constexpr int P2_SW = 80, P2_SH = 2 * P2_MH + 3;        // source region: columns 4 x0 - 12 .. 4 x0 + 67, rows 4 y0 - 6 .. 4 y0 + 50
+constexpr int P2_TW = 16, P2_TH = 10;                   // second-level outputs per workgroup
+constexpr int P2_MG = (2 * P2_TW + 5 + 3) / 4, P2_MW = 4 * P2_MG;  // first-level region: groups of 4 columns from 2 x0 - 4 on (taps of the tile: 2 x0 - 2 .. 2 x0 + 2 P2_TW)
+constexpr int P2_MH = 2 * P2_TH + 3;                    // rows 2 y0 - 2 .. 2 y0 + 2 P2_TH
+constexpr int P2_ITEMS = P2_MG * P2_MH, P2_ROUNDS = (P2_ITEMS + 255) / 256;
+static_assert(P2_TW % 4 == 0 && 2 * P2_TW + 5 <= P2_MW, "the region holds the taps of the tile's last output");
 
-__global__ void __launch_bounds__(256) k_pyr_down_x2(const uint8_t *__restrict__ src, uint32_t spitch, int sw, int sh, uint8_t *__restrict__ mid,
-                                                     uint32_t mpitch, int mw, int mh, uint8_t *__restrict__ dst, uint32_t dpitch, int dw, int dh, int vec_ok) {
-    __shared__ __attribute__((aligned(16))) uint8_t ssrc[P2_SH][P2_SW];
-    __shared__ __attribute__((aligned(16))) uint8_t smid[P2_MH][P2_MW];
+template <bool NEAR>
+__device__ __forceinline__ void pyr_down_x2_tile(const uint8_t *__restrict__ src, uint32_t spitch, int sw, int sh, uint8_t *__restrict__ mid, uint32_t mpitch, int mw,
+                                                 int mh, uint8_t *__restrict__ dst, uint32_t dpitch, int dw, int dh, bool vec_ok, bool dst_vec_ok,
+                                                 uint8_t (&smid)[P2_MH][P2_MW]) {
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * P2_TW, y0 = blockIdx.y * P2_TH;  // second-level origin of the tile
     const int mx0 = 2 * x0 - 4, my0 = 2 * y0 - 2;                 // first-level origin of the region
-    const int sx0 = 2 * mx0 - 4, sy0 = 2 * my0 - 2;               // source origin of the region (a multiple of 4)
-    // ---- stage the source region, reflected -----------------------------------------------------------------------------
-    // (a workgroup whose whole region lies inside the image -- all but the border ones -- loads aligned dwords, all in flight
-    // together, and needs no reflection in any phase: the kernel's instruction count is a quarter of the generic path's)
-    const bool interior = vec_ok && sx0 >= 0 && sy0 >= 0 && sx0 + P2_SW <= sw && sy0 + P2_SH <= sh;  // uniform
+    // an interior workgroup: every first-level output of its region exists, and all their taps (source columns 2 mx0 - 4 .. 2 mx0 + 2 P2_MW + 3,
+    // rows 2 my0 - 2 .. 2 my0 + 2 P2_MH) lie inside the source -- aligned dword loads, no reflection in either level, whole tile inside dst
+    const bool interior = vec_ok && mx0 >= 2 && my0 >= 1 && mx0 + P2_MW <= mw && my0 + P2_MH <= mh && 2 * (mx0 + P2_MW) + 4 <= sw && 2 * (my0 + P2_MH) + 1 <= sh;  // uniform
+    // ---- first level: P2_MG groups of 4 outputs x P2_MH rows, one group per thread (P2_ROUNDS = 1 with the 16 x 10 tile) --------------------------
     if (interior) {
-        constexpr int ND = P2_SH * (P2_SW / 4), NT = (ND + 255) / 256;
-        static_assert(P2_SW / 4 == 20, "the index split below divides by 20");
-        uint32_t v[NT];
-        const uint8_t *base = src + (uint32_t)sy0 * spitch + (uint32_t)sx0;
+        // every load of the thread's groups first (one memory latency however many rounds), then the arithmetic
+        uint32_t d[P2_ROUNDS][5][4];
 #pragma unroll
-        for (int k = 0; k < NT; k++) {
-            const int e = min(tid + 256 * k, ND - 1), ry = __mul24(e, 3277) >> 16, rd = e - __mul24(ry, 20);
-            v[k] = *reinterpret_cast<const uint32_t *>(base + __umul24((uint32_t)ry, spitch) + 4 * rd);
-        }
-#pragma unroll
-        for (int k = 0; k < NT; k++) {
-            const int e = tid + 256 * k, ry = __mul24(e, 3277) >> 16, rd = e - __mul24(ry, 20);
-            if (e < ND) reinterpret_cast<uint32_t *>(&ssrc[ry][0])[rd] = v[k];
-        }
-    } else {
-        for (int e = tid; e < P2_SH * (P2_SW / 4); e += 256) {
-            const int ry = e / (P2_SW / 4), rd = e - ry * (P2_SW / 4);
-            reinterpret_cast<uint32_t *>(&ssrc[ry][0])[rd] = load4_reflect(src, spitch, sw, sh, sx0 + 4 * rd, sy0 + ry, vec_ok != 0);
-        }
-    }
-    __syncthreads();
-    // ---- first level: 9 groups of 4 outputs x 27 rows, one group per thread ---------------------------------------------
-    if (tid < 9 * P2_MH) {
-        const int ry = tid / 9, g = tid - ry * 9;
-        const int my = my0 + ry, mx = mx0 + 4 * g;
-        if (my >= 0 && my < mh && mx + 3 >= 0 && mx < mw) {
-            // output column c of the group uses source bytes 8 g + 2 c + 2 .. + 6 of source rows 2 ry .. 2 ry + 4
-            uint32_t acc[4] = {128u, 128u, 128u, 128u};
+        for (int k = 0; k < P2_ROUNDS; k++) {
+            const int it = min(tid + 256 * k, P2_ITEMS - 1);  // (a thread past the end loads the last group again and drops it)
+            const int ry = it / P2_MG, g = it - ry * P2_MG;
+            const uint8_t *r0 = src + (uint32_t)(2 * (my0 + ry) - 2) * spitch + (uint32_t)(2 * (mx0 + 4 * g) - 4);
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                const uint2 dl = *reinterpret_cast<const uint2 *>(&ssrc[2 * ry + j][8 * g]), dh2 = *reinterpret_cast<const uint2 *>(&ssrc[2 * ry + j][8 * g + 8]);
-                const uint4 d = make_uint4(dl.x, dl.y, dh2.x, dh2.y);  // (8-byte aligned: rows are 80 bytes, groups 8 bytes apart)
-                const uint32_t k = j == 0 || j == 4 ? 1u : j == 2 ? 6u : 4u;
-                const uint32_t w_hi2 = (k << 16) | (4 * k << 24);
-                const uint32_t w_lo3 = 6 * k | (4 * k << 8) | (k << 16);
-                const uint32_t w_all = k | (4 * k << 8) | (6 * k << 16) | (4 * k << 24);
-                acc[0] = udot4(d.y, w_lo3, udot4(d.x, w_hi2, acc[0]));
-                acc[1] = udot4(d.z, k, udot4(d.y, w_all, acc[1]));
-                acc[2] = udot4(d.z, w_lo3, udot4(d.y, w_hi2, acc[2]));
-                acc[3] = udot4(d.w, k, udot4(d.z, w_all, acc[3]));
+                const uint4 v = *reinterpret_cast<const uint4 *>(r0 + (uint32_t)j * spitch);  // (16 bytes at a 4-byte aligned address: global loads take any alignment)
+                d[k][j][0] = v.x, d[k][j][1] = v.y, d[k][j][2] = v.z, d[k][j][3] = v.w;
             }
-            const uint32_t p01 = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0501u), p23 = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0501u);
-            const uint32_t out = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+        }
+#pragma unroll
+        for (int k = 0; k < P2_ROUNDS; k++) {
+            const int it = tid + 256 * k;
+            if (it >= P2_ITEMS) break;
+            const int ry = it / P2_MG, g = it - ry * P2_MG;
+            const uint32_t out = pyr_down_dot4x4(d[k]);
             *reinterpret_cast<uint32_t *>(&smid[ry][4 * g]) = out;
-            // the tile owns first-level columns 2 x0 .. 2 x0 + 27 (groups 1 .. 7) and rows 2 y0 .. 2 y0 + 23
-            if (g >= 1 && g <= 7 && ry >= 2 && ry < 2 + 2 * P2_TH) {
+            // the tile owns first-level columns 2 x0 .. 2 x0 + 2 P2_TW - 1 (groups 1 .. P2_TW / 2) and rows 2 y0 .. 2 y0 + 2 P2_TH - 1
+            if (g >= 1 && g <= P2_TW / 2 && ry >= 2 && ry < 2 + 2 * P2_TH) *reinterpret_cast<uint32_t *>(mid + (uint32_t)(my0 + ry) * mpitch + (mx0 + 4 * g)) = out;
+        }
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < P2_ROUNDS; k++) {
+            const int it = tid + 256 * k;
+            if (it >= P2_ITEMS) break;
+            const int ry = it / P2_MG, g = it - ry * P2_MG;
+            const int my = my0 + ry, mx = mx0 + 4 * g;
+            if (my < 0 || my >= mh || mx < 0 || mx >= mw) continue;  // (outside the first level: never read -- the second level reflects its coordinates into the image)
+            const uint32_t out = pyr_down_group4<true, NEAR>(src, spitch, sw, sh, mx, my, vec_ok);
+            *reinterpret_cast<uint32_t *>(&smid[ry][4 * g]) = out;
+            if (g >= 1 && g <= P2_TW / 2 && ry >= 2 && ry < 2 + 2 * P2_TH) {
                 uint8_t *o = mid + (uint32_t)my * mpitch + mx;
                 if (vec_ok && mx + 4 <= mw) *reinterpret_cast<uint32_t *>(o) = out;
                 else
@@ -229,26 +234,29 @@ __global__ void __launch_bounds__(256) k_pyr_down_x2(const uint8_t *__restrict__
         }
     }
     __syncthreads();
-    // ---- second level from the first-level region (REFLECT_101 in first-level coordinates) ------------------------------
-    if (tid < P2_TW * P2_TH) {
-        const int ty = tid / P2_TW, tx = tid - ty * P2_TW;
-        const int x = x0 + tx, y = y0 + ty;
-        if (interior && x < dw && y < dh) {
-            // no reflection: the five taps of a row are bytes 2 tx + 2 .. 2 tx + 6 of region row 2 ty + j -- two aligned dwords, the
-            // first four taps shifted into place (v_alignbyte) for one dot product with (k, 4k, 6k, 4k), the fifth in byte 0 of the rest
-            const int c0 = 2 * tx + 2, sh8 = (c0 & 3), a0 = c0 >> 2;
-            uint32_t acc = 128u;
+    // ---- second level from the first-level region ----------------------------------------------------------------------------------------------
+    if (interior) {
+        // four outputs per item: their taps are bytes 8 g + 2 c + 2 .. + 6 of region rows 2 ty .. 2 ty + 4 -- the layout of pyr_down_dot4x4
+        if (tid < (P2_TW / 4) * P2_TH) {
+            const int ty = tid / (P2_TW / 4), g = tid - ty * (P2_TW / 4);
+            uint32_t d[5][4];
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                const uint32_t *r = reinterpret_cast<const uint32_t *>(&smid[2 * ty + j][0]) + a0;
-                const uint32_t A = r[0], B = r[1];
-                const uint32_t k = j == 0 || j == 4 ? 1u : j == 2 ? 6u : 4u;
-                const uint32_t w_all = k | (4 * k << 8) | (6 * k << 16) | (4 * k << 24);
-                acc = udot4(__builtin_amdgcn_alignbyte(B, A, sh8), w_all, acc);
-                acc = udot4(B >> (8 * sh8), k, acc);
+                const uint2 lo = *reinterpret_cast<const uint2 *>(&smid[2 * ty + j][8 * g]), hi = *reinterpret_cast<const uint2 *>(&smid[2 * ty + j][8 * g + 8]);
+                d[j][0] = lo.x, d[j][1] = lo.y, d[j][2] = hi.x, d[j][3] = hi.y;
             }
-            dst[(uint32_t)y * dpitch + x] = (uint8_t)(acc >> 8);
-        } else if (x < dw && y < dh) {
+            const uint32_t out = pyr_down_dot4x4(d);
+            uint8_t *o = dst + (uint32_t)(y0 + ty) * dpitch + (x0 + 4 * g);
+            if (dst_vec_ok) *reinterpret_cast<uint32_t *>(o) = out;
+            else
+                for (int c = 0; c < 4; c++) o[c] = (uint8_t)(out >> (8 * c));
+        }
+    } else {
+        // border workgroups: output by output, REFLECT_101 in first-level coordinates
+        for (int e = tid; e < P2_TW * P2_TH; e += 256) {
+            const int ty = e / P2_TW, tx = e - ty * P2_TW;
+            const int x = x0 + tx, y = y0 + ty;
+            if (x >= dw || y >= dh) continue;
             int col[5];
 #pragma unroll
             for (int i = 0; i < 5; i++) col[i] = reflect101(2 * x - 2 + i, mw) - mx0;
@@ -262,6 +270,14 @@ __global__ void __launch_bounds__(256) k_pyr_down_x2(const uint8_t *__restrict__
             dst[(uint32_t)y * dpitch + x] = (uint8_t)(acc >> 8);
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_pyr_down_x2(const uint8_t *__restrict__ src, uint32_t spitch, int sw, int sh, uint8_t *__restrict__ mid,
+                                                     uint32_t mpitch, int mw, int mh, uint8_t *__restrict__ dst, uint32_t dpitch, int dw, int dh, int vec_ok,
+                                                     int dst_vec_ok, int near) {
+    __shared__ __attribute__((aligned(16))) uint8_t smid[P2_MH][P2_MW];
+    if (near) pyr_down_x2_tile<true>(src, spitch, sw, sh, mid, mpitch, mw, mh, dst, dpitch, dw, dh, vec_ok != 0, dst_vec_ok != 0, smid);
+    else pyr_down_x2_tile<false>(src, spitch, sw, sh, mid, mpitch, mw, mh, dst, dpitch, dw, dh, vec_ok != 0, dst_vec_ok != 0, smid);
 }
 
 // =============================================================================================
@@ -1291,8 +1307,10 @@ vstab_status launch_pyr_down_x2(const uint8_t *src, size_t spitch, int sw, int s
     if ((uint64_t)spitch * (uint64_t)sh >= (1ull << 32) || (uint64_t)mpitch * (uint64_t)mh >= (1ull << 32) || (uint64_t)dpitch * (uint64_t)dh >= (1ull << 32))
         return fail(VSTAB_ERR_INVALID, "pyr_down_x2: planes of 4 GiB or more are not supported");
     const int vec_ok = reinterpret_cast<uintptr_t>(src) % 4 == 0 && spitch % 4 == 0 && reinterpret_cast<uintptr_t>(mid) % 4 == 0 && mpitch % 4 == 0;
+    const int dst_vec_ok = reinterpret_cast<uintptr_t>(dst) % 4 == 0 && dpitch % 4 == 0;
+    const int near = sw >= 16 && sh >= 4;
     hipExtLaunchKernelGGL(k_pyr_down_x2, dim3(div_up(dw, P2_TW), div_up(dh, P2_TH)), dim3(256), 0, s, nullptr, done, 0, src, (uint32_t)spitch, sw, sh, mid,
-                          (uint32_t)mpitch, mw, mh, dst, (uint32_t)dpitch, dw, dh, vec_ok);
+                          (uint32_t)mpitch, mw, mh, dst, (uint32_t)dpitch, dw, dh, vec_ok, dst_vec_ok, near);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }
