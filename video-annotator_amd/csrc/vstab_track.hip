@@ -93,8 +93,8 @@ __device__ __forceinline__ uint32_t pyr_down_group4(const uint8_t *__restrict__ 
             const uint8_t *r0 = src + (size_t)(uint32_t)(2 * y - 2) * spitch + sx0;
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                const uint32_t *p = reinterpret_cast<const uint32_t *>(r0 + (size_t)j * spitch);
-                d[j][0] = p[0], d[j][1] = p[1], d[j][2] = p[2], d[j][3] = p[3];
+                const uint4 v = *reinterpret_cast<const uint4 *>(r0 + (size_t)j * spitch);  // one 16-byte load (4-byte aligned: global loads take any alignment)
+                d[j][0] = v.x, d[j][1] = v.y, d[j][2] = v.z, d[j][3] = v.w;
             }
         } else {
 #pragma unroll
