@@ -61,8 +61,8 @@ if rows.shape[1] >= 32:
         prev = r[:, 2]
         for i, lvl in enumerate((3, 2, 1, 0)):
             a, b = r[:, 3 + 3 * i], r[:, 4 + 3 * i]
-            bar, fetch, ahead = r[:, 18 + 3 * i], r[:, 19 + 3 * i], r[:, 20 + 3 * i]
+            bar, fetch = r[:, 18 + 3 * i], r[:, 19 + 3 * i]
             ok = (a != 0) & (bar != 0)
             print(f"   level {lvl}: previous level end -> barrier passed {np.median(us(bar - prev)[ok]):.2f}, fetch code {np.median(us(fetch - bar)[ok]):.2f}, "
-                  f"-> iterations start {np.median(us(a - fetch)[ok]):.2f}; finer block ahead used {int(ahead[ok].sum())} of {int(ok.sum())}")
+                  f"-> iterations start {np.median(us(a - fetch)[ok]):.2f}")
             prev = np.where(b != 0, b, prev)
