@@ -900,11 +900,14 @@ __global__ void __launch_bounds__(LK_THREADS, 3) k_lk_track(LkSegArgs args) {
     // iterations; the dwords wait in registers: (a) the previous-image neighbourhoods of all levels -- blocks of the current next image
     // around where the feature stands now, wide enough (32 x 32 for a 24 x 24 neighbourhood) to hold the neighbourhood of the point the
     // pair finally ends on: the top level's by the three waves together (it is needed first), every lower level's by the wave that will
-    // prepare that level (it alone writes the neighbourhood to LDS, right before it reads it) -- and (b) the next-image blocks of all
-    // levels around the position PREDICTED there: this pair's end plus this pair's motion.  Without them a pair began with one exposed
+    // prepare that level (it alone writes the neighbourhood to LDS, right before it reads it) -- and (b) the TOP level's next-image
+    // block around the position PREDICTED there: this pair's end plus this pair's motion.  Without them a pair began with one exposed
     // memory latency (2.2 - 2.9 of a feature's 18 us in the 4K pipeline).  A block that turns out not to hold what is needed -- the
-    // motion changed by more than the slack -- is fetched again as before.  Where a block sits never changes a value: it holds image
-    // bytes either way.  The origins travel through LDS (s_pf), so that wave 0 spends no instruction on any of it.
+    // motion changed by more than the slack, or the block would cross the image border (blocks fetched ahead are loaded without border
+    // handling) -- is fetched as before.  Where a block sits never changes a value: it holds image bytes either way.  The origins
+    // travel through LDS (s_pf), so that wave 0 spends no instruction on any of it.  (The lower levels' next-image blocks fetched ahead
+    // the same way were measured and dropped: the fetch one level ahead already hides their latency, and a predicted block is left by
+    // the Gauss-Newton window more often than one centred on the running estimate.)
     LkStage<LKJR, LK_THREADS - 64> pfIt, pfJt;
     LkStage<LKJR, 64> pfIo;
     constexpr int PF_NONE = INT_MIN / 2;
