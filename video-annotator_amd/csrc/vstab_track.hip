@@ -698,6 +698,9 @@ __device__ __forceinline__ int lk_div21(int k) { return __mul24(k, 3121) >> 16; 
 // part so that every wave sum stays inside int32; hi * 65536 + lo is exact in double and the one double -> float
 // conversion equals (float)(int64 total).
 constexpr int LK_THREADS = 256, LK_WAVES = 4;
+#ifndef VSTAB_LK_PRIO
+#define VSTAB_LK_PRIO 1
+#endif
 constexpr int LK_WPAD = (LKW * LKW + 63) & ~63;  // window pixels rounded up to whole waves
 
 // The 2 x 2 matrix of a level from the exact sums of Ix Ix, Ix Iy, Iy Iy (as floats): A11, A12, A22, 1 / D and whether the level is
@@ -851,9 +854,7 @@ __global__ void __launch_bounds__(LK_THREADS, 3) k_lk_track(LkSegArgs args) {
     const int n = args.n;
     if (f >= n) return;
     unsigned long long *const clk = args.clk;
-#ifdef VSTAB_LK_PRIO
-    __builtin_amdgcn_s_setprio(VSTAB_LK_PRIO);
-#endif
+    __builtin_amdgcn_s_setprio(VSTAB_LK_PRIO);  // with the warp, above the pyramid and detector kernels (vstab_warp_fused.hip: VSTAB_WARP_PRIO)
     // development aid (VSTAB_LK_CLOCK): first workgroup start / last workgroup end on the 100 MHz wall clock
     if (clk && tid == 0) atomicMin(&clk[0], wall_clock64());
     unsigned int seq = args.seq[0];

@@ -48,6 +48,13 @@ namespace vstab {
 #ifndef VSTAB_WARP_WAVES
 #define VSTAB_WARP_WAVES 7
 #endif
+// Issue priority of the kernel's waves (the probe wave runs at 3).  The warp and the tracker (k_lk_track, VSTAB_LK_PRIO) run at 1, the pyramid
+// and detector kernels at the default 0: beside a saturating warp those two take a fifth of its rate while they run (every warp launch's
+// duration against what ran beside it: profiles/r04_warp_overlap_regression.txt), and they have slack.  The warp ABOVE the tracker loses:
+// the tracker's single iterating wave then waits for issue slots and its chain becomes the limiter (-3 % at 4K, -9 % at 1080p).
+#ifndef VSTAB_WARP_PRIO
+#define VSTAB_WARP_PRIO 1
+#endif
 #ifndef VSTAB_MAP_GROUP
 #define VSTAB_MAP_GROUP 2
 #endif
@@ -338,7 +345,7 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);  // three waves wait for this one
         probe_tile<TH, STAGE_MAX, MODE, CACHED>(ta, x0, y0, lane, rfx, rfy, smem);
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(VSTAB_WARP_PRIO);
     }
     __syncthreads();
     const int bx0 = __builtin_amdgcn_readfirstlane((int)smem[0]), by0 = __builtin_amdgcn_readfirstlane((int)smem[1]);
@@ -853,6 +860,7 @@ template <int RWB, int MODE, int FMT, bool CACHED, int DEPTH = 8, int BLEND = 0>
 __global__ void __launch_bounds__(256, DEPTH == 10 ? 5 : (RWB == 8 || map_mode_is_rs(MODE)) ? VSTAB_WARP_WAVES - 1 : VSTAB_WARP_WAVES) k_warp_fused(FusedArgs ta) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int TH = 4 * RWB, TS = TH / 2;
+    if (VSTAB_WARP_PRIO) __builtin_amdgcn_s_setprio(VSTAB_WARP_PRIO);
     const int k = (int)(blockIdx.x & 7u);
     const int y_lo = ta.band_y[k], y_sp = ta.split_y[k], y_hi = ta.band_y[k + 1];
     const int n_tall = ((y_sp - y_lo) / TH) * ta.tiles_x;  // y_sp - y_lo is a multiple of TH
