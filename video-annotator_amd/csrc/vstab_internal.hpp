@@ -40,4 +40,7 @@ bool launch_events_pending();
 vstab_status pack_p010_planes(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width, int height, void *dst, bool luma_only,
                               void *stream);
 
+// vstab_pack_nv12 with an optional event that completes with the copy kernel (bound to the launch: no marker packet on the stream)
+vstab_status pack_nv12_planes(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width, int height, void *dst, void *stream, hipEvent_t done);
+
 }  // namespace vstab

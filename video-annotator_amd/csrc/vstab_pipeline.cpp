@@ -629,6 +629,8 @@ struct vstab_handle {
         for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
         for (auto &s : slots)
             if (s.ingested) (void)hipEventDestroy(s.ingested);
+        for (auto &s : slots)
+            if (s.copied) (void)hipEventDestroy(s.copied);
         for (hipEvent_t e : warp_events)
             if (e) (void)hipEventDestroy(e);
         for (hipStream_t s : {dstream, pstream, tstream})
@@ -664,6 +666,8 @@ struct vstab_handle {
         bool queued = false, last = false;
         long freed_at = 0;               // FIFO reuse: the slot idle the longest is taken first
         hipEvent_t ingested = nullptr;   // recorded on pstream after the copy into the slot (and its pyramid, when tracking)
+        hipEvent_t copied = nullptr;     // completes with the copy kernel alone (8-bit frames copied by vstab_pack_nv12 while tracking): what
+        bool copied_valid = false;       //   upstream's surface has to wait for -- the pyramid behind the copy reads the ring, not the surface
         int warped = -1;                 // index into warp_events of the event recorded behind the warp that read the slot
         bool warp_pending = false;       // a warp has read the slot since it was last filled
         unsigned long ingest_serial = 0;  // which copy `ingested` was last recorded for
@@ -988,6 +992,7 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
     if (wide && f.mem != 0) return fail(VSTAB_ERR_INVALID, "16-bit frames must be in device memory");
     if (H->cfg.pixel_depth == 10 && !wide) return fail(VSTAB_ERR_INVALID, "a pixel_depth 10 handle needs P010 device frames (vstab_frame.bit_depth > 8)");
     S.y16 = S.uv16 = nullptr;  // set again below when this frame has 16-bit planes to warp from
+    S.copied_valid = false;
     if (f.mem == 0 && !wide && f.hold >= H->borrow_hold && f.pitch_y < (1u << 24) && f.pitch_uv < (1u << 24)) {  // (the kernels form row offsets with 24-bit multiplies)
         // zero copy: track, build the pyramid from and warp upstream's planes where they are
         S.y = static_cast<const uint8_t *>(f.y), S.uv = static_cast<const uint8_t *>(f.uv), S.pitch_y = f.pitch_y, S.pitch_uv = f.pitch_uv;
@@ -1019,7 +1024,9 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
             }
         }
     } else if (f.mem == 0) {
-        VSTAB_TRY(vstab_pack_nv12(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->pstream));
+        // (while tracking, `ingested` completes with the pyramid enqueued behind the copy: upstream's surface is free as soon as the copy is)
+        S.copied_valid = H->cfg.tracking != 0;
+        VSTAB_TRY(pack_nv12_planes(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->pstream, S.copied_valid ? S.copied : nullptr));
     } else {
         VSTAB_HIP_TRY(hipMemcpy2DAsync(dst, H->w, f.y, f.pitch_y, H->w, H->h, hipMemcpyHostToDevice, H->pstream));
         VSTAB_HIP_TRY(hipMemcpy2DAsync(dst + (size_t)H->w * H->h, H->w, f.uv, f.pitch_uv, H->w, H->h / 2, hipMemcpyHostToDevice, H->pstream));
@@ -1058,7 +1065,7 @@ static vstab_status prefetch_next(vstab_handle *H) {
             }
             const vstab_handle::Slot &S = H->slots[it->slot];
             if (S.ingest_serial == it->serial)  // (a re-used slot's newer copy was enqueued behind this one: also done)
-                VSTAB_TRY(vstab_handle::host_wait(S.ingested));
+                VSTAB_TRY(vstab_handle::host_wait(S.copied_valid ? S.copied : S.ingested));
             it = H->copies.erase(it);
         }
         // frames used in place: the warp reading them must be through before the callback that ends upstream's promise
@@ -1481,6 +1488,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     H->slots.resize((size_t)cfg->smooth_radius + 6 + H->prefetch_depth + vstab_handle::WARP_EVENT_STRIDE);
     for (auto &s : H->slots) {
         VSTAB_HIP_TRY(hipEventCreateWithFlags(&s.ingested, hipEventDisableTiming));
+        VSTAB_HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
     }
     // a frame stays in the pipeline from its pull until its warp: read-ahead + look-ahead queue + the frames in between
     H->borrow_hold = getenv("VSTAB_ALWAYS_COPY") ? (1 << 30) + 1 : cfg->smooth_radius + H->prefetch_depth + 6;

@@ -375,10 +375,11 @@ vstab_status pack_p010_planes(const void *y, size_t pitch_y, const void *uv, siz
 }
 }  // namespace vstab
 
-extern "C" {
-
-vstab_status vstab_pack_nv12(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width,
-                             int height, void *dst, void *stream) {
+// vstab_pack_nv12 with an optional event that completes with the copy kernel -- bound to the launch itself (hipExtLaunchKernelGGL's
+// stop event), no marker packet on the stream: the pipeline waits for THAT before it lets upstream recycle a surface, not for the
+// pyramid kernels enqueued behind the copy
+namespace vstab {
+vstab_status pack_nv12_planes(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width, int height, void *dst, void *stream, hipEvent_t done) {
     if (!y || !uv || !dst) return fail(VSTAB_ERR_INVALID, "vstab_pack_nv12: null pointer");
     if (width <= 0 || height <= 0 || (width & 1) || (height & 1))
         return fail(VSTAB_ERR_INVALID, "Mismatched image dimensions");  // FrameSourceFfmpegOpenCl.cpp:53-56
@@ -391,25 +392,33 @@ vstab_status vstab_pack_nv12(const void *y, size_t pitch_y, const void *uv, size
     if (v16) {
         const int vecs = width / 16;
         dim3 grid(std::min<unsigned>(div_up((unsigned)((long)vecs * rows), 256), 1024));
-        hipLaunchKernelGGL(k_pack_nv12<uint4>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y,
+        hipExtLaunchKernelGGL(k_pack_nv12<uint4>, grid, dim3(256), 0, s, nullptr, done, 0, (const uint8_t *)y, pitch_y,
                            (const uint8_t *)uv, pitch_uv, vecs, height, (uint8_t *)dst, (size_t)width);
     } else if (aligned(y, 8) && aligned(uv, 8) && aligned(dst, 8) && pitch_y % 8 == 0 && pitch_uv % 8 == 0 && width % 8 == 0) {
         const int vecs = width / 8;
         dim3 grid(std::min<unsigned>(div_up((unsigned)((long)vecs * rows), 256), 1024));
-        hipLaunchKernelGGL(k_pack_nv12<uint2>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y,
+        hipExtLaunchKernelGGL(k_pack_nv12<uint2>, grid, dim3(256), 0, s, nullptr, done, 0, (const uint8_t *)y, pitch_y,
                            (const uint8_t *)uv, pitch_uv, vecs, height, (uint8_t *)dst, (size_t)width);
     } else if (aligned(y, 4) && aligned(uv, 4) && aligned(dst, 4) && pitch_y % 4 == 0 && pitch_uv % 4 == 0 && width % 4 == 0) {
         const int vecs = width / 4;
         dim3 grid(std::min<unsigned>(div_up((unsigned)((long)vecs * rows), 256), 1024));
-        hipLaunchKernelGGL(k_pack_nv12<uint32_t>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y,
+        hipExtLaunchKernelGGL(k_pack_nv12<uint32_t>, grid, dim3(256), 0, s, nullptr, done, 0, (const uint8_t *)y, pitch_y,
                            (const uint8_t *)uv, pitch_uv, vecs, height, (uint8_t *)dst, (size_t)width);
     } else {
         dim3 grid(std::min<unsigned>(div_up((unsigned)((long)width * rows), 256), 1024));
-        hipLaunchKernelGGL(k_pack_nv12<uint8_t>, grid, dim3(256), 0, s, (const uint8_t *)y, pitch_y,
+        hipExtLaunchKernelGGL(k_pack_nv12<uint8_t>, grid, dim3(256), 0, s, nullptr, done, 0, (const uint8_t *)y, pitch_y,
                            (const uint8_t *)uv, pitch_uv, width, height, (uint8_t *)dst, (size_t)width);
     }
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
+}
+}  // namespace vstab
+
+extern "C" {
+
+vstab_status vstab_pack_nv12(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width,
+                             int height, void *dst, void *stream) {
+    return pack_nv12_planes(y, pitch_y, uv, pitch_uv, width, height, dst, stream, nullptr);
 }
 
 vstab_status vstab_pack_p010(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int width, int height,
