@@ -1023,6 +1023,10 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
                 S.y16 = d16, S.uv16 = d16 + row * H->h, S.pitch_y16 = S.pitch_uv16 = row;
             }
         }
+        if (H->cfg.tracking) {  // upstream's surface is free once these copies are through (not the pyramid behind them: see pack_nv12_planes)
+            VSTAB_HIP_TRY(hipEventRecord(S.copied, H->pstream));
+            S.copied_valid = true;
+        }
     } else if (f.mem == 0) {
         // (while tracking, `ingested` completes with the pyramid enqueued behind the copy: upstream's surface is free as soon as the copy is)
         S.copied_valid = H->cfg.tracking != 0;
