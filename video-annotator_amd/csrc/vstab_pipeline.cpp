@@ -1144,7 +1144,12 @@ static vstab_status prefetch_next(vstab_handle *H) {
         if (debug_spec()) std::fprintf(stderr, "spec launch for frame %ld (last_key %ld)\n", H->prefetch_count, H->last_key);
         HT t(HostTimers::SPEC_DETECT);
         hipStream_t ds = H->dstream ? H->dstream : H->pstream;
-        if (ds != H->pstream) VSTAB_HIP_TRY(hipStreamWaitEvent(ds, H->slots[slot].ingested, 0));
+        // the detector reads the frame's luma plane, nothing else: it waits for the copy into the ring (if there was one), not for the
+        // pyramid enqueued behind it -- beside a saturating warp the detection needs most of the read-ahead's lead as it is
+        if (ds != H->pstream) {
+            const vstab_handle::Slot &DS = H->slots[slot];
+            if (!DS.borrowed) VSTAB_HIP_TRY(hipStreamWaitEvent(ds, DS.copied_valid ? DS.copied : DS.ingested, 0));
+        }
         VSTAB_TRY(H->tracker.spec_launch(H->gray(slot), H->gpitch(slot), 0.01, ds, H->prefetch_count));
         H->tracker.spec_select_async(200, 30.0);
     }
