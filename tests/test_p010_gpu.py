@@ -114,14 +114,22 @@ def test_pipeline_object_with_10bit_pixels(vs, cuda):
     dev = [torch.from_numpy(x.view(np.int16)).to(cuda) for x in wide]
     Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
 
-    def run(depth, blend):
-        state = {"i": 0}
+    surface = torch.empty_like(dev[0])
+
+    def run(depth, blend, recycle=False):
+        state = {"i": 0, "loaded": -1}
 
         def fill(out, advance):
             i = state["i"]
             if i >= n:
                 return vs.EOF
             t = dev[i]
+            if recycle:  # a decoder with ONE surface: every callback overwrites what the previous one handed out (vstab_frame.hold = 0)
+                if state["loaded"] != i:
+                    surface.copy_(dev[i])
+                    torch.cuda.synchronize()
+                    state["loaded"] = i
+                t = surface
             o = out.contents
             o.y, o.uv = t.data_ptr(), t.data_ptr() + H * t.stride(0) * 2
             o.pitch_y = o.pitch_uv = t.stride(0) * 2
@@ -168,6 +176,10 @@ def test_pipeline_object_with_10bit_pixels(vs, cuda):
             p = oracle.map_params(K, Ko, rots[i])
             y16, uv16 = wide[i + 1][:H], wide[i + 1][H:]
             assert np.array_equal(outs[i].view(np.uint16), expect.warp_p010(y16, uv16, p, cw, ch, None, blend)), (blend, i)
+    # upstream recycling one surface: the library calls it again only once the 16-bit planes and the narrowed luma have been copied
+    outs_r, rots_r = run(10, vs.BLEND_EXACT, recycle=True)
+    outs_e, rots_e = run(10, vs.BLEND_EXACT)
+    assert len(outs_r) == n - 1 and all(np.array_equal(a, b) for a, b in zip(outs_r, outs_e)) and all(np.array_equal(a, b) for a, b in zip(rots_r, rots_e))
     assert max(oracle.rotation_angle(R) for R in rots8) > 1e-4
 
 

@@ -714,6 +714,10 @@ def test_p010_input_equals_8bit_input_of_the_truncated_frames(vs, cuda, clip):
     ref_stab, ref = run_product(vs, cuda, frames[:n], smooth_radius=3, seed=9)
     outs = _run_raw_device_source(vs, cuda, frames[:n], 1 << 20, False, p010=True, smooth_radius=3, seed=9)
     assert len(outs) == len(ref) and all(np.array_equal(a, b) for a, b in zip(outs, ref))
+    # a decoder that recycles ONE P010 surface (hold = 0): the library may call upstream again as soon as the narrowing copy of the
+    # surface is through (an event behind the copies, not the frame's pyramid) -- and not before
+    outs = _run_raw_device_source(vs, cuda, frames[:n], 0, True, p010=True, smooth_radius=3, seed=9)
+    assert len(outs) == len(ref) and all(np.array_equal(a, b) for a, b in zip(outs, ref))
 
 
 def test_two_handles_interleaved_are_independent(vs, cuda, clip):
