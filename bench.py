@@ -433,6 +433,8 @@ def main():
     else:
         outs = [torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(args.ring)]
     out_name = "NV12" if nv12_out else "BGR"
+    if os.environ.get("VSTAB_BENCH_OWN_STREAM"):  # development: the caller works on a stream of its own instead of the default stream (the default stream stays in the process: a fifth stream)
+        torch.cuda.set_stream(torch.cuda.Stream())
     stream = torch.cuda.current_stream()
 
     # a fixed per-frame rotation schedule (small smooth shake) so every launch has a different map

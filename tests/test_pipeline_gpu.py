@@ -966,6 +966,26 @@ def test_every_clip_length_and_radius_against_the_state_machine(vs, cuda, monkey
             _check_against_oracle_state_machine(vs, cuda, frames[:n], K, w, h, r, 100 + n)
 
 
+@pytest.mark.parametrize("env", [None, "1", "0"])
+def test_caller_on_a_stream_of_its_own(vs, cuda, clip, monkeypatch, env):
+    """vstab_config.stream: a caller that works on a stream of its own gets the frames of the default-stream run, bit for bit -- with the
+    speculative corner detection on the read-ahead stream (the default beside a non-NULL stream: INTEGRATION.md section 3), on a stream
+    of its own (VSTAB_DETECT_STREAM=1) and without one on the default stream (=0).  26 frames: one planned key frame inside."""
+    import torch
+    K, frames, _ = clip
+    _, ref = run_product(vs, cuda, frames[:26], smooth_radius=3, seed=9)
+    if env is not None:
+        monkeypatch.setenv("VSTAB_DETECT_STREAM", env)
+    if env == "0":
+        _, outs = run_product(vs, cuda, frames[:26], smooth_radius=3, seed=9)
+    else:
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            _, outs = run_product(vs, cuda, frames[:26], smooth_radius=3, seed=9)
+        s.synchronize()
+    assert len(outs) == len(ref) == 25 and all(np.array_equal(a, b) for a, b in zip(outs, ref))
+
+
 def test_pull_into_host_memory_equals_device_pull(vs, cuda, clip):
     import torch
     K, frames, _ = clip

@@ -1460,7 +1460,13 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
         // The runtime multiplexes its streams onto four hardware queues, and two streams that share one serialise (a fifth
         // stream cost the 4K pipeline 4 k frames/s merely by existing): caller + tracker + prefetch leave ONE more: the
         // speculative corner detection's.
-        VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->dstream, hipStreamNonBlocking, lo));
+        // A caller that hands over a stream of its own very likely has the default stream in the process as well (any synchronous copy
+        // uses it): with the detection's stream that makes five, and the fifth costs 15 % of the 4K rate and 10 % at 1080p, where queueing
+        // the detection on the read-ahead stream costs 0.7 % and 3.5 % (profiles/r04_stream_count_ab.txt).  So the detection gets a stream
+        // of its own only beside a caller on the default stream; VSTAB_DETECT_STREAM=1 / 0 overrides.
+        const char *ds_env = getenv("VSTAB_DETECT_STREAM");
+        const bool detect_stream = ds_env ? atoi(ds_env) != 0 : H->stream == nullptr;
+        if (detect_stream) VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->dstream, hipStreamNonBlocking, lo));
         for (auto &e : H->warp_events) VSTAB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // :214-219 peek the first frame for the input size, then derive both cameras
