@@ -346,7 +346,7 @@ typedef struct vstab_frame {
                           until the next callback -- the library then waits for its copy of this frame to finish before
                           it calls upstream again (a decoder that recycles one output surface).  Ref-counted or pooled
                           frames can say how deep the pool is and the wait disappears from the frame loop.  From
-                          smooth_radius + 14 on, the planes are not copied at all but read in place by the tracker and
+                          smooth_radius + 18 on, the planes are not copied at all but read in place by the tracker and
                           by the warp (which runs on vstab_config.stream): the callback at which the promise runs out
                           first waits, on the host, for that warp to finish.  1 << 29 or more: never waited for.
                           That threshold is the 8-BIT rule.  16-bit (P010) frames are always narrowed into library
@@ -456,7 +456,7 @@ VSTAB_API vstab_status vstab_get_output_info(const vstab_handle *h, int *width, 
  * dst is complete once vstab_config.stream is synchronised.  Upstream frames handed to the callbacks
  * must already be complete in memory when the callback returns (they are read on an internal stream).
  * Read-ahead: to overlap copy, pyramid, corner detection and tracking with the host work, the library pulls
- * upstream up to ten frames earlier than the reference's loop would (same frames, same order, same outputs). */
+ * upstream up to fourteen frames earlier than the reference's loop would (same frames, same order, same outputs). */
 VSTAB_API vstab_status vstab_pull_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
 /* The consumer's loop (DisplayImage.cpp:60-70: `while (true) { frame = source.pull_frame(); ... }`) as one call: n consecutive
  * vstab_pull_frame calls, frame i into dst[(first + i) % n_dst] with pitch[(first + i) % n_dst] -- an encoder's ring of output

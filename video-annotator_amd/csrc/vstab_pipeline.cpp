@@ -89,7 +89,10 @@ constexpr int PYR_DEV_EXTRA = 0;
 #endif
 // frames pulled from upstream ahead of the one being tracked: deep enough that the speculative corner detection of a
 // key frame (137 us of kernels beside everything else + the host selection) is finished before its turn comes
-constexpr int PREFETCH_DEPTH = 8;  // default; VSTAB_PREFETCH=n (1 .. PREFETCH_MAX) for experiments
+// default read-ahead; VSTAB_PREFETCH=n (1 .. PREFETCH_MAX) for experiments.  Twelve since the end of round 4 (eight before): the rates are the
+// same, but the speculative corner detection launched when the frame before a planned key frame is read ahead then has ~430 us at 4K for
+// its ~150 + 45 us beside the saturating warp instead of ~290 -- the margin that keeps a slow box from waiting for corners at key frames
+constexpr int PREFETCH_DEPTH = 12;
 
 class Tracker {
   public:
