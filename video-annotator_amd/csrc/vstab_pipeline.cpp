@@ -1026,7 +1026,9 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
                 S.y16 = d16, S.uv16 = d16 + row * H->h, S.pitch_y16 = S.pitch_uv16 = row;
             }
         }
-        if (H->cfg.tracking) {  // upstream's surface is free once these copies are through (not the pyramid behind them: see pack_nv12_planes)
+        // upstream's surface is free once these copies are through (not the pyramid behind them: see pack_nv12_planes) -- an event of its own,
+        // but only for a frame somebody will wait for: a marker packet per frame costs the read-ahead stream what it saves the caller
+        if (H->cfg.tracking && f.hold < (int)H->slots.size()) {
             VSTAB_HIP_TRY(hipEventRecord(S.copied, H->pstream));
             S.copied_valid = true;
         }
