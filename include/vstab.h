@@ -414,7 +414,11 @@ typedef struct vstab_config {
                             upstream-supplied vstab_frame.delta_rotation (external gyro), smoothed the same way */
     uint64_t seed;       /* PCG32 seed replacing the reference's un-seeded rand() */
     void *stream;        /* hipStream_t the warp (and so dst) is enqueued on; NULL = default stream.  Ingest and
-                            tracking run on an internal stream that overlaps it; ordering is by events. */
+                            tracking run on internal streams that overlap it; ordering is by events.  The runtime has
+                            four hardware queues per process: beside a NULL stream the handle creates three streams
+                            (tracking, read-ahead, speculative corner detection), beside a stream of the caller's two
+                            (the detection then queues on the read-ahead stream; VSTAB_DETECT_STREAM=1 in the
+                            environment gives it its own) -- INTEGRATION.md section 3. */
     /* libdewobble-style lens surface.  lens_mode 0 (default) = the reference's preset cameras
      * and createMap.cl; 1 = the fields below replace preset / scale / crop_borders / zoom. */
     int lens_mode;
