@@ -125,7 +125,10 @@ class Tracker {
     // levels 1.. of the pyramid of `gray` into slot s (level 0 is the frame itself)
     // `done` (optional) completes with the LAST kernel of the pyramid, bound to that launch (launch_pyr_down); *done_bound says whether a kernel
     // took it (an image too small for a second level has no pyramid kernel: the caller records the event itself)
-    vstab_status build_pyramid(int s, const uint8_t *gray, size_t pitch, hipStream_t st, hipEvent_t done = nullptr, bool *done_bound = nullptr) {
+    // level 1 of set s, for a caller that fills it itself (launch_pack_pyr: the copy into the ring and the first level in one launch)
+    uint8_t *level1(int s) { return levels_ >= 2 ? pyr_[s][1].as<uint8_t>() : nullptr; }
+    size_t level1_pitch() const { return (size_t)lvl_w_[1]; }
+    vstab_status build_pyramid(int s, const uint8_t *gray, size_t pitch, hipStream_t st, hipEvent_t done = nullptr, bool *done_bound = nullptr, bool have_level1 = false) {
 #ifdef VSTAB_DEV
         static const bool twice = getenv("VSTAB_DEV_PYR_TWICE") != nullptr;
         if (twice && s != PYR_SETS) VSTAB_TRY(build_pyramid(PYR_SETS, gray, pitch, st));
@@ -141,6 +144,10 @@ class Tracker {
                 break;
             }
             const bool last = l == levels_ - 1;
+            if (l == 1 && have_level1) {  // (written by k_pack_pyr together with the copy; if it is the only level the caller records the event)
+                src = pyr_[s][l].as<uint8_t>(), sp = (size_t)lvl_w_[l];
+                continue;
+            }
             VSTAB_TRY(launch_pyr_down(src, sp, lvl_w_[l - 1], lvl_h_[l - 1], pyr_[s][l].as<uint8_t>(), (size_t)lvl_w_[l], st, last ? done : nullptr));
             if (last && done_bound) *done_bound = done != nullptr;
             src = pyr_[s][l].as<uint8_t>(), sp = (size_t)lvl_w_[l];
@@ -985,7 +992,9 @@ static vstab_status resolve_dmabuf(vstab_handle *H, vstab_frame &f) {
     return VSTAB_OK;
 }
 
-static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
+// pyr: the pyramid set the frame's levels go to; *level1_done: the copy kernel wrote level 1 as well (k_pack_pyr)
+static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot, int pyr, bool *level1_done) {
+    *level1_done = false;
     GpuStage gs(H, vstab_handle::ST_INGEST);
     if (f.width != H->w || f.height != H->h) return fail(VSTAB_ERR_INVALID, "frame size changed mid-stream");
     vstab_handle::Slot &S = H->slots[slot];
@@ -1035,6 +1044,14 @@ static vstab_status ingest(vstab_handle *H, const vstab_frame &f, int slot) {
     } else if (f.mem == 0) {
         // (while tracking, `ingested` completes with the pyramid enqueued behind the copy: upstream's surface is free as soon as the copy is)
         S.copied_valid = H->cfg.tracking != 0;
+        static const bool fuse = getenv("VSTAB_PACK_PYR") == nullptr || atoi(getenv("VSTAB_PACK_PYR")) != 0;  // development: =0 copies and builds level 1 in two launches
+        uint8_t *l1 = H->cfg.tracking ? H->tracker.level1(pyr) : nullptr;
+        if (fuse && l1 && pack_pyr_ok(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, l1, H->tracker.level1_pitch())) {
+            // one pass over the luma plane: the copy into the ring and the first pyramid level (k_pack_pyr)
+            VSTAB_TRY(launch_pack_pyr(static_cast<const uint8_t *>(f.y), f.pitch_y, static_cast<const uint8_t *>(f.uv), f.pitch_uv, f.width, f.height, dst, l1,
+                                      H->tracker.level1_pitch(), H->pstream, S.copied));
+            *level1_done = true;
+        } else
         VSTAB_TRY(pack_nv12_planes(f.y, f.pitch_y, f.uv, f.pitch_uv, f.width, f.height, dst, H->pstream, S.copied_valid ? S.copied : nullptr));
     } else {
         VSTAB_HIP_TRY(hipMemcpy2DAsync(dst, H->w, f.y, f.pitch_y, H->w, H->h, hipMemcpyHostToDevice, H->pstream));
@@ -1108,9 +1125,11 @@ static vstab_status prefetch_next(vstab_handle *H) {
     VSTAB_TRY(resolve_dmabuf(H, f));  // a DMA-BUF frame becomes an ordinary device frame here
     const int slot = H->acquire_slot();
     if (slot < 0) return fail(VSTAB_ERR_NOMEM, "look-ahead ring exhausted");
+    const int pyr = (int)(H->prefetch_count % PYR_SETS);
+    bool level1_done = false;
     {
         HT t(HostTimers::INGEST);
-        VSTAB_TRY(ingest(H, f, slot));
+        VSTAB_TRY(ingest(H, f, slot, pyr, &level1_done));
     }
     H->last_ingest_slot = slot;
     H->slots[slot].have_delta = f.delta_rotation != nullptr;
@@ -1128,14 +1147,13 @@ static vstab_status prefetch_next(vstab_handle *H) {
         H->copies.push_back({slot, H->ingest_serial, f.hold < 0 ? 0 : f.hold});
     if (H->slots[slot].borrowed && f.hold < vstab_handle::HOLD_FOREVER) H->borrows.push_back({H->ingest_serial, f.hold, false, -1});
     H->slots[slot].queued = true;  // reserved from now on (released when its warp has been enqueued)
-    const int pyr = (int)(H->prefetch_count % PYR_SETS);
     if (H->cfg.tracking) {
         HT t(HostTimers::PYRAMID);
         GpuStage gs(H, vstab_handle::ST_PYRAMID);
         // `ingested` = copy AND pyramid of this frame: the event completes with the pyramid's last kernel (no marker packet on the stream)
         static const bool bind_event = getenv("VSTAB_PYR_EVENT_RECORD") == nullptr;  // development: =1 records the event behind the kernels instead
         bool bound = false;
-        VSTAB_TRY(H->tracker.build_pyramid(pyr, H->gray(slot), H->gpitch(slot), H->pstream, bind_event ? H->slots[slot].ingested : nullptr, &bound));
+        VSTAB_TRY(H->tracker.build_pyramid(pyr, H->gray(slot), H->gpitch(slot), H->pstream, bind_event ? H->slots[slot].ingested : nullptr, &bound, level1_done));
         if (!bound) VSTAB_HIP_TRY(hipEventRecord(H->slots[slot].ingested, H->pstream));
     }
     // Key-frame rule, counter half (:415): the frame after this one re-detects corners on THIS frame when

@@ -75,8 +75,12 @@ __device__ __forceinline__ uint32_t pyr_down_dot4x4(const uint32_t (&d)[5][4]) {
 
 // outputs x0 .. x0+3 of row y, packed.  EDGE = false: the 16-byte window lies inside the row and everything is dword aligned.
 // NEAR: sw >= 16 and sh >= 4, so that every tap is within one reflection of the image.
-template <bool EDGE, bool NEAR>
-__device__ __forceinline__ uint32_t pyr_down_group4(const uint8_t *__restrict__ src, uint32_t spitch, int sw, int sh, int x0, int y, bool vec_ok) {
+// COPY: the group also copies the source bytes it owns -- columns 2 x0 .. 2 x0 + 7 of rows 2 y and 2 y + 1, which it has loaded anyway
+// (dwords 1 and 2 of window rows 2 and 3) -- to `cp` (pitch cpitch, 8-byte aligned rows when !EDGE): k_pack_pyr, the copy of an
+// upstream frame into the ring and the first pyramid level in one pass over the luma plane.
+template <bool EDGE, bool NEAR, bool COPY = false>
+__device__ __forceinline__ uint32_t pyr_down_group4(const uint8_t *__restrict__ src, uint32_t spitch, int sw, int sh, int x0, int y, bool vec_ok,
+                                                    uint8_t *__restrict__ cp = nullptr, uint32_t cpitch = 0) {
     const int sx0 = 2 * x0 - 4;  // the 16 bytes [sx0, sx0+16) hold the taps of outputs x0..x0+3: output c uses bytes 2c+2 .. 2c+6
     const uint8_t *row[5];
 #pragma unroll
@@ -122,13 +126,28 @@ __device__ __forceinline__ uint32_t pyr_down_group4(const uint8_t *__restrict__ 
             }
         }
     }
+    if (COPY) {
+#pragma unroll
+        for (int jj = 2; jj <= 3; jj++) {
+            const int r = 2 * y + jj - 2;
+            if (r >= sh) break;  // (an odd height's last output row has no second source row)
+            uint8_t *o = cp + (uint32_t)r * cpitch + (uint32_t)(2 * x0);
+            if (!EDGE) {
+                *reinterpret_cast<uint2 *>(o) = make_uint2(d[jj][1], d[jj][2]);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 8; b++)
+                    if (2 * x0 + b < sw) o[b] = (uint8_t)((b < 4 ? d[jj][1] : d[jj][2]) >> (8 * (b & 3)));
+            }
+        }
+    }
     return pyr_down_dot4x4(d);
 }
 
-template <bool EDGE, bool NEAR>
+template <bool EDGE, bool NEAR, bool COPY = false>
 __device__ __forceinline__ void pyr_down_group(const uint8_t *__restrict__ src, uint32_t spitch, int sw, int sh, uint8_t *__restrict__ dst, size_t dpitch,
-                                               int dw, int x0, int y, bool vec_ok) {
-    const uint32_t out = pyr_down_group4<EDGE, NEAR>(src, spitch, sw, sh, x0, y, vec_ok);
+                                               int dw, int x0, int y, bool vec_ok, uint8_t *__restrict__ cp = nullptr, uint32_t cpitch = 0) {
+    const uint32_t out = pyr_down_group4<EDGE, NEAR, COPY>(src, spitch, sw, sh, x0, y, vec_ok, cp, cpitch);
     uint8_t *o = dst + (size_t)((uint32_t)y * (uint32_t)dpitch) + x0;  // one 32-bit multiply (images are at most 32767 x 32767 bytes)
     if (!EDGE) {
         *reinterpret_cast<uint32_t *>(o) = out;
@@ -159,6 +178,49 @@ __global__ void __launch_bounds__(256) k_pyr_down(const uint8_t *__restrict__ sr
             pyr_down_group<true, true>(src, (uint32_t)spitch, sw, sh, dst, dpitch, dw, 4 * g, y, vec_ok != 0);
         else
             pyr_down_group<true, false>(src, (uint32_t)spitch, sw, sh, dst, dpitch, dw, 4 * g, y, vec_ok != 0);
+    }
+}
+
+// k_pack_pyr -- the copy of an upstream NV12 frame into the library's ring AND the first pyramid level of its luma plane in one launch
+// (vstab_frame.hold = 0: a decoder that recycles its surfaces): every group of k_pyr_down also stores the 8 x 2 source bytes it owns,
+// and workgroups behind the pyramid's copy the chroma plane.  One pass over the luma instead of two, one kernel less on the read-ahead
+// stream.  Same arithmetic, same bytes.
+__global__ void __launch_bounds__(256) k_pack_pyr(const uint8_t *__restrict__ src, uint32_t spitch, int sw, int sh, uint8_t *__restrict__ dst, uint32_t dpitch,
+                                                  int dw, int dh, int vec_ok, int g_lo, int g_hi, int nbx, int nb_edge, int n_groups, int near, int nb_pyr,
+                                                  const uint8_t *__restrict__ uv, uint32_t uvpitch, uint8_t *__restrict__ ring, uint32_t rpitch, int uv_vec) {
+    if ((int)blockIdx.x >= nb_pyr) {
+        // chroma: sh / 2 rows of sw bytes behind the luma rows of the ring, 16 bytes per thread where everything is aligned
+        uint8_t *cdst = ring + (uint32_t)sh * rpitch;
+        const int rows = sh / 2;
+        if (uv_vec) {
+            const int vecs = sw / 16;
+            for (int e = ((int)blockIdx.x - nb_pyr) * 256 + threadIdx.x; e < rows * vecs; e += ((int)gridDim.x - nb_pyr) * 256) {
+                const int r = e / vecs, c = e - r * vecs;
+                reinterpret_cast<uint4 *>(cdst + (uint32_t)r * rpitch)[c] = reinterpret_cast<const uint4 *>(uv + (uint32_t)r * uvpitch)[c];
+            }
+        } else {
+            for (int e = ((int)blockIdx.x - nb_pyr) * 256 + threadIdx.x; e < rows * sw; e += ((int)gridDim.x - nb_pyr) * 256) {
+                const int r = e / sw, c = e - r * sw;
+                cdst[(uint32_t)r * rpitch + c] = uv[(uint32_t)r * uvpitch + c];
+            }
+        }
+        return;
+    }
+    if ((int)blockIdx.x >= nb_edge) {
+        const int b = blockIdx.x - nb_edge, by = b / nbx, bx = b - by * nbx;
+        const int g = g_lo + bx * 64 + (threadIdx.x & 63), y = by * 4 + (threadIdx.x >> 6);
+        if (g >= g_hi || y >= dh) return;
+        pyr_down_group<false, true, true>(src, spitch, sw, sh, dst, dpitch, dw, 4 * g, y, true, ring, rpitch);
+    } else {
+        const int n_edge = n_groups - (g_hi - g_lo);  // edge groups per row
+        const int e = blockIdx.x * 256 + threadIdx.x;
+        const int y = e / n_edge, i = e - y * n_edge;
+        if (y >= dh) return;
+        const int g = i < g_lo ? i : g_hi + (i - g_lo);
+        if (near)
+            pyr_down_group<true, true, true>(src, spitch, sw, sh, dst, dpitch, dw, 4 * g, y, vec_ok != 0, ring, rpitch);
+        else
+            pyr_down_group<true, false, true>(src, spitch, sw, sh, dst, dpitch, dw, 4 * g, y, vec_ok != 0, ring, rpitch);
     }
 }
 
@@ -1297,6 +1359,29 @@ vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, 
     const int nb_edge = div_up(dh * (n_groups - (g_hi - g_lo)), 256);
     hipExtLaunchKernelGGL(k_pyr_down, dim3(nb_edge + nb_int), dim3(256), 0, s, nullptr, done, 0, src, spitch, sw, sh, dst, dpitch, dw, dh, vec_ok, g_lo, g_hi, nbx, nb_edge,
                           n_groups, near);
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+// Copy + first level in one launch (k_pack_pyr): ring = the NV12 frame (y, uv) packed (luma rows of pitch w, chroma rows behind them: what
+// vstab_pack_nv12 writes), dst = pyrDown(luma).  Only where pack_pyr_ok says so; `copied` (optional) completes with the launch.
+bool pack_pyr_ok(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int w, int h, const void *ring, const void *dst, size_t dpitch) {
+    return w >= 16 && h >= 4 && !(w & 7) && !(h & 1) && reinterpret_cast<uintptr_t>(y) % 4 == 0 && pitch_y % 4 == 0 && reinterpret_cast<uintptr_t>(ring) % 8 == 0 &&
+           reinterpret_cast<uintptr_t>(dst) % 4 == 0 && dpitch % 4 == 0 && pitch_y < (1u << 24) && pitch_uv < (1u << 24) && (uint64_t)pitch_y * (uint64_t)h < (1ull << 32) &&
+           (uint64_t)w * (uint64_t)h * 3 / 2 < (1ull << 32);
+}
+vstab_status launch_pack_pyr(const uint8_t *y, size_t pitch_y, const uint8_t *uv, size_t pitch_uv, int sw, int sh, uint8_t *ring, uint8_t *dst, size_t dpitch,
+                             hipStream_t s, hipEvent_t copied) {
+    const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    if (!pack_pyr_ok(y, pitch_y, uv, pitch_uv, sw, sh, ring, dst, dpitch)) return fail(VSTAB_ERR_INVALID, "pack_pyr: planes not aligned for the fused copy");
+    const int n_groups = div_up(dw, 4);
+    const int g_lo = 1, g_hi = std::max(g_lo, std::min(sw >= 12 ? (sw - 12) / 8 + 1 : 0, dw / 4));
+    const int nbx = div_up(g_hi - g_lo, 64), nb_int = nbx * div_up(dh, 4);
+    const int nb_edge = div_up(dh * (n_groups - (g_hi - g_lo)), 256);
+    const int uv_vec = reinterpret_cast<uintptr_t>(uv) % 16 == 0 && pitch_uv % 16 == 0 && sw % 16 == 0 && reinterpret_cast<uintptr_t>(ring) % 16 == 0;
+    const int nb_uv = std::max(1, std::min(256, (int)div_up((unsigned)(sw * (sh / 2)), 256u * 16u)));
+    hipExtLaunchKernelGGL(k_pack_pyr, dim3(nb_edge + nb_int + nb_uv), dim3(256), 0, s, nullptr, copied, 0, y, (uint32_t)pitch_y, sw, sh, dst, (uint32_t)dpitch, dw, dh, 1, g_lo,
+                          g_hi, nbx, nb_edge, n_groups, 1, nb_edge + nb_int, uv, (uint32_t)pitch_uv, ring, (uint32_t)sw, uv_vec);
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }

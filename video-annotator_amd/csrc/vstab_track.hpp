@@ -30,6 +30,11 @@ inline int lk_levels(int w, int h) {
 
 // done (optional): an event that completes with the kernel, bound to the launch itself (no marker packet of its own on the stream)
 vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *dst, size_t dpitch, hipStream_t s, hipEvent_t done = nullptr);
+// the copy of an NV12 frame into the ring (what vstab_pack_nv12 writes: luma rows of pitch w, chroma rows behind them) and the first pyramid
+// level of its luma in one launch; `copied` (optional) completes with it
+bool pack_pyr_ok(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int w, int h, const void *ring, const void *dst, size_t dpitch);
+vstab_status launch_pack_pyr(const uint8_t *y, size_t pitch_y, const uint8_t *uv, size_t pitch_uv, int w, int h, uint8_t *ring, uint8_t *dst, size_t dpitch, hipStream_t s,
+                             hipEvent_t copied = nullptr);
 // two levels in one launch: mid = pyrDown(src) ((sw+1)/2 x (sh+1)/2), dst = pyrDown(mid); only where pyr_down_x2_ok(sw, sh)
 bool pyr_down_x2_ok(int sw, int sh);
 vstab_status launch_pyr_down_x2(const uint8_t *src, size_t spitch, int sw, int sh, uint8_t *mid, size_t mpitch, uint8_t *dst, size_t dpitch, hipStream_t s,
