@@ -293,6 +293,7 @@ class Tracker {
     // sort + minimum-distance pass, so that by the time the key frame comes its corners are simply there.
     void spec_select_async(int max_corners, double min_distance) {
         spec_join();
+        spec_owner_.store(0, std::memory_order_release);  // nobody has taken this selection yet (the helper thread, or the caller: spec_poll_inline)
         spec_state_.store(1, std::memory_order_release);
         if (!spec_thread_started_) {
             spec_thread_started_ = true;
@@ -305,6 +306,10 @@ class Tracker {
                     spec_cv_.wait(lk, [this] { return spec_job_ || spec_quit_; });
                     if (spec_quit_) return;
                     spec_job_ = false;
+                    {
+                        int unclaimed = 0;  // the caller may have done this selection itself while this thread was waking up
+                        if (!spec_owner_.compare_exchange_strong(unclaimed, 1, std::memory_order_acq_rel)) continue;
+                    }
                     lk.unlock();
                     int result = 3;
                     const auto t0 = std::chrono::steady_clock::now();
@@ -338,6 +343,25 @@ class Tracker {
         }
         spec_cv_.notify_one();
     }
+    // The helper thread sleeps on a condition variable between two detections (720 us apart at 4K); on a busy host its wake-up can take
+    // longer than the detection itself.  Whoever looks for the corners first while the job is still unclaimed and the detection's event
+    // has completed does the selection on the spot (45 us of host time instead of a wait for another thread's wake-up).
+    void spec_poll_inline() {
+        if (spec_state_.load(std::memory_order_acquire) != 1 || !spec_ev_ || hipEventQuery(spec_ev_) != hipSuccess) {
+            (void)hipGetLastError();  // "not ready" is an answer, not an error the next launch check should find
+            return;
+        }
+        int unclaimed = 0;
+        if (!spec_owner_.compare_exchange_strong(unclaimed, 2, std::memory_order_acq_rel)) return;  // the helper thread has it
+        int result = 3;
+        const unsigned int n = spec_host_.as<unsigned int>()[0];
+        if (n <= SPEC_CAP) {
+            select_corners(reinterpret_cast<unsigned long long *>(spec_host_.as<uint8_t>() + 64), n, spec_max_, spec_dist_, spec_xy_);
+            result = 2;
+        }
+        if (debug_spec()) std::fprintf(stderr, "selection done by the caller (the helper thread had not woken up): %zu of %u candidates\n", spec_xy_.size() / 2, n);
+        spec_state_.store(result, std::memory_order_release);
+    }
     // 0 = no asynchronous selection, 1 = running, 2 = corners ready, 3 = failed (candidate overflow / device error)
     int spec_state() const { return spec_state_.load(std::memory_order_acquire); }
     void spec_join() {
@@ -363,7 +387,8 @@ class Tracker {
     }
     // returns true and fills xy if the speculative result is usable (candidate count within SPEC_CAP)
     bool spec_finish(int max_corners, double min_distance, std::vector<float> &xy) {
-        if (spec_state() != 0) {  // the helper thread has (or is about to have) the answer
+        if (spec_state() != 0) {  // the helper thread has (or is about to have) the answer -- or nobody yet: then this thread, if the kernels are through
+            spec_poll_inline();
             spec_join();
             const bool ok = spec_state() == 2;
             if (ok) xy = spec_xy_;
@@ -538,6 +563,7 @@ class Tracker {
     std::mutex spec_m_;
     std::condition_variable spec_cv_;
     std::atomic<int> spec_state_{0};
+    std::atomic<int> spec_owner_{0};  // who runs the posted selection: 0 nobody yet, 1 the helper thread, 2 the caller (spec_poll_inline)
     int spec_max_ = 200;
     double spec_dist_ = 30.0;
     std::vector<float> spec_xy_;
@@ -1314,6 +1340,7 @@ static vstab_status launch_tracking(vstab_handle *H) {
             if (avail <= 0 || back.launch.n_slots == 0) break;
             const long kc = back.last_key_after + 21;  // next planned key frame
             if (next == kc) {
+                if (H->tracker.spec_tag() == tail) H->tracker.spec_poll_inline();
                 if (H->tracker.spec_tag() != tail || H->tracker.spec_state() != 2) {
                     if (debug_spec() && H->tracker.spec_tag() == tail)
                         std::fprintf(stderr, "frame %ld: corners for key frame %ld not selected yet (state %d)\n", F, next, H->tracker.spec_state());
