@@ -307,6 +307,15 @@ class Tracker {
                     if (spec_quit_) return;
                     spec_job_ = false;
                     {
+                        // (development: VSTAB_SPEC_HELPER_DELAY_US=n makes this thread wake up late, so that a test reaches spec_poll_inline)
+                        const char *late = getenv("VSTAB_SPEC_HELPER_DELAY_US");  // (read per job, once in twenty frames: a test sets it for one handle)
+                        const long late_us = late ? atol(late) : 0;
+                        if (late_us > 0) {
+                            lk.unlock();
+                            std::this_thread::sleep_for(std::chrono::microseconds(late_us));
+                            lk.lock();
+                            if (spec_quit_) return;
+                        }
                         int unclaimed = 0;  // the caller may have done this selection itself while this thread was waking up
                         if (!spec_owner_.compare_exchange_strong(unclaimed, 1, std::memory_order_acq_rel)) continue;
                     }
