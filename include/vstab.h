@@ -161,14 +161,30 @@ typedef enum vstab_map_mode {
 } vstab_map_mode;
 typedef enum vstab_out_format {
     VSTAB_OUT_BGR8 = 0, /* what FrameSourceWarp emits (FrameSourceWarp.cpp:313) */
-    VSTAB_OUT_NV12 = 1  /* BGR result converted with cvtColor(COLOR_BGR2YUV_I420) arithmetic, chroma interleaved */
+    VSTAB_OUT_NV12 = 1, /* BGR result converted with cvtColor(COLOR_BGR2YUV_I420) arithmetic, chroma interleaved */
+    /* PLANE-WISE warp, no colour round trip (SURVEY.md 8(f) row 2 as written: what a filter between NV12 surfaces does,
+     * render.ts:606-607, 664-665, 688): the two planes of the source are remapped as they are.
+     *   luma    cv::remap(INTER_LINEAR, BORDER_CONSTANT 16) of the Y plane with the map and 1/32-pixel quantisation of the BGR path;
+     *   chroma  cv::remap(INTER_LINEAR, BORDER_CONSTANT (128, 128)) of the interleaved UV plane (2 channels, w/2 x h/2).  Output chroma
+     *           sample (cx, cy) -- ceil(dst_width / 2) x ceil(dst_height / 2) of them -- sits on luma pixel (2 cx, 2 cy), as source
+     *           chroma sample (i, j) sits on source luma pixel (2 i, 2 j): the siting the BGR path's conversions imply (NV12 -> BGR
+     *           replicates a chroma sample over its 2 x 2 block, BGR -> NV12 takes the block's top-left pixel).  Its position in the
+     *           source chroma plane is that luma pixel's map entry halved, (mapx / 2, mapy / 2) -- exact in fp32 -- and cv::remap
+     *           quantises it like any map: cvRound(32 * (map / 2)).  A sample offset common to both frames (MPEG-2's half-pixel
+     *           vertical shift) cancels to first order;
+     *   border  limited-range black (Y 16, U = V 128): what the BGR path's border, cv::remap's Scalar(0), is in this colour space
+     *           (a border of 0 would be green).  As in cv::remap a footprint wholly outside the source gives the border value
+     *           and a tap outside it enters the blend as the border value.
+     * Not the bytes of VSTAB_OUT_NV12 (which blends converted BGR pixels and converts back); on in-gamut content the two agree within
+     * a level.  No reference counterpart: defined here and in the test infrastructure's plain-C statement (vo_remap_plane). */
+    VSTAB_OUT_NV12_PLANAR = 2
 } vstab_out_format;
 /* vstab_create_map with a projection pair.  params as for vstab_create_map (focal lengths in pixels). */
 VSTAB_API vstab_status vstab_create_map_ex(void *map_x, size_t pitch_x, void *map_y, size_t pitch_y,
                                            int cols, int rows, const float params[17], int map_mode,
                                            void *stream);
-/* vstab_warp_nv12_bgr with a projection pair and an output format.  VSTAB_OUT_NV12: dst is the luma plane
- * (width bytes per row), dst_uv the interleaved chroma plane (ceil(height/2) rows of 2*ceil(width/2) bytes);
+/* vstab_warp_nv12_bgr with a projection pair and an output format.  VSTAB_OUT_NV12 / VSTAB_OUT_NV12_PLANAR: dst is the luma
+ * plane (width bytes per row), dst_uv the interleaved chroma plane (ceil(height/2) rows of 2*ceil(width/2) bytes);
  * dst_uv is ignored for VSTAB_OUT_BGR8. */
 VSTAB_API vstab_status vstab_warp_nv12_ex(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv,
                                           int src_width, int src_height, const float params[17], int map_mode,
@@ -200,6 +216,15 @@ VSTAB_API vstab_status vstab_warp_p010(const void *y, size_t pitch_y, const void
                                        int src_width, int src_height, const float params[17], const float *rot_bottom,
                                        int map_mode, int blend, void *dst_bgr16, size_t pitch_dst, int dst_width,
                                        int dst_height, void *stream);
+
+/* The plane-wise warp at 10 bits: P010 planes in, P010 planes out, no colour round trip -- VSTAB_OUT_NV12_PLANAR's definition on
+ * the ten significant bits of each word (sample = word >> 6; border 64 / 512; result word = value << 6).  blend: VSTAB_BLEND_EXACT,
+ * (sum + 512) >> 10 per sample, or VSTAB_BLEND_FP16, vstab_warp_p010's binary16 chain per sample.  All map modes; rot_bottom != NULL
+ * adds the rotation per output row (modes 0 / 1 / 5).  dst_y: dst_width words per row; dst_uv: ceil(dst_height / 2) rows of
+ * ceil(dst_width / 2) (U, V) word pairs.  Pitches in bytes; planes 2-byte aligned, chroma pairs 4-byte aligned. */
+VSTAB_API vstab_status vstab_warp_p010_planar(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int src_width, int src_height,
+                                              const float params[17], const float *rot_bottom, int map_mode, int blend, void *dst_y,
+                                              size_t pitch_dst_y, void *dst_uv, size_t pitch_dst_uv, int dst_width, int dst_height, void *stream);
 
 /* vstab_warp_p010 with P010 planes out in the same kernel (no 16-bit BGR frame in memory): the blended 10-bit BGR pixel is converted
  * in registers by vstab_cvt_bgr16_p010's arithmetic (below).  Served by the LDS-tiled kernel only: VSTAB_ERR_UNSUPPORTED unless the

@@ -75,6 +75,11 @@ def lib():
         L.vo_remap_bilinear10.argtypes = [c.c_void_p, c.c_int, c.c_int, f32p, f32p, c.c_int, c.c_void_p, c.c_int, c.c_int]
         L.vo_cvt_p010_bgr10.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.c_void_p]
         L.vo_warp_nv12_rs.argtypes = [u8p, c.c_int, c.c_int, f32p, f32p, c.c_int, c.c_int, u8p, c.c_int, c.c_int, u8p]
+        L.vo_chroma_maps.argtypes = [f32p, f32p, c.c_int, c.c_int, f32p, f32p]
+        L.vo_remap_plane.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.c_int, c.c_int, f32p, f32p, c.POINTER(c.c_int), c.c_int, c.c_void_p,
+                                     c.c_size_t, c.c_int, c.c_int]
+        L.vo_warp_planar_mapped.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.c_int, f32p, f32p, c.c_int, c.c_void_p,
+                                            c.c_void_p, c.c_int, c.c_int, f32p]
         L.vo_min_eig.argtypes = [u8p, c.c_size_t, c.c_int, c.c_int, f32p]
         L.vo_good_features.argtypes = [u8p, c.c_size_t, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, f32p, f32p]
         L.vo_good_features.restype = c.c_int
@@ -374,6 +379,65 @@ def warp_nv12_rs(nv12, params, rot_bottom, dw, dh, mode=0, out_format=0):
     if out_format == 0:
         return out.reshape(dh, dw, 3)
     return out[: dw * dh].reshape(dh, dw), out[dw * dh:].reshape(ch, cw, 2)
+
+
+def chroma_maps(mapx, mapy):
+    """Map planes of the chroma planes in the plane-wise warp: cmap(cx, cy) = map(2 cx, 2 cy) * 0.5f (vo_chroma_maps)."""
+    mx, mxp = _f32(mapx)
+    my, myp = _f32(mapy)
+    dh, dw = mx.shape
+    cmx = np.empty(((dh + 1) // 2, (dw + 1) // 2), np.float32)
+    cmy = np.empty_like(cmx)
+    lib().vo_chroma_maps(mxp, myp, dw, dh, _p(cmx, ctypes.c_float), _p(cmy, ctypes.c_float))
+    return cmx, cmy
+
+
+def warp_planar_mapped(y, uv, mapx, mapy, depth=8, blend=0):
+    """The plane-wise warp (SURVEY.md 8(f) row 2 as written: no colour round trip; DEFINED in vo_remap_plane / vo_warp_planar_mapped)
+    with luma map planes from anywhere.  depth 8: y (h, w) uint8, uv (h/2, w) uint8 interleaved -> (y' (dh, dw), uv' (ceil(dh/2),
+    2 * ceil(dw/2))) uint8.  depth 10: the same shapes in uint16 P010 words."""
+    dt = np.uint8 if depth == 8 else np.uint16
+    ya, ua = np.ascontiguousarray(y, dt), np.ascontiguousarray(uv, dt)
+    h, w = ya.shape
+    mx, mxp = _f32(mapx)
+    my, myp = _f32(mapy)
+    dh, dw = mx.shape
+    cw, ch = (dw + 1) // 2, (dh + 1) // 2
+    oy, ouv = np.empty((dh, dw), dt), np.empty((ch, 2 * cw), dt)
+    work = np.empty(2 * cw * ch, np.float32)
+    vp = ctypes.c_void_p
+    lib().vo_warp_planar_mapped(ya.ctypes.data_as(vp), ctypes.c_size_t(ya.strides[0]), ua.ctypes.data_as(vp), ctypes.c_size_t(ua.strides[0]), w, h,
+                                int(depth), mxp, myp, int(blend), oy.ctypes.data_as(vp), ouv.ctypes.data_as(vp), dw, dh, _p(work, ctypes.c_float))
+    return oy, ouv
+
+
+def _split_nv12(nv12):
+    rows, w = nv12.shape
+    h = rows * 2 // 3
+    return nv12[:h], nv12[h:]
+
+
+def warp_nv12_planar(nv12, params, dw, dh, mode=0, rot_bottom=None):
+    """Plane-wise NV12 -> NV12 warp, map in the CPU oracle's (IEEE) arithmetic: -> (y', uv')."""
+    mx, my = create_map_rs(params, rot_bottom, dw, dh, mode) if rot_bottom is not None else create_map_ex(params, dw, dh, mode)
+    return warp_planar_mapped(*_split_nv12(np.asarray(nv12)), mx, my)
+
+
+def warp_nv12_planar_ref_gfx950(nv12, params, dw, dh, rot_bottom=None):
+    """The same with the map from the REFERENCE's own kernel on this GPU (the pipeline object's default arithmetic)."""
+    mx, my = create_map_ref_gfx950(params, dw, dh) if rot_bottom is None else create_map_ref_gfx950_rs(params, rot_bottom, dw, dh)
+    return warp_planar_mapped(*_split_nv12(np.asarray(nv12)), mx, my)
+
+
+def warp_p010_planar(y, uv, params, dw, dh, mode=0, rot_bottom=None, blend=0):
+    """Plane-wise P010 -> P010 warp (config 5's encoder hand-off without a colour round trip), IEEE map."""
+    mx, my = create_map_rs(params, rot_bottom, dw, dh, mode) if rot_bottom is not None else create_map_ex(params, dw, dh, mode)
+    return warp_planar_mapped(y, uv, mx, my, 10, blend)
+
+
+def warp_p010_planar_ref_gfx950(y, uv, params, dw, dh, rot_bottom=None, blend=0):
+    mx, my = create_map_ref_gfx950(params, dw, dh) if rot_bottom is None else create_map_ref_gfx950_rs(params, rot_bottom, dw, dh)
+    return warp_planar_mapped(y, uv, mx, my, 10, blend)
 
 
 def min_eig(gray):

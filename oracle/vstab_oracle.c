@@ -564,6 +564,84 @@ VO_API void vo_warp_p010(const uint8_t *y, size_t pitch_y, const uint8_t *uv, si
 }
 
 /* ------------------------------------------------------------------------------------------
+ * f2 as SURVEY.md 8(f) row 2 states it: the PLANE-WISE warp, "without a colour round trip" -- what an ffmpeg filter that
+ * takes and returns NV12 / P010 surfaces does (render.ts:606-607, 664-665, 688; encoders render.ts:275-281).  The C++
+ * prototype stops at BGR and libdewobble is not in the reference tree, so this operator is DEFINED here ("parity unpinned")
+ * as what an OpenCV caller would write with the reference's own map:
+ *     remap(Y,  Y',  mapx,  mapy,  INTER_LINEAR, BORDER_CONSTANT, Scalar(16))            -- luma, 1 channel
+ *     remap(UV, UV', cmapx, cmapy, INTER_LINEAR, BORDER_CONSTANT, Scalar(128, 128))      -- chroma, 2 interleaved channels
+ *     cmap(cx, cy) = map(2 cx, 2 cy) * 0.5f,   ceil(dw / 2) x ceil(dh / 2) entries
+ *   - luma uses the map and cv::remap's quantisation of the BGR path (vo_remap_pixel): same coordinates, same weights;
+ *   - chroma: sample (cx, cy) of either chroma plane sits on luma pixel (2 cx, 2 cy) -- the siting vo_cvt_bgr_nv12 uses when
+ *     it takes chroma from the top-left pixel of a 2 x 2 block, and the one cvtColor(NV12 -> BGR) implies when it replicates
+ *     a chroma sample over its block.  Source and destination share the convention, so a sample offset common to both
+ *     (MPEG-2's half-pixel vertical shift) cancels to first order.  The map entry of that luma pixel, halved (exact in
+ *     fp32), is the position in the chroma plane; cv::remap then quantises it like any other map: cvRound(32 * cmap);
+ *   - border: limited-range black (Y 16, U = V 128; 64 / 512 at 10 bits) -- what the BGR path's border, cv::remap's
+ *     Scalar(0) = black, is in this colour space (vo_cvt_bgr_nv12 of (0, 0, 0)).  A border of 0 would be green.
+ *     As in cv::remap, a footprint entirely outside the source gives the border value, and a tap outside it contributes the
+ *     border value with its weight;
+ *   - 10 bits (P010 words, significant bits at the top): sample = word >> 6, same coordinates and weights, blend 0 exact
+ *     ((sum + 512) >> 10), blend 1 the binary16 chain of vo_blend_f16; output word = value << 6.
+ * ------------------------------------------------------------------------------------------ */
+VO_API void vo_chroma_maps(const float *mapx, const float *mapy, int dw, int dh, float *cmx, float *cmy) {
+    const int cw = (dw + 1) / 2, ch = (dh + 1) / 2;
+    for (int cy = 0; cy < ch; cy++)
+        for (int cx = 0; cx < cw; cx++) {
+            cmx[(size_t)cy * cw + cx] = mapx[(size_t)(2 * cy) * dw + 2 * cx] * 0.5f;
+            cmy[(size_t)cy * cw + cx] = mapy[(size_t)(2 * cy) * dw + 2 * cx] * 0.5f;
+        }
+}
+
+/* cv::remap(INTER_LINEAR, BORDER_CONSTANT, border) of one plane: cn interleaved channels (1 or 2), depth 8 (bytes) or 10
+ * (16-bit words, sample = word >> 6, stored back << 6).  Pitches in bytes.  border[c]: the constant, as a sample value. */
+VO_API void vo_remap_plane(const uint8_t *src, size_t spitch, int sw, int sh, int cn, int depth, const float *mapx, const float *mapy,
+                           const int *border, int blend, uint8_t *dst, size_t dpitch, int dw, int dh) {
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            const float mx = mapx[(size_t)y * dw + x], my = mapy[(size_t)y * dw + x];
+            const int sx = vo_cvround(mx * 32.0f), sy = vo_cvround(my * 32.0f);
+            const int X = vo_sat16(sx >> 5), Y = vo_sat16(sy >> 5), fx = sx & 31, fy = sy & 31;
+            const int outside = X >= sw || X + 1 < 0 || Y >= sh || Y + 1 < 0;
+            const int w00 = (32 - fx) * (32 - fy), w01 = fx * (32 - fy), w10 = (32 - fx) * fy, w11 = fx * fy;
+            const int in00 = X >= 0 && Y >= 0, in01 = X + 1 < sw && Y >= 0, in10 = X >= 0 && Y + 1 < sh, in11 = X + 1 < sw && Y + 1 < sh;
+            for (int c = 0; c < cn; c++) {
+                int v;
+                if (outside) {
+                    v = border[c];
+                } else {
+#define VO_TAP(XX, YY, IN) ((IN) ? (depth == 8 ? (int)src[(size_t)(YY) * spitch + (size_t)(XX) * cn + c]                                         \
+                                               : vo_p010_sample(src + (size_t)(YY) * spitch, (XX) * cn + c))                                      \
+                                 : border[c])
+                    const int p00 = VO_TAP(X, Y, in00), p01 = VO_TAP(X + 1, Y, in01), p10 = VO_TAP(X, Y + 1, in10), p11 = VO_TAP(X + 1, Y + 1, in11);
+#undef VO_TAP
+                    v = blend ? (int)vo_blend_f16(p00, p01, p10, p11, w00, w01, w10, w11) : (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + 512) >> 10;
+                }
+                if (depth == 8) {
+                    dst[(size_t)y * dpitch + (size_t)x * cn + c] = (uint8_t)v;
+                } else {
+                    uint8_t *o = dst + (size_t)y * dpitch + ((size_t)x * cn + c) * 2;
+                    o[0] = (uint8_t)((v << 6) & 255), o[1] = (uint8_t)((v << 6) >> 8);
+                }
+            }
+        }
+}
+
+/* The plane-wise warp given luma map planes (from vo_create_map*, or from anywhere else: the reference's own kernel run on the GPU).
+ * y / uv: source planes (w x h luma, w/2 x h/2 chroma pairs), dst_y: dw x dh, dst_uv: ceil(dw/2) x ceil(dh/2) pairs, all dense
+ * (pitch = row bytes).  work: 2 * ceil(dw/2) * ceil(dh/2) floats. */
+VO_API void vo_warp_planar_mapped(const uint8_t *y, size_t pitch_y, const uint8_t *uv, size_t pitch_uv, int w, int h, int depth, const float *mapx,
+                                  const float *mapy, int blend, uint8_t *dst_y, uint8_t *dst_uv, int dw, int dh, float *work) {
+    const int cw = (dw + 1) / 2, ch = (dh + 1) / 2, bps = depth == 8 ? 1 : 2;
+    const int black_y[1] = {depth == 8 ? 16 : 64}, black_uv[2] = {depth == 8 ? 128 : 512, depth == 8 ? 128 : 512};
+    float *cmx = work, *cmy = work + (size_t)cw * ch;
+    vo_remap_plane(y, pitch_y, w, h, 1, depth, mapx, mapy, black_y, blend, dst_y, (size_t)dw * bps, dw, dh);
+    vo_chroma_maps(mapx, mapy, dw, dh, cmx, cmy);
+    vo_remap_plane(uv, pitch_uv, w / 2, h / 2, 2, depth, cmx, cmy, black_uv, blend, dst_uv, (size_t)cw * 2 * bps, cw, ch);
+}
+
+/* ------------------------------------------------------------------------------------------
  * a3: goodFeaturesToTrack(gray, 200, 0.01, 30), call site FrameSourceWarp.cpp:230.
  * Third-party arithmetic (OpenCV 4.5 imgproc featureselect/corner, CPU path).
  * ------------------------------------------------------------------------------------------ */

@@ -27,3 +27,17 @@ def warp_p010(y, uv, params, dw, dh, rot_bottom=None, blend=0, prec=DEFAULT):
     if prec == OPENCL:
         return oracle.warp_p010_ref_gfx950(y, uv, params, dw, dh, rot_bottom, blend)
     return oracle.warp_p010(y, uv, params, dw, dh, rot_bottom, 0, blend)
+
+
+def warp_planar(frame, params, dw, dh, prec=DEFAULT, rot_bottom=None, mode=0):
+    """(y', uv') the plane-wise NV12 -> NV12 warp must emit for `frame` (packed NV12).  `mode`: IEEE projection pairs 0..4."""
+    if prec == OPENCL:
+        return oracle.warp_nv12_planar_ref_gfx950(frame, params, dw, dh, rot_bottom)
+    return oracle.warp_nv12_planar(frame, params, dw, dh, mode, rot_bottom)
+
+
+def warp_p010_planar(y, uv, params, dw, dh, rot_bottom=None, blend=0, prec=DEFAULT, mode=0):
+    """(y', uv') P010 words of the plane-wise 10-bit warp."""
+    if prec == OPENCL:
+        return oracle.warp_p010_planar_ref_gfx950(y, uv, params, dw, dh, rot_bottom, blend)
+    return oracle.warp_p010_planar(y, uv, params, dw, dh, mode, rot_bottom, blend)

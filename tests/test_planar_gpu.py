@@ -1,0 +1,203 @@
+"""GPU parity of the plane-wise warp (SURVEY.md 8(f) row 2 as written: NV12 -> NV12 / P010 -> P010, no colour round trip) through the
+C ABI: vstab_warp_nv12_ex / _rs with VSTAB_OUT_NV12_PLANAR and vstab_warp_p010_planar.  Bar: every byte / word equals the checker --
+the CPU oracle's chain for the IEEE maps, and for the default arithmetic (VSTAB_MAP_CREATEMAP_CL_OPENCL) the REFERENCE's own createMap
+kernel run on this GPU followed by the oracle's plane-wise remap."""
+import numpy as np
+import pytest
+
+import expect
+import oracle
+import synth
+from test_p010_cpu import p010_frame
+
+pytestmark = pytest.mark.gpu
+
+ROTS = [(0.0, 0.0, 0.0), (0.02, -0.03, 0.01), (-0.15, 0.1, 0.3)]
+
+
+def dev(a, cuda):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def cams(w, h, rvec, preset=4):
+    K = oracle.get_preset_camera(preset, w, h)
+    Ko, (dw, dh) = oracle.get_output_camera(K, w, h)
+    return oracle.map_params(K, Ko, oracle.rodrigues(rvec)), dw, dh, K, Ko
+
+
+def planes(vs, cuda, dw, dh, pad=0, dtype=None, fill=7):
+    import torch
+    dtype = dtype or torch.uint8
+    cw = (dw + 1) // 2
+    yb = torch.full((dh, dw + pad), fill, dtype=dtype, device=cuda)
+    cb = torch.full(((dh + 1) // 2, 2 * cw + pad), fill, dtype=dtype, device=cuda)
+    return yb, cb, yb[:, :dw], cb[:, :2 * cw]
+
+
+def run8(vs, cuda, f, p, dw, dh, mode, rot_bottom=None, pad=0):
+    yb, cb, yv, cv = planes(vs, cuda, dw, dh, pad)
+    fd = dev(f, cuda)
+    if rot_bottom is None:
+        vs.warp_nv12(fd, p, dw, dh, mode, vs.OUT_NV12_PLANAR, out=(yv, cv))
+    else:
+        vs.warp_nv12_rs(fd, p, rot_bottom, dw, dh, mode, vs.OUT_NV12_PLANAR, out=(yv, cv))
+    if pad:
+        assert bool((yb[:, dw:] == 7).all()) and bool((cb[:, cv.shape[1]:] == 7).all())      # nothing written beyond a row
+    return yv.cpu().numpy(), cv.cpu().numpy()
+
+
+def test_planar_bit_exact_vs_oracle_sizes_and_rotations(vs, cuda):
+    """IEEE map (mode 0): 128 x 72 ... 1080p, preset cameras, odd outputs, rotations that look past the source (black border)."""
+    for (w, h) in [(128, 72), (320, 180), (640, 368), (1920, 1080)]:
+        f = synth.nv12(w + h, w, h, full_range=(w < 1000))
+        for rv in (ROTS if w < 1000 else ROTS[1:2]):
+            p, dw, dh, _, _ = cams(w, h, rv)
+            for (ow, oh) in ([(dw, dh), (dw - 1, dh - 3)] if w < 1000 else [(dw, dh)]):
+                gy, guv = run8(vs, cuda, f, p, ow, oh, vs.MAP_CREATEMAP_CL, pad=(16 if w == 320 else 0))
+                ey, euv = oracle.warp_nv12_planar(f, p, ow, oh, 0)
+                assert np.array_equal(gy, ey), (w, rv, ow, oh, int((gy != ey).sum()))
+                assert np.array_equal(guv, euv), (w, rv, ow, oh, int((guv != euv).sum()))
+
+
+def test_planar_every_projection_pair_and_per_row_rotation(vs, cuda):
+    w, h, dw, dh = 640, 360, 481, 271
+    f = synth.nv12(9, w, h, full_range=True)
+    lenses = [(oracle.PROJ_FISH, 150.0, oracle.PROJ_RECT, 110.0), (oracle.PROJ_FISH, 150.0, oracle.PROJ_FISH, 165.0),
+              (oracle.PROJ_RECT, 100.0, oracle.PROJ_RECT, 80.0), (oracle.PROJ_RECT, 100.0, oracle.PROJ_FISH, 300.0)]
+    for ip, ifov, op, ofov in lenses:
+        Kin, Kout = oracle.lens_camera(ip, ifov, w, h), oracle.lens_camera(op, ofov, dw, dh)
+        mode = oracle.map_mode(ip, op)
+        for rv in ROTS + [(0.0, 1.2, 0.0)]:
+            p = oracle.map_params(Kin, Kout, oracle.rodrigues(rv))
+            gy, guv = run8(vs, cuda, f, p, dw, dh, mode)
+            ey, euv = oracle.warp_nv12_planar(f, p, dw, dh, mode)
+            assert np.array_equal(gy, ey) and np.array_equal(guv, euv), (mode, rv)
+    # a rotation per output row (modes 0 and 1)
+    p, dw, dh, K, Ko = cams(w, h, (0.03, -0.02, 0.05))
+    rb = oracle.map_params(K, Ko, oracle.rodrigues((0.05, -0.01, 0.02)))[8:]
+    for mode in (0, 1):
+        gy, guv = run8(vs, cuda, f, p, dw, dh, mode, rot_bottom=rb)
+        ey, euv = oracle.warp_nv12_planar(f, p, dw, dh, mode, rb)
+        assert np.array_equal(gy, ey) and np.array_equal(guv, euv), mode
+
+
+def test_planar_default_arithmetic_vs_the_reference_kernel(vs, cuda):
+    """VSTAB_MAP_CREATEMAP_CL_OPENCL (the handle's default): the checker's map IS the reference's createMap kernel on this GPU."""
+    if not oracle.ref_gfx950_available():
+        pytest.fail("oracle/_ref/createMap.gfx950.co is missing: __graft_entry__.build() compiles it where /root/reference exists")
+    for (w, h) in [(320, 180), (1280, 720)]:
+        f = synth.nv12(31 + w, w, h)
+        for rv in ROTS[:2] if w > 1000 else ROTS:
+            p, dw, dh, K, Ko = cams(w, h, rv)
+            gy, guv = run8(vs, cuda, f, p, dw, dh, vs.MAP_CREATEMAP_CL_OPENCL)
+            ey, euv = expect.warp_planar(f, p, dw, dh, expect.OPENCL)
+            assert np.array_equal(gy, ey) and np.array_equal(guv, euv), (w, rv, int((gy != ey).sum()), int((guv != euv).sum()))
+        rb = oracle.map_params(K, Ko, oracle.rodrigues((0.02, 0.01, -0.01)))[8:]
+        if w < 1000:  # per row: the checker launches the reference kernel once per output row
+            gy, guv = run8(vs, cuda, f, p, dw, dh, vs.MAP_CREATEMAP_CL_OPENCL, rot_bottom=rb)
+            ey, euv = expect.warp_planar(f, p, dw, dh, expect.OPENCL, rb)
+            assert np.array_equal(gy, ey) and np.array_equal(guv, euv)
+
+
+def test_planar_4k_config_3_shape(vs, cuda):
+    """BASELINE config 3's warp (4K NV12 -> 3524 x 1999) plane-wise, default arithmetic, against the reference kernel's map."""
+    w, h = 3840, 2160
+    f = synth.nv12(77, w, h)
+    p, dw, dh, _, _ = cams(w, h, (0.01, -0.02, 0.015))
+    assert (dw, dh) == (3524, 1999)
+    gy, guv = run8(vs, cuda, f, p, dw, dh, vs.MAP_CREATEMAP_CL_OPENCL)
+    ey, euv = expect.warp_planar(f, p, dw, dh, expect.OPENCL)
+    assert np.array_equal(gy, ey), int((gy != ey).sum())
+    assert np.array_equal(guv, euv), int((guv != euv).sum())
+    # size-independent properties at full size, no oracle involved: identical pinhole cameras -> the planes come back as they are;
+    # principal point moved by (38, -6) -> both planes shifted, limited-range black where the source ends
+    K = np.array([[2048.0, 0, 1920], [0, 2048.0, 1080], [0, 0, 1]])
+    gy, guv = run8(vs, cuda, f, oracle.map_params(K, K, np.eye(3)), w, h, vs.MAP_RECT_TO_RECT)
+    assert np.array_equal(gy, f[:h]) and np.array_equal(guv, f[h:])
+    Ko = K.copy()
+    Ko[0, 2] -= 38
+    Ko[1, 2] += 6
+    gy, guv = run8(vs, cuda, f, oracle.map_params(K, Ko, np.eye(3)), w, h, vs.MAP_RECT_TO_RECT)
+    ey = np.full((h, w), 16, np.uint8)
+    ey[6:, : w - 38] = f[: h - 6, 38:]
+    euv = np.full((h // 2, w), 128, np.uint8)
+    euv[3:, : w - 38] = f[h: h + h // 2 - 3, 38:]
+    assert np.array_equal(gy, ey) and np.array_equal(guv, euv)
+
+
+def test_planar_unaligned_and_pitched_planes_take_the_gather_path(vs, cuda):
+    """Planes the 16-byte staging loads cannot take (odd base offsets, pitches not multiples of 16, a width that is not a multiple
+    of 16) are sampled straight from global memory: same bytes."""
+    import torch
+    for (w, h, off, pitch) in [(328, 180, 0, 328), (320, 180, 8, 344), (320, 180, 2, 322)]:
+        f = synth.nv12(5 + off, w, h, full_range=True)
+        p, dw, dh, _, _ = cams(w, h, (0.02, -0.03, 0.01))
+        buf = torch.zeros((h * 3 // 2) * pitch + 64, dtype=torch.uint8, device=cuda)
+        view = buf[off:off + (h * 3 // 2) * pitch].view(h * 3 // 2, pitch)[:, :w]
+        view.copy_(dev(f, cuda))
+        yb, cb, yv, cv = planes(vs, cuda, dw, dh, pad=5)
+        vs.warp_nv12(view, p, dw, dh, vs.MAP_CREATEMAP_CL, vs.OUT_NV12_PLANAR, out=(yv, cv))
+        ey, euv = oracle.warp_nv12_planar(f, p, dw, dh, 0)
+        assert np.array_equal(yv.cpu().numpy(), ey) and np.array_equal(cv.cpu().numpy(), euv), (w, off, pitch)
+
+
+def test_planar_extreme_boxes(vs, cuda):
+    """Strong magnification / minification and a roll of 90 degrees: boxes over the LDS budget (tall tiles split in two, then the
+    gather path), tiles wholly outside the source."""
+    w, h = 1280, 720
+    f = synth.nv12(13, w, h)
+    K = oracle.get_preset_camera(4, w, h)
+    for scale, rv, (dw, dh) in [(0.25, (0.0, 0.0, 0.0), (448, 252)), (1.0, (0.0, 0.0, 1.5708), (1100, 700)), (3.0, (0.01, 0.0, 0.0), (1500, 900)),
+                                (1.0, (0.9, 0.0, 0.0), (800, 450))]:
+        Ko, _ = oracle.get_output_camera(K, w, h, scale=scale)
+        p = oracle.map_params(K, Ko, oracle.rodrigues(rv))
+        gy, guv = run8(vs, cuda, f, p, dw, dh, vs.MAP_CREATEMAP_CL)
+        ey, euv = oracle.warp_nv12_planar(f, p, dw, dh, 0)
+        assert np.array_equal(gy, ey) and np.array_equal(guv, euv), (scale, rv)
+
+
+def run10(vs, cuda, y, uv, p, dw, dh, mode, blend, rot_bottom=None):
+    import torch
+    yb, cb, yv, cv = planes(vs, cuda, dw, dh, pad=8, dtype=torch.int16)
+    vs.warp_p010_planar(dev(y.view(np.int16), cuda), dev(uv.view(np.int16), cuda), p, dw, dh, rot_bottom, mode, blend, out_y=yv, out_uv=cv)
+    assert bool((yb[:, dw:] == 7).all())
+    return yv.cpu().numpy().view(np.uint16), cv.cpu().numpy().view(np.uint16)
+
+
+def test_planar_p010_both_blends_per_row_and_default_arithmetic(vs, cuda):
+    for (w, h) in [(320, 180), (1280, 720)]:
+        y, uv, _, _ = p010_frame(3 + w, w, h)
+        p, dw, dh, K, Ko = cams(w, h, (0.02, -0.03, 0.01))
+        rb = oracle.map_params(K, Ko, oracle.rodrigues((0.04, -0.02, 0.0)))[8:]
+        for blend in (0, 1):
+            for rot_bottom in (None, rb):
+                gy, guv = run10(vs, cuda, y, uv, p, dw, dh, vs.MAP_CREATEMAP_CL, blend, rot_bottom)
+                ey, euv = oracle.warp_p010_planar(y, uv, p, dw, dh, 0, rot_bottom, blend)
+                assert np.array_equal(gy, ey) and np.array_equal(guv, euv), (w, blend, rot_bottom is not None, int((gy != ey).sum()), int((guv != euv).sum()))
+            if w < 1000:
+                gy, guv = run10(vs, cuda, y, uv, p, dw, dh, vs.MAP_CREATEMAP_CL_OPENCL, blend)
+                ey, euv = expect.warp_p010_planar(y, uv, p, dw, dh, None, blend, expect.OPENCL)
+                assert np.array_equal(gy, ey) and np.array_equal(guv, euv), (w, blend)
+    # odd output size, another projection pair
+    y, uv, _, _ = p010_frame(11, 640, 360)
+    Kin, Kout = oracle.lens_camera(oracle.PROJ_FISH, 150.0, 640, 360), oracle.lens_camera(oracle.PROJ_FISH, 165.0, 481, 271)
+    p = oracle.map_params(Kin, Kout, oracle.rodrigues((0.02, -0.03, 0.01)))
+    gy, guv = run10(vs, cuda, y, uv, p, 481, 271, vs.MAP_FISH_TO_FISH, 0)
+    ey, euv = oracle.warp_p010_planar(y, uv, p, 481, 271, 2, None, 0)
+    assert np.array_equal(gy, ey) and np.array_equal(guv, euv)
+
+
+def test_planar_argument_errors(vs, cuda):
+    import torch
+    f = dev(synth.nv12(1, 64, 36), cuda)
+    p, dw, dh, _, _ = cams(64, 36, (0, 0, 0))
+    yv, cv = vs.nv12_out_planes(dw, dh, cuda)
+    with pytest.raises(vs.VstabError):          # chroma rows shorter than 2 * ceil(width / 2) bytes
+        vs.warp_nv12(f, p, dw, dh, 0, vs.OUT_NV12_PLANAR, out=(yv, torch.empty((cv.shape[0], cv.shape[1] - 2), dtype=torch.uint8, device=cuda)))
+    q = vs.quantised_map(p, dw, dh)
+    with pytest.raises(vs.VstabError) as e:      # the quantised map holds no chroma positions
+        vs.warp_nv12_mapped(f, q, dw, dh, vs.OUT_NV12_PLANAR, out=(yv, cv))
+    assert e.value.status == vs.ERR_UNSUPPORTED
+    with pytest.raises(vs.VstabError):
+        vs.warp_p010_planar(torch.zeros((36, 64), dtype=torch.int16, device=cuda), torch.zeros((18, 64), dtype=torch.int16, device=cuda), p, dw, dh, blend=2)

@@ -78,7 +78,7 @@ class Profile(_c.Structure):  # vstab_profile
 SMOOTHER_SG, SMOOTHER_KALMAN, SMOOTHER_NONE, SMOOTHER_FIXED = 0, 1, 2, 3
 PROJ_RECT, PROJ_FISH = 0, 1
 MAP_CREATEMAP_CL, MAP_FISH_TO_RECT, MAP_FISH_TO_FISH, MAP_RECT_TO_RECT, MAP_RECT_TO_FISH, MAP_CREATEMAP_CL_OPENCL = range(6)
-OUT_BGR8, OUT_NV12 = 0, 1
+OUT_BGR8, OUT_NV12, OUT_NV12_PLANAR = 0, 1, 2
 MAP_PRECISION_IEEE, MAP_PRECISION_OPENCL = 0, 1
 _pp = _c.POINTER(_vp)
 
@@ -129,6 +129,7 @@ SIGNATURES = {
     "vstab_get_output_info": (_i, [_vp, _ip, _ip, _dp, _dp]),
     "vstab_pull_frame": (_i, [_vp, _vp, _sz]),
     "vstab_warp_p010_planes": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _fp, _i, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
+    "vstab_warp_p010_planar": (_i, [_vp, _sz, _vp, _sz, _i, _i, _fp, _fp, _i, _i, _vp, _sz, _vp, _sz, _i, _i, _vp]),
     "vstab_cvt_bgr16_p010": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp, _sz, _vp]),
     "vstab_pull_frame_p010": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "vstab_pull_frames": (_i, [_vp, _i, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t), _i, _i, _c.POINTER(_c.c_int)]),
@@ -410,6 +411,22 @@ def warp_p010_planes(y, uv, params, dw, dh, rot_bottom=None, mode=MAP_CREATEMAP_
     _check(_L.vstab_warp_p010_planes(y.data_ptr(), y.stride(0) * 2, uv.data_ptr(), uv.stride(0) * 2, w, h, _fptr(p), None if rb is None else _fptr(rb),
                                      int(mode), int(blend), out_y.data_ptr(), out_y.stride(0) * 2, out_uv.data_ptr(), out_uv.stride(0) * 2, dw, dh, _stream()),
            "vstab_warp_p010_planes")
+    return out_y, out_uv
+
+
+def warp_p010_planar(y, uv, params, dw, dh, rot_bottom=None, mode=MAP_CREATEMAP_CL, blend=BLEND_EXACT, out_y=None, out_uv=None):
+    """vstab_warp_p010_planar: the plane-wise 10-bit warp, P010 planes in and out, no colour round trip."""
+    import torch
+    h, w = y.shape
+    p = np.ascontiguousarray(params, np.float32)
+    rb = None if rot_bottom is None else np.ascontiguousarray(rot_bottom, np.float32).reshape(9)
+    if out_y is None:
+        out_y = torch.empty((dh, dw), dtype=torch.int16, device=y.device)
+    if out_uv is None:
+        out_uv = torch.empty(((dh + 1) // 2, 2 * ((dw + 1) // 2)), dtype=torch.int16, device=y.device)
+    _check(_L.vstab_warp_p010_planar(y.data_ptr(), y.stride(0) * 2, uv.data_ptr(), uv.stride(0) * 2, w, h, _fptr(p), None if rb is None else _fptr(rb),
+                                     int(mode), int(blend), out_y.data_ptr(), out_y.stride(0) * 2, out_uv.data_ptr(), out_uv.stride(0) * 2, dw, dh, _stream()),
+           "vstab_warp_p010_planar")
     return out_y, out_uv
 
 

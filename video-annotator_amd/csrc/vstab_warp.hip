@@ -509,8 +509,10 @@ static vstab_status warp_impl(const void *y, size_t pitch_y, const void *uv, siz
     if (dw <= 0 || dh <= 0 || dw > 32767 || dh > 32767)
         return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: output size must be in [1, 32767]");
     if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_CREATEMAP_CL_OPENCL) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: unknown map mode");
-    if (out_format != VSTAB_OUT_BGR8 && out_format != VSTAB_OUT_NV12) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: unknown output format");
-    const bool nv12_out = out_format == VSTAB_OUT_NV12;
+    if (out_format != VSTAB_OUT_BGR8 && out_format != VSTAB_OUT_NV12 && out_format != VSTAB_OUT_NV12_PLANAR)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: unknown output format");
+    const bool planar = out_format == VSTAB_OUT_NV12_PLANAR;
+    const bool nv12_out = out_format == VSTAB_OUT_NV12 || planar;
     if (pitch_y < (size_t)sw || pitch_uv < (size_t)sw || pitch_dst < (size_t)dw * (nv12_out ? 1 : 3))
         return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: pitch smaller than row");
     if (nv12_out && (!dst_uv || pitch_dst_uv < (size_t)((dw + 1) / 2) * 2))
@@ -527,6 +529,13 @@ static vstab_status warp_impl(const void *y, size_t pitch_y, const void *uv, siz
         return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12_rs: the per-row warp exists for the fisheye -> pinhole modes (0, 1, 5) only");
     const bool plain = map_mode == VSTAB_MAP_CREATEMAP_CL && !nv12_out && !qmap && !rot_bottom;
     if (!plain && !small_pitch) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: source pitch too large for this mode");
+    if (planar) {  // the plane-wise warp: its own kernel (vstab_warp_planar.hip); the map is always evaluated
+        if (qmap) return fail(VSTAB_ERR_UNSUPPORTED, "vstab_warp_nv12_mapped: the quantised map holds no chroma positions -- VSTAB_OUT_NV12_PLANAR goes through vstab_warp_nv12_ex");
+        if (sw < 16 || sh < 2) return fail(VSTAB_ERR_INVALID, "vstab_warp_nv12: the plane-wise warp needs a source of at least 16 x 2");
+        const bool src16 = aligned(y, 16) && aligned(uv, 16) && pitch_y % 16 == 0 && pitch_uv % 16 == 0;  // 16-byte staging loads
+        const bool dst16 = aligned(dst, 16) && aligned(dst_uv, 16) && pitch_dst % 16 == 0 && pitch_dst_uv % 16 == 0;
+        return launch_warp_planar(a, params, map_mode, 8, 0, src16, dst16, rot_bottom, static_cast<hipStream_t>(stream));
+    }
     bool direct = !small_pitch;
 #ifdef VSTAB_DEV
     static const int variant = getenv("VSTAB_WARP_VARIANT") ? atoi(getenv("VSTAB_WARP_VARIANT")) : 2;

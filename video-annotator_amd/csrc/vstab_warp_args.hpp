@@ -76,4 +76,8 @@ vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int ma
 vstab_status launch_warp_fused10(const WarpArgs &a, const float params[17], int map_mode, int blend, const float *rot_bottom, bool p010_out, bool dst_vec_ok,
                                  hipStream_t st);
 
+// the plane-wise warp (vstab_warp_planar.hip): a.dst / a.dst_uv = the output planes; depth 8 (NV12 bytes) or 10 (P010 words)
+vstab_status launch_warp_planar(const WarpArgs &a, const float params[17], int map_mode, int depth, int blend, bool src_vec_ok, bool dst_vec_ok,
+                                const float *rot_bottom, hipStream_t st);
+
 }  // namespace vstab

@@ -163,6 +163,36 @@ extern "C" vstab_status vstab_warp_p010_planes(const void *y, size_t pitch_y, co
     return launch_warp_fused10(wa, params, map_mode, blend, rot_bottom, true, vec, static_cast<hipStream_t>(stream));
 }
 
+// The plane-wise 10-bit warp (vstab_warp_planar.hip, DEPTH 10): P010 planes in and out, no colour conversion at all.
+extern "C" vstab_status vstab_warp_p010_planar(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int sw, int sh, const float params[17],
+                                               const float *rot_bottom, int map_mode, int blend, void *dst_y, size_t pitch_dst_y, void *dst_uv,
+                                               size_t pitch_dst_uv, int dw, int dh, void *stream) {
+    if (!y || !uv || !dst_y || !dst_uv || !params) return fail(VSTAB_ERR_INVALID, "vstab_warp_p010_planar: null pointer");
+    if (sw < 8 || sh < 2 || (sw & 1) || (sh & 1) || dw <= 0 || dh <= 0 || sw > 32767 || sh > 32767 || dw > 32767 || dh > 32767)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_p010_planar: sizes must be in [1, 32767], source even and at least 8 x 2");
+    if (pitch_y < (size_t)sw * 2 || pitch_uv < (size_t)sw * 2 || pitch_y % 2 || pitch_uv % 4 || reinterpret_cast<uintptr_t>(y) % 2 ||
+        reinterpret_cast<uintptr_t>(uv) % 4)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_p010_planar: bad source pitch or alignment (16-bit samples; chroma pairs 4-byte aligned)");
+    if (pitch_dst_y < (size_t)dw * 2 || pitch_dst_y % 2 || pitch_dst_uv < (size_t)((dw + 1) / 2) * 4 || pitch_dst_uv % 4 ||
+        reinterpret_cast<uintptr_t>(dst_y) % 2 || reinterpret_cast<uintptr_t>(dst_uv) % 4)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_p010_planar: bad output pitch or alignment (16-bit samples; chroma pairs 4-byte aligned)");
+    if (map_mode < VSTAB_MAP_CREATEMAP_CL || map_mode > VSTAB_MAP_CREATEMAP_CL_OPENCL) return fail(VSTAB_ERR_INVALID, "vstab_warp_p010_planar: unknown map mode");
+    if (blend != VSTAB_BLEND_EXACT && blend != VSTAB_BLEND_FP16) return fail(VSTAB_ERR_INVALID, "vstab_warp_p010_planar: unknown blend");
+    if (rot_bottom && map_mode != VSTAB_MAP_CREATEMAP_CL && map_mode != VSTAB_MAP_FISH_TO_RECT && map_mode != VSTAB_MAP_CREATEMAP_CL_OPENCL)
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_p010_planar: the per-row warp exists for the fisheye -> pinhole modes (0, 1, 5) only");
+    if (!(pitch_y < (1u << 24) && pitch_uv < (1u << 24) && (uint64_t)pitch_y * sh < (1ull << 32)))
+        return fail(VSTAB_ERR_INVALID, "vstab_warp_p010_planar: source pitch too large");
+    WarpArgs wa;
+    wa.y = static_cast<const uint8_t *>(y), wa.uv = static_cast<const uint8_t *>(uv), wa.dst = static_cast<uint8_t *>(dst_y), wa.dst_uv = static_cast<uint8_t *>(dst_uv);
+    wa.pitch_y = pitch_y, wa.pitch_uv = pitch_uv, wa.pitch_dst = pitch_dst_y, wa.pitch_dst_uv = pitch_dst_uv;
+    wa.sw = sw, wa.sh = sh, wa.dw = dw, wa.dh = dh;
+    wa.p = {params[0], params[1], params[2], params[3], params[4], params[5], params[6], params[7],
+            {params[8], params[9], params[10], params[11], params[12], params[13], params[14], params[15], params[16]}};
+    const bool src16 = reinterpret_cast<uintptr_t>(y) % 16 == 0 && reinterpret_cast<uintptr_t>(uv) % 16 == 0 && pitch_y % 16 == 0 && pitch_uv % 16 == 0;
+    const bool dst16 = reinterpret_cast<uintptr_t>(dst_y) % 16 == 0 && reinterpret_cast<uintptr_t>(dst_uv) % 16 == 0 && pitch_dst_y % 16 == 0 && pitch_dst_uv % 16 == 0;
+    return launch_warp_planar(wa, params, map_mode, 10, blend, src16, dst16, rot_bottom, static_cast<hipStream_t>(stream));
+}
+
 extern "C" vstab_status vstab_cvt_bgr16_p010(const void *src_bgr16, size_t pitch_src, int width, int height, void *dst_y, size_t pitch_y, void *dst_uv,
                                              size_t pitch_uv, void *stream) {
     if (!src_bgr16 || !dst_y || !dst_uv) return fail(VSTAB_ERR_INVALID, "vstab_cvt_bgr16_p010: null pointer");

@@ -1,0 +1,475 @@
+// vstab_warp_planar.hip -- the PLANE-WISE undistort-remap kernel (gfx950 / MI355X): NV12 -> NV12 and P010 -> P010 with no colour
+// round trip (SURVEY.md 8(f) row 2 as it is written; the route the CLI's filter and encoders use: render.ts:606-607, 664-665, 688,
+// 275-281).  Definition (include/vstab.h, VSTAB_OUT_NV12_PLANAR; restated in plain C in the test infrastructure):
+//   luma    cv::remap(INTER_LINEAR, BORDER_CONSTANT 16) of the Y plane with the map and quantisation of the BGR path
+//           (createMap.cl:13-50, FrameSourceWarp.cpp:306-312);
+//   chroma  cv::remap(INTER_LINEAR, BORDER_CONSTANT (128, 128)) of the interleaved UV plane; chroma sample (cx, cy) takes the map
+//           entry of luma pixel (2 cx, 2 cy), halved (exact) and quantised again: cvRound(32 * (map / 2)).
+// The kernel is k_warp_fused's structure (vstab_warp_fused.hip) without its colour conversion: probe -> load -> map -> stage -> sample
+// -> store, one workgroup per 64-column tile, lane = output column, a wave owns RW consecutive rows.  What differs:
+//   stage   the box is staged AS IT IS -- luma bytes and chroma byte pairs, 1.5 bytes per source pixel instead of a 4-byte BGRx pixel
+//           -- in blocks of 16 bytes x 2 luma rows + 16 bytes of chroma (three 16-byte loads, three ds_write_b128 per thread);
+//           blocks outside the source are written as limited-range black;
+//   sample  a luma pixel is two unaligned ds_read_u16 (the two taps of a row), two v_dot4_u32_u8 and one multiply-add; a thread's
+//           eight luma pixels come with TWO chroma pixels (the even-row map entries of the even lanes, dealt to lane pairs with DPP),
+//           each two ds_read_b32 and four dot products;
+//   store   result bytes are transposed through 768 bytes of LDS per wave, so every lane stores 8 (luma) + 4 (chroma) contiguous bytes.
+// 10-bit samples (P010 words, DEPTH 10): staged as their ten significant bits in 16-bit fields, v_dot2_u32_u16 in place of v_dot4.
+// Bit-exactness never depends on the box: a footprint outside it is sampled from global memory with the same integers.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+
+#include <hip/hip_ext.h>
+
+#include "vstab_device.hpp"
+#include "vstab_device10.hpp"
+#include "vstab_internal.hpp"
+#include "vstab_warp_args.hpp"
+#include "vstab_warp_tile.hpp"
+
+namespace vstab {
+
+typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
+typedef uint32_t __attribute__((aligned(2))) u32_align2;
+typedef __attribute__((address_space(3))) u16_unaligned LdsU16;      // two bytes anywhere in LDS (the hardware reads them unaligned)
+typedef __attribute__((address_space(3))) u32_align2 LdsU32a2;       // a dword on a 2-byte boundary
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+template <int DEPTH>
+struct Planar {
+    static constexpr int BPS = DEPTH == 10 ? 2 : 1;            // bytes per sample
+    static constexpr int BW = 16 / BPS;                        // luma pixels of a staging block row (one 16-byte load)
+    static constexpr int BLACK_Y = DEPTH == 10 ? 64 : 16;      // limited-range black: what cv::remap's Scalar(0) border of the BGR path is here
+    static constexpr int BLACK_C = DEPTH == 10 ? 512 : 128;
+    static constexpr uint32_t BLACK_Y_DWORD = DEPTH == 10 ? 0x00400040u : 0x10101010u;  // as staged in LDS (10 bits: values, not words)
+    static constexpr uint32_t BLACK_C_DWORD = DEPTH == 10 ? 0x02000200u : 0x80808080u;
+    static constexpr int SCRATCH_PER_WAVE = 768 * BPS;         // 8 rows x 64 luma + 4 rows x 32 chroma pairs
+};
+
+// ---- the rare path: one sample straight from global memory, taps outside the source = the border value ---------------------------
+template <int DEPTH>
+__device__ __forceinline__ int plane_tap(const uint8_t *plane, size_t pitch, int X, int Y, int cn, int c, int w, int h, int border) {
+    if ((unsigned)X >= (unsigned)w || (unsigned)Y >= (unsigned)h) return border;
+    const uint8_t *p = plane + (size_t)Y * pitch + ((size_t)X * cn + c) * Planar<DEPTH>::BPS;
+    if constexpr (DEPTH == 10) return (int)(*reinterpret_cast<const uint16_t *>(p) >> 6);
+    else return (int)*p;
+}
+template <int DEPTH, int BLEND>
+__device__ __forceinline__ int blend4(int p00, int p01, int p10, int p11, int fx, int fy) {
+    const int w00 = (32 - fx) * (32 - fy), w01 = fx * (32 - fy), w10 = (32 - fx) * fy, w11 = fx * fy;
+    if constexpr (DEPTH == 10 && BLEND == VSTAB_BLEND_FP16) return blend_fp16(p00, p01, p10, p11, w00, w01, w10, w11);
+    else return (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + 512) >> 10;
+}
+// sx, sy = rint(32 * position in the plane); cn interleaved channels of a w x h plane
+template <int DEPTH, int BLEND>
+__device__ __forceinline__ int gather_sample(const uint8_t *plane, size_t pitch, int w, int h, int cn, int c, int sx, int sy, int border) {
+    const int X = sx >> 5, Y = sy >> 5;
+    if (X >= w || X + 1 < 0 || Y >= h || Y + 1 < 0) return border;
+    return blend4<DEPTH, BLEND>(plane_tap<DEPTH>(plane, pitch, X, Y, cn, c, w, h, border), plane_tap<DEPTH>(plane, pitch, X + 1, Y, cn, c, w, h, border),
+                                plane_tap<DEPTH>(plane, pitch, X, Y + 1, cn, c, w, h, border), plane_tap<DEPTH>(plane, pitch, X + 1, Y + 1, cn, c, w, h, border),
+                                sx & 31, sy & 31);
+}
+
+// NB bytes of this lane from the wave's transposition scratch to global memory (NB = 1, 2, 4, 8, 16)
+// (the scratch is written as samples and read as vectors: may_alias types, so that the reads stay behind the writes)
+typedef uint16_t __attribute__((may_alias)) u16_alias;
+typedef uint32_t __attribute__((may_alias)) u32_alias;
+typedef uint32_t u32x2_alias __attribute__((ext_vector_type(2), may_alias));
+typedef uint32_t u32x4_alias __attribute__((ext_vector_type(4), may_alias));
+template <int NB>
+__device__ __forceinline__ void scratch_to_global(const uint8_t *lds, uint8_t *dst) {
+    if constexpr (NB == 1) *dst = *lds;
+    else if constexpr (NB == 16) *reinterpret_cast<u32x4_alias *>(dst) = *reinterpret_cast<const u32x4_alias *>(lds);
+    else if constexpr (NB == 8) *reinterpret_cast<u32x2_alias *>(dst) = *reinterpret_cast<const u32x2_alias *>(lds);
+    else if constexpr (NB == 4) *reinterpret_cast<u32_alias *>(dst) = *reinterpret_cast<const u32_alias *>(lds);
+    else *reinterpret_cast<u16_alias *>(dst) = *reinterpret_cast<const u16_alias *>(lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One output tile: 64 luma columns x 4 RW rows at (x0, y0) and the 32 x 2 RW chroma pairs under them.  Returns false -- right
+// behind the probe -- when SPLIT is set and the box is over the LDS budget (the caller then does two half-height tiles).
+// LDS: [0, 32) tile header | 4 x SCRATCH_PER_WAVE transposition scratch | luma box (hb rows of pw bytes) | chroma box (hb / 2 rows of pw bytes)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int RWB, int RW, int MODE, bool SPLIT, int DEPTH, int BLEND>
+__device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *smem, const int x0, const int y0) {
+    using P = Planar<DEPTH>;
+    constexpr int BPS = P::BPS, BW = P::BW, BWB = 16;  // block row: BW samples = 16 bytes
+    constexpr int TH = 4 * RW;
+    constexpr int STAGE_MAX = 2;
+    constexpr int CR = RW / 2;        // chroma rows of a wave
+    constexpr int NS = (RW + 3) / 4;  // chroma pixels per thread: CR rows x 32 columns over 64 lanes (RW = 2: the even lanes only)
+    constexpr int QB = QMAGIC_BITS;
+    uint8_t *const scratch = reinterpret_cast<uint8_t *>(smem) + 32;
+    uint8_t *const tile = scratch + 4 * P::SCRATCH_PER_WAVE;
+    const WarpArgs &a = ta.w;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float rfx = rcp_refined(a.p.ofx), rfy = rcp_refined(a.p.ofy);
+
+    // ---- probe (wave 0; the other waves wait at the barrier) ------------------------------------------------------------
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        probe_tile<TH, STAGE_MAX, MODE, false, true, BW>(ta, x0, y0, lane, rfx, rfy, smem);
+        __builtin_amdgcn_s_setprio(VSTAB_WARP_PRIO);
+    }
+    __syncthreads();
+    const int bx0 = __builtin_amdgcn_readfirstlane((int)smem[0]), by0 = __builtin_amdgcn_readfirstlane((int)smem[1]);
+    const int wb = __builtin_amdgcn_readfirstlane((int)smem[2]), hb = __builtin_amdgcn_readfirstlane((int)smem[3]);
+    const int box_state = __builtin_amdgcn_readfirstlane((int)smem[4]);
+    if constexpr (SPLIT) {
+        if (box_state == 2) return false;  // uniform
+    }
+    const bool use_lds = box_state == 1;
+    const int x = x0 + lane;
+    const int pw = wb * BPS;                       // LDS row pitch in bytes, of both boxes (a chroma pair takes as much as two luma samples)
+    const int luma_bytes = pw * hb;
+
+    // ---- load: this thread's blocks (BW x 2 luma samples + BW / 2 chroma pairs), every load in flight at once -----------
+    const int ux_n = wb / BW, units = use_lds ? ux_n * (hb >> 1) : 0;
+    uint4 y0w[STAGE_MAX], y1w[STAGE_MAX], uvw[STAGE_MAX];
+    int off_y[STAGE_MAX], off_c[STAGE_MAX];  // byte offsets of the block in the two boxes (off_y | ZERO_BLOCK: outside the source); -1 = no block
+    constexpr int ZERO_BLOCK = 1 << 24;
+    if (use_lds) {
+        const float rn = __builtin_amdgcn_rcpf((float)ux_n);
+        int uy = (int)((float)tid * rn), ux = tid - uy * ux_n;  // divmod(tid, ux_n): the float quotient is off by at most one
+        if (ux < 0) ux += ux_n, uy--;
+        if (ux >= ux_n) ux -= ux_n, uy++;
+        int sy_ = (int)(256.0f * rn), sx_ = 256 - sy_ * ux_n;   // uniform: divmod(256, ux_n)
+        if (sx_ < 0) sx_ += ux_n, sy_--;
+        if (sx_ >= ux_n) sx_ -= ux_n, sy_++;
+        const uint32_t pitch_y = (uint32_t)a.pitch_y, pitch_uv = (uint32_t)a.pitch_uv;  // < 2^24, frame < 4 GiB (host check)
+        const int sw_al = a.sw & ~(BW - 1);
+#pragma unroll
+        for (int it = 0; it < STAGE_MAX; it++) {
+            if (it > 0 && units <= it * 256) {  // uniform: most boxes have fewer than 256 blocks
+                y0w[it] = y1w[it] = uvw[it] = uint4(), off_y[it] = off_c[it] = -1;
+                continue;
+            }
+            // a thread without a block in this trip, or with a block outside the source (the black border), loads from the
+            // nearest block inside; neither uses what it loaded
+            const bool valid = tid + it * 256 < units;
+            const int gx = bx0 + BW * ux, gy = by0 + 2 * uy;
+            const bool inside = (uint32_t)gx < (uint32_t)sw_al && (uint32_t)gy < (uint32_t)a.sh;
+            const uint32_t cx = (uint32_t)min(max(gx, 0), sw_al - BW), cy = (uint32_t)min(max(gy, 0), a.sh - 2);
+            const uint32_t oy = __umul24(cy, pitch_y) + cx * BPS, ouv = __umul24(cy >> 1, pitch_uv) + cx * BPS;
+            y0w[it] = *reinterpret_cast<const uint4 *>(a.y + oy);
+            y1w[it] = *reinterpret_cast<const uint4 *>(a.y + (oy + pitch_y));
+            uvw[it] = *reinterpret_cast<const uint4 *>(a.uv + ouv);
+            off_y[it] = valid ? (__mul24(2 * uy, pw) + BWB * ux) | (inside ? 0 : ZERO_BLOCK) : -1;
+            off_c[it] = luma_bytes + __mul24(uy, pw) + BWB * ux;
+            ux += sx_, uy += sy_;
+            if (ux >= ux_n) ux -= ux_n, uy++;
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < STAGE_MAX; it++) y0w[it] = y1w[it] = uvw[it] = uint4(), off_y[it] = off_c[it] = -1;
+    }
+
+    // ---- map: RW exact evaluations per thread, and the chroma positions of the even rows (vstab_warp_tile.hpp) ---------
+    int qxb[RW], qyb[RW], qcx[RW / 2], qcy[RW / 2];
+    map_phase<RW, MODE, false, true>(ta, x, y0, wave, lane, rfx, rfy, qxb, qyb, qcx, qcy);
+#pragma unroll
+    for (int j = 0; j < RW; j++) asm volatile("" : "+v"(qxb[j]), "+v"(qyb[j]) : : "memory");
+#pragma unroll
+    for (int j = 0; j < RW / 2; j++) asm volatile("" : "+v"(qcx[j]), "+v"(qcy[j]));
+
+    // ---- stage: the loaded blocks go to LDS as they are (10 bits: reduced to their significant bits) -------------------
+    if (use_lds) {
+#pragma unroll
+        for (int it = 0; it < STAGE_MAX; it++) {
+            if (off_y[it] >= ZERO_BLOCK) {
+                uint8_t *d = tile + (off_y[it] - ZERO_BLOCK);
+                const uint4 ky = make_uint4(P::BLACK_Y_DWORD, P::BLACK_Y_DWORD, P::BLACK_Y_DWORD, P::BLACK_Y_DWORD);
+                *reinterpret_cast<uint4 *>(d) = ky, *reinterpret_cast<uint4 *>(d + pw) = ky;
+                *reinterpret_cast<uint4 *>(tile + off_c[it]) = make_uint4(P::BLACK_C_DWORD, P::BLACK_C_DWORD, P::BLACK_C_DWORD, P::BLACK_C_DWORD);
+            } else if (off_y[it] >= 0) {
+                uint8_t *d = tile + off_y[it];
+                if constexpr (DEPTH == 10) {
+                    auto sig = [](uint4 v) { return make_uint4((v.x >> 6) & 0x03ff03ffu, (v.y >> 6) & 0x03ff03ffu, (v.z >> 6) & 0x03ff03ffu, (v.w >> 6) & 0x03ff03ffu); };
+                    *reinterpret_cast<uint4 *>(d) = sig(y0w[it]), *reinterpret_cast<uint4 *>(d + pw) = sig(y1w[it]);
+                    *reinterpret_cast<uint4 *>(tile + off_c[it]) = sig(uvw[it]);
+                } else {
+                    *reinterpret_cast<uint4 *>(d) = y0w[it], *reinterpret_cast<uint4 *>(d + pw) = y1w[it];
+                    *reinterpret_cast<uint4 *>(tile + off_c[it]) = uvw[it];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- sample + blend: luma ------------------------------------------------------------------------------------------
+    const bool col_live = x < a.dw;
+    const uint32_t tile_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)tile;
+    int out[RW];
+    {
+        // every footprint of the wave inside the staged box?  in the registers' representation: QB + 32 * bx0 <= q < QB + 32 * (bx0 + wb - 1)
+        int mnx = qxb[0], mxx = qxb[0], mny = qyb[0], mxy = qyb[0];
+#pragma unroll
+        for (int j = 1; j < RW; j++) mnx = min(mnx, qxb[j]), mxx = max(mxx, qxb[j]), mny = min(mny, qyb[j]), mxy = max(mxy, qyb[j]);
+        const int lox = QB + 32 * bx0, hix = QB + 32 * (bx0 + wb - 1), loy = QB + 32 * by0, hiy = QB + 32 * (by0 + hb - 1);
+        const bool outside_box = !use_lds || mnx < lox || mxx >= hix || mny < loy || mxy >= hiy;
+        if (!__builtin_amdgcn_ballot_w64(outside_box)) {
+            // tap address = tile + (Y - by0) * pw + (X - bx0) * BPS with X = (q >> 5) - (QB >> 5): the constants are ONE register
+            // (K), and v_mad_u32_u24 keeps the low 24 bits of q >> 5 = (QB >> 5) + Y, of which (QB >> 5) & 0xffffff is in K too
+            constexpr uint32_t QH = (uint32_t)QB >> 5, QH24 = QH & 0xffffffu;
+            uint32_t K = tile_lds - (QH24 + (uint32_t)by0) * (uint32_t)pw - (QH + (uint32_t)bx0) * (uint32_t)BPS;
+            uint32_t Kv = K;
+            asm("" : "+v"(Kv));  // (a VGPR: the multiply-add below already has one scalar operand, the pitch)
+            constexpr int TG = RW < 4 ? RW : 4;  // rows whose tap reads are issued before the first blend
+#pragma unroll
+            for (int j0 = 0; j0 < RW; j0 += TG) {
+                uint32_t t0[TG], t1[TG];
+#pragma unroll
+                for (int j = 0; j < TG; j++) {
+                    const uint32_t xa = (uint32_t)(qxb[j0 + j] >> 5), ya = (uint32_t)(qyb[j0 + j] >> 5);
+                    uint32_t ad;
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ad) : "v"(ya), "s"(pw), "v"(Kv));
+                    if constexpr (DEPTH == 10) {
+                        ad += xa << 1;
+                        t0[j] = *reinterpret_cast<const LdsU32a2 *>(ad), t1[j] = *reinterpret_cast<const LdsU32a2 *>(ad + (uint32_t)pw);
+                    } else {
+                        ad += xa;
+                        t0[j] = *reinterpret_cast<const LdsU16 *>(ad), t1[j] = *reinterpret_cast<const LdsU16 *>(ad + (uint32_t)pw);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TG; j++) {
+                    const uint32_t fx = (uint32_t)qxb[j0 + j] & 31u, fy = (uint32_t)qyb[j0 + j] & 31u;
+                    if constexpr (DEPTH == 10 && BLEND == VSTAB_BLEND_FP16) {
+                        out[j0 + j] = blend4<DEPTH, BLEND>((int)(t0[j] & 0xffffu), (int)(t0[j] >> 16), (int)(t1[j] & 0xffffu), (int)(t1[j] >> 16), (int)fx, (int)fy);
+                    } else {
+                        uint32_t h0, h1;
+                        if constexpr (DEPTH == 10) {
+                            const uint32_t wx = fx * 65535u + 32u;  // (32 - fx) | fx << 16
+                            h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, t0[j]), __builtin_bit_cast(u16x2, wx), 0u, false);
+                            h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, t1[j]), __builtin_bit_cast(u16x2, wx), 0u, false);
+                        } else {
+                            const uint32_t wx = fx * 255u + 32u;    // (32 - fx) | fx << 8; the taps' upper bytes are zero
+                            h0 = __builtin_amdgcn_udot4(t0[j], wx, 0u, false);
+                            h1 = __builtin_amdgcn_udot4(t1[j], wx, 0u, false);
+                        }
+                        // (h0 * (32 - fy) + h1 * fy + 512) >> 10
+                        out[j0 + j] = (int)(((h0 << 5) + 512u + (uint32_t)__mul24((int)(h1 - h0), (int)fy)) >> 10);
+                    }
+                }
+            }
+        } else {
+            // rare (a box that had to be cut, degenerate rotation, box over the LDS budget, unaligned planes): straight from global memory
+#pragma unroll 1
+            for (int j = 0; j < RW; j++) {
+                int sx = qxb[0], sy = qyb[0];
+#pragma unroll
+                for (int k = 1; k < RW; k++) sx = j == k ? qxb[k] : sx, sy = j == k ? qyb[k] : sy;
+                const int v = gather_sample<DEPTH, BLEND>(a.y, a.pitch_y, a.sw, a.sh, 1, 0, sx - QB, sy - QB, P::BLACK_Y);
+#pragma unroll
+                for (int k = 0; k < RW; k++) out[k] = j == k ? v : out[k];
+            }
+        }
+    }
+
+    // ---- sample + blend: chroma.  Lane pair (2k, 2k + 1) shares chroma column k; the even lane holds its map entries for the even
+    // rows j = 0, 2, ..: the even lane keeps rows j = 4 s, the odd lane takes rows j = 4 s + 2 (chroma rows 2 s and 2 s + 1) -------------
+    int cu[NS], cv[NS];
+    {
+        int ccx[NS], ccy[NS];
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int so = 2 * s + 1 < CR ? 2 * s + 1 : 2 * s;  // (RW = 2: one chroma row; the odd lanes shadow their neighbour and store nothing)
+            const int ox = __builtin_amdgcn_mov_dpp(qcx[so], 0xa0, 0xf, 0xf, true), oy = __builtin_amdgcn_mov_dpp(qcy[so], 0xa0, 0xf, 0xf, true);  // quad_perm [0,0,2,2]
+            ccx[s] = odd ? ox : qcx[2 * s], ccy[s] = odd ? oy : qcy[2 * s];
+        }
+        int mnx = ccx[0], mxx = ccx[0], mny = ccy[0], mxy = ccy[0];
+#pragma unroll
+        for (int s = 1; s < NS; s++) mnx = min(mnx, ccx[s]), mxx = max(mxx, ccx[s]), mny = min(mny, ccy[s]), mxy = max(mxy, ccy[s]);
+        const int cbx0 = bx0 >> 1, cby0 = by0 >> 1, cwb = wb >> 1, chb = hb >> 1;  // the chroma box, in chroma pixels (bx0, by0 even, also when negative)
+        const int lox = QB + 32 * cbx0, hix = QB + 32 * (cbx0 + cwb - 1), loy = QB + 32 * cby0, hiy = QB + 32 * (cby0 + chb - 1);
+        const bool outside_box = !use_lds || mnx < lox || mxx >= hix || mny < loy || mxy >= hiy;
+        if (!__builtin_amdgcn_ballot_w64(outside_box)) {
+            constexpr uint32_t QH = (uint32_t)QB >> 5, QH24 = QH & 0xffffffu;
+            constexpr uint32_t CPX = 2 * BPS;  // bytes of a chroma pair
+            uint32_t Kv = tile_lds + (uint32_t)luma_bytes - (QH24 + (uint32_t)cby0) * (uint32_t)pw - (QH + (uint32_t)cbx0) * CPX;
+            asm("" : "+v"(Kv));
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const uint32_t xa = (uint32_t)(ccx[s] >> 5), ya = (uint32_t)(ccy[s] >> 5);
+                const uint32_t fx = (uint32_t)ccx[s] & 31u, fy = (uint32_t)ccy[s] & 31u;
+                uint32_t ad;
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ad) : "v"(ya), "s"(pw), "v"(Kv));
+                ad += xa * CPX;
+                if constexpr (DEPTH == 10) {
+                    // (U0 | V0 << 16, U1 | V1 << 16) of both rows
+                    const u32_align2 __attribute__((address_space(3))) *pt = reinterpret_cast<const LdsU32a2 *>(ad), *pb = reinterpret_cast<const LdsU32a2 *>(ad + (uint32_t)pw);
+                    const uint32_t a0 = pt[0], a1 = pt[1], b0 = pb[0], b1 = pb[1];
+                    cu[s] = blend4<DEPTH, BLEND>((int)(a0 & 0xffffu), (int)(a1 & 0xffffu), (int)(b0 & 0xffffu), (int)(b1 & 0xffffu), (int)fx, (int)fy);
+                    cv[s] = blend4<DEPTH, BLEND>((int)(a0 >> 16), (int)(a1 >> 16), (int)(b0 >> 16), (int)(b1 >> 16), (int)fx, (int)fy);
+                } else {
+                    const uint32_t tt = *reinterpret_cast<const LdsU32a2 *>(ad), tb = *reinterpret_cast<const LdsU32a2 *>(ad + (uint32_t)pw);  // U0 V0 U1 V1
+                    const uint32_t wu = fx * 65535u + 32u, wv = wu << 8;  // (32 - fx) at byte 0 / 1, fx at byte 2 / 3
+                    const uint32_t hu0 = __builtin_amdgcn_udot4(tt, wu, 0u, false), hu1 = __builtin_amdgcn_udot4(tb, wu, 0u, false);
+                    const uint32_t hv0 = __builtin_amdgcn_udot4(tt, wv, 0u, false), hv1 = __builtin_amdgcn_udot4(tb, wv, 0u, false);
+                    cu[s] = (int)(((hu0 << 5) + 512u + (uint32_t)__mul24((int)(hu1 - hu0), (int)fy)) >> 10);
+                    cv[s] = (int)(((hv0 << 5) + 512u + (uint32_t)__mul24((int)(hv1 - hv0), (int)fy)) >> 10);
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < NS; s++) {
+                int sx = ccx[0], sy = ccy[0];
+#pragma unroll
+                for (int k = 1; k < NS; k++) sx = s == k ? ccx[k] : sx, sy = s == k ? ccy[k] : sy;
+                const int u = gather_sample<DEPTH, BLEND>(a.uv, a.pitch_uv, a.sw >> 1, a.sh >> 1, 2, 0, sx - QB, sy - QB, P::BLACK_C);
+                const int v = gather_sample<DEPTH, BLEND>(a.uv, a.pitch_uv, a.sw >> 1, a.sh >> 1, 2, 1, sx - QB, sy - QB, P::BLACK_C);
+#pragma unroll
+                for (int k = 0; k < NS; k++) cu[k] = s == k ? u : cu[k], cv[k] = s == k ? v : cv[k];
+            }
+        }
+    }
+
+    // ---- store: through the wave's scratch, so that a lane stores contiguous bytes of ONE row ------------------------------
+    const int yw = y0 + wave * RW;                      // first luma row of this wave (even)
+    const int ncols = min(64, a.dw - x0);               // > 0
+    constexpr int SH = DEPTH == 10 ? 6 : 0;             // P010 words carry the value at the top
+    if (ta.dst_vec_ok && ncols == 64 && yw + RW <= a.dh) {
+        uint8_t *const scr = scratch + wave * P::SCRATCH_PER_WAVE;
+        uint8_t *const scr_c = scr + RW * 64 * BPS;
+        {
+            uint8_t *w = scr + lane * BPS;
+#pragma unroll
+            for (int j = 0; j < RW; j++) {
+                if constexpr (DEPTH == 10) *reinterpret_cast<u16_alias *>(w + j * 128) = (uint16_t)(out[j] << SH);
+                else w[j * 64] = (uint8_t)out[j];
+            }
+            uint8_t *wc = scr_c + (lane & 1) * 64 * BPS + (lane >> 1) * 2 * BPS;  // chroma row (lane & 1) + 2 s, pair lane >> 1
+            if (CR > 1 || !(lane & 1)) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    if constexpr (DEPTH == 10) *reinterpret_cast<u32_alias *>(wc + s * 256) = (uint32_t)(cu[s] << SH) | ((uint32_t)(cv[s] << SH) << 16);
+                    else *reinterpret_cast<u16_alias *>(wc + s * 128) = (uint16_t)(cu[s] | (cv[s] << 8));
+                }
+            }
+        }
+        // luma: RW rows of 64 * BPS bytes = 64 lanes x RW * BPS bytes; chroma: RW / 2 rows of 64 * BPS bytes = 64 lanes x RW * BPS / 2
+        constexpr int NBY = RW * BPS, NBC = RW * BPS / 2;
+        constexpr int LPR_Y = 64 * BPS / NBY, LPR_C = 64 * BPS / NBC;  // lanes per row
+        {
+            const int r = lane / LPR_Y, c = (lane % LPR_Y) * NBY;
+            scratch_to_global<NBY>(scr + lane * NBY, a.dst + ((size_t)(uint32_t)(yw + r) * a.pitch_dst + (uint32_t)x0 * BPS + (uint32_t)c));
+        }
+        {
+            const int r = lane / LPR_C, c = (lane % LPR_C) * NBC;
+            scratch_to_global<NBC>(scr_c + lane * NBC, a.dst_uv + ((size_t)(uint32_t)((yw >> 1) + r) * a.pitch_dst_uv + (uint32_t)x0 * BPS + (uint32_t)c));
+        }
+    } else {
+        // ragged tiles (last tile column / row) and unaligned destinations: sample by sample
+#pragma unroll
+        for (int j = 0; j < RW; j++) {
+            const int y = yw + j;
+            if (col_live && y < a.dh) {
+                uint8_t *o = a.dst + ((size_t)(uint32_t)y * a.pitch_dst + (uint32_t)x * BPS);
+                if constexpr (DEPTH == 10) o[0] = (uint8_t)((out[j] << SH) & 255), o[1] = (uint8_t)((out[j] << SH) >> 8);
+                else o[0] = (uint8_t)out[j];
+            }
+        }
+        const int xc = x0 + (lane & ~1);  // the luma column this lane's chroma pairs belong to
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int y = yw + 2 * ((lane & 1) + 2 * s);  // the luma row
+            if (xc < a.dw && y < a.dh && (lane & 1) + 2 * s < CR) {
+                uint8_t *o = a.dst_uv + ((size_t)(uint32_t)(y >> 1) * a.pitch_dst_uv + (uint32_t)xc * BPS);
+                const uint32_t u = (uint32_t)cu[s] << SH, v = (uint32_t)cv[s] << SH;
+                if constexpr (DEPTH == 10) o[0] = u & 255, o[1] = u >> 8, o[2] = v & 255, o[3] = v >> 8;
+                else o[0] = (uint8_t)u, o[1] = (uint8_t)v;
+            }
+        }
+    }
+    return true;
+}
+
+// Workgroups and tiles as k_warp_fused deals them (vstab_warp_fused.hip): block b -> XCD b % 8, every XCD one band of output rows,
+// tall tiles first and half-height tiles for the last round of workgroup slots.
+template <int RWB, int MODE, int DEPTH, int BLEND>
+__global__ void __launch_bounds__(256, RWB == 8 ? 5 : 6) k_warp_planar(FusedArgs ta) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr int TH = 4 * RWB, TS = TH / 2;
+    if (VSTAB_WARP_PRIO) __builtin_amdgcn_s_setprio(VSTAB_WARP_PRIO);
+    const int k = (int)(blockIdx.x & 7u);
+    const int y_lo = ta.band_y[k], y_sp = ta.split_y[k], y_hi = ta.band_y[k + 1];
+    const int n_tall = ((y_sp - y_lo) / TH) * ta.tiles_x;
+    const int idx = (int)(blockIdx.x >> 3);
+    int x0, ys, n_half;
+    if (idx < n_tall) {
+        const int row = idx / ta.tiles_x;
+        x0 = (idx - row * ta.tiles_x) * 64, ys = y_lo + row * TH;
+        n_half = warp_tile_planar<RWB, RWB, MODE, true, DEPTH, BLEND>(ta, smem, x0, ys) ? 0 : 2;
+    } else {
+        const int i2 = idx - n_tall, row = i2 / ta.tiles_x;
+        x0 = (i2 - row * ta.tiles_x) * 64, ys = y_sp + row * TS, n_half = 1;
+        if (ys >= y_hi) return;  // uniform for the workgroup (before any barrier)
+    }
+#pragma unroll 1
+    for (int i = 0; i < n_half; i++) warp_tile_planar<RWB, RWB / 2, MODE, false, DEPTH, BLEND>(ta, smem, x0, ys + i * TS);
+}
+
+// Launch; called by the C-ABI entry points (vstab_warp.hip, vstab_warp_p010.hip) after argument validation.  a.y / a.uv / a.dst / a.dst_uv:
+// the four planes, pitches in bytes; depth 8 (NV12 bytes) or 10 (P010 words); src_vec_ok: source planes and pitches 16-byte aligned
+// (else every pixel takes the global-memory path: correct, slow); dst_vec_ok: destination planes and pitches 16-byte aligned.
+vstab_status launch_warp_planar(const WarpArgs &a, const float params[17], int map_mode, int depth, int blend, bool src_vec_ok, bool dst_vec_ok,
+                                const float *rot_bottom, hipStream_t st) {
+    FusedArgs ta;
+    ta.w = a;
+    ta.p32 = {params[0] * 32.0f, params[1] * 32.0f, params[2] * 32.0f, params[3] * 32.0f, params[10], params[13], params[16]};
+    ta.src_vec_ok = src_vec_ok, ta.dst_vec_ok = dst_vec_ok;
+    ta.qmap = nullptr, ta.qpitch = 0;
+    for (int k = 0; k < 9; k++) ta.rs_d[k] = rot_bottom ? rot_bottom[k] - params[8 + k] : 0.0f;
+    ta.rs_den = (float)(a.dh > 1 ? a.dh - 1 : 1);
+    if (rot_bottom) map_mode = map_mode == VSTAB_MAP_CREATEMAP_CL_OPENCL ? (int)MAP_RS_CREATEMAP_CL_OPENCL : map_mode + (int)MAP_RS_CREATEMAP_CL;
+#ifdef VSTAB_DEV
+    ta.timing = nullptr, ta.ablate = 0, ta.lds_pad = 0;
+#endif
+    // 64 x 32 tiles; LDS per workgroup: header + scratch + 1.5 bytes (3 at 10 bits) per pixel of the box.  24 KB (8-bit) lets six
+    // workgroups share a CU -- as many as the register budget admits -- and holds the largest boxes of a 4K fisheye frame.
+    const int bps = depth == 10 ? 2 : 1;
+    const long tiles32 = (long)div_up(a.dw, 64) * div_up(a.dh, 32);
+    const int rwb = tiles32 < 1536 ? 4 : 8;
+    const int lds_kb = (rwb == 8 ? 24 : 14) * bps;
+    const double tail_rounds = (double)div_up(a.dw, 64) * div_up(a.dh, 4 * rwb) > 256.0 * std::min(6, 160 / lds_kb) ? 0.5 : 0.0;
+    const dim3 grid(tile_schedule(ta, rwb, lds_kb, tail_rounds));
+    const size_t lds_bytes = (size_t)lds_kb * 1024;
+    ta.lds_capacity_px = (int)((lds_bytes - 32 - 4 * 768 * (size_t)bps) * 2 / (3 * (size_t)bps));
+    const LaunchEvents ev = take_launch_events();
+#define VSTAB_LAUNCHP(R, M, D, B)                                                                                                 \
+    do {                                                                                                                          \
+        if (ev.start) hipExtLaunchKernelGGL((k_warp_planar<R, M, D, B>), grid, dim3(256), lds_bytes, st, ev.start, ev.stop, 0, ta); \
+        else hipLaunchKernelGGL((k_warp_planar<R, M, D, B>), grid, dim3(256), lds_bytes, st, ta);                                  \
+    } while (0)
+#define VSTAB_LAUNCHP_M(M)                                                               \
+    do {                                                                                 \
+        if (depth == 10) {                                                               \
+            if (blend == VSTAB_BLEND_FP16) {                                             \
+                if (rwb == 8) VSTAB_LAUNCHP(8, M, 10, VSTAB_BLEND_FP16);                 \
+                else VSTAB_LAUNCHP(4, M, 10, VSTAB_BLEND_FP16);                          \
+            } else if (rwb == 8) VSTAB_LAUNCHP(8, M, 10, VSTAB_BLEND_EXACT);             \
+            else VSTAB_LAUNCHP(4, M, 10, VSTAB_BLEND_EXACT);                             \
+        } else if (rwb == 8) VSTAB_LAUNCHP(8, M, 8, 0);                                  \
+        else VSTAB_LAUNCHP(4, M, 8, 0);                                                  \
+    } while (0)
+    switch (map_mode) {
+        case VSTAB_MAP_CREATEMAP_CL: VSTAB_LAUNCHP_M(MAP_CREATEMAP_CL); break;
+        case VSTAB_MAP_FISH_TO_RECT: VSTAB_LAUNCHP_M(MAP_FISH_TO_RECT); break;
+        case VSTAB_MAP_FISH_TO_FISH: VSTAB_LAUNCHP_M(MAP_FISH_TO_FISH); break;
+        case VSTAB_MAP_RECT_TO_RECT: VSTAB_LAUNCHP_M(MAP_RECT_TO_RECT); break;
+        case VSTAB_MAP_RECT_TO_FISH: VSTAB_LAUNCHP_M(MAP_RECT_TO_FISH); break;
+        case VSTAB_MAP_CREATEMAP_CL_OPENCL: VSTAB_LAUNCHP_M(MAP_CREATEMAP_CL_OPENCL); break;
+        case MAP_RS_CREATEMAP_CL: VSTAB_LAUNCHP_M(MAP_RS_CREATEMAP_CL); break;
+        case MAP_RS_CREATEMAP_CL_OPENCL: VSTAB_LAUNCHP_M(MAP_RS_CREATEMAP_CL_OPENCL); break;
+        default: VSTAB_LAUNCHP_M(MAP_RS_FISH_TO_RECT); break;
+    }
+#undef VSTAB_LAUNCHP_M
+#undef VSTAB_LAUNCHP
+    VSTAB_HIP_TRY(hipGetLastError());
+    return VSTAB_OK;
+}
+
+}  // namespace vstab
