@@ -21,5 +21,5 @@ SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 
 FETCH_SIZE
 WRITE_SIZE GRBM_GUI_ACTIVE
 LIST
-python3 $R/tools/summarize_pmc.py $OUT k_warp_fused
+python3 $R/tools/summarize_pmc.py $OUT ${KERN:-k_warp_fused}
 grep us/frame $OUT/trace.log

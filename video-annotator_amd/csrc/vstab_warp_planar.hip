@@ -31,10 +31,12 @@
 
 namespace vstab {
 
-typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
-typedef uint32_t __attribute__((aligned(2))) u32_align2;
-typedef __attribute__((address_space(3))) u16_unaligned LdsU16;      // two bytes anywhere in LDS (the hardware reads them unaligned)
-typedef __attribute__((address_space(3))) u32_align2 LdsU32a2;       // a dword on a 2-byte boundary
+// LDS reads are issued at their NATURAL alignment only: gfx950 executes an unaligned ds_read_u16 / ds_read_b32 lane by lane -- 64 cycles
+// of the CU's LDS pipe against 2.3 (tools/probe_lds.hip, profiles/r05_lds_access_cost.txt) -- so the two taps of a row, which start at
+// any byte, are two byte reads (two 16-bit reads for 16-bit samples and for chroma byte pairs) joined by one v_lshl_or_b32.
+typedef __attribute__((address_space(3))) uint8_t LdsU8;
+typedef __attribute__((address_space(3))) uint16_t LdsU16;
+typedef __attribute__((address_space(3))) uint32_t LdsU32;
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 template <int DEPTH>
@@ -70,6 +72,14 @@ __device__ __forceinline__ int gather_sample(const uint8_t *plane, size_t pitch,
     return blend4<DEPTH, BLEND>(plane_tap<DEPTH>(plane, pitch, X, Y, cn, c, w, h, border), plane_tap<DEPTH>(plane, pitch, X + 1, Y, cn, c, w, h, border),
                                 plane_tap<DEPTH>(plane, pitch, X, Y + 1, cn, c, w, h, border), plane_tap<DEPTH>(plane, pitch, X + 1, Y + 1, cn, c, w, h, border),
                                 sx & 31, sy & 31);
+}
+
+// (h0 * (32 - fy) + h1 * fy + 512) >> 10 from the two rows' horizontal sums.  Plain C++ on purpose: h0 / h1 come out of v_dot4 / v_dot2,
+// whose results the next few VALU instructions must not read (the compiler pads ITS instructions; it cannot see into inline assembly --
+// hand-written consumers here read stale sums).
+__device__ __forceinline__ int lerp_rows(uint32_t h0, uint32_t h1, uint32_t fy) {
+    const uint32_t base = (h0 << 5) + 512u;
+    return (int)((base + (uint32_t)__mul24((int)(h1 - h0), (int)fy)) >> 10);
 }
 
 // NB bytes of this lane from the wave's transposition scratch to global memory (NB = 1, 2, 4, 8, 16)
@@ -225,12 +235,15 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
                     const uint32_t xa = (uint32_t)(qxb[j0 + j] >> 5), ya = (uint32_t)(qyb[j0 + j] >> 5);
                     uint32_t ad;
                     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ad) : "v"(ya), "s"(pw), "v"(Kv));
+                    // t = (tap X) | (tap X + 1) << 16 of the upper and of the lower row
                     if constexpr (DEPTH == 10) {
                         ad += xa << 1;
-                        t0[j] = *reinterpret_cast<const LdsU32a2 *>(ad), t1[j] = *reinterpret_cast<const LdsU32a2 *>(ad + (uint32_t)pw);
+                        const LdsU16 *u = reinterpret_cast<const LdsU16 *>(ad), *l = reinterpret_cast<const LdsU16 *>(ad + (uint32_t)pw);
+                        t0[j] = (uint32_t)u[0] | ((uint32_t)u[1] << 16), t1[j] = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
                     } else {
                         ad += xa;
-                        t0[j] = *reinterpret_cast<const LdsU16 *>(ad), t1[j] = *reinterpret_cast<const LdsU16 *>(ad + (uint32_t)pw);
+                        const LdsU8 *u = reinterpret_cast<const LdsU8 *>(ad), *l = reinterpret_cast<const LdsU8 *>(ad + (uint32_t)pw);
+                        t0[j] = (uint32_t)u[0] | ((uint32_t)u[1] << 16), t1[j] = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
                     }
                 }
 #pragma unroll
@@ -240,17 +253,15 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
                         out[j0 + j] = blend4<DEPTH, BLEND>((int)(t0[j] & 0xffffu), (int)(t0[j] >> 16), (int)(t1[j] & 0xffffu), (int)(t1[j] >> 16), (int)fx, (int)fy);
                     } else {
                         uint32_t h0, h1;
+                        const uint32_t wx = fx * 65535u + 32u;  // (32 - fx) | fx << 16: against the 16-bit fields, or against bytes 0 and 2
                         if constexpr (DEPTH == 10) {
-                            const uint32_t wx = fx * 65535u + 32u;  // (32 - fx) | fx << 16
                             h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, t0[j]), __builtin_bit_cast(u16x2, wx), 0u, false);
                             h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, t1[j]), __builtin_bit_cast(u16x2, wx), 0u, false);
                         } else {
-                            const uint32_t wx = fx * 255u + 32u;    // (32 - fx) | fx << 8; the taps' upper bytes are zero
                             h0 = __builtin_amdgcn_udot4(t0[j], wx, 0u, false);
                             h1 = __builtin_amdgcn_udot4(t1[j], wx, 0u, false);
                         }
-                        // (h0 * (32 - fy) + h1 * fy + 512) >> 10
-                        out[j0 + j] = (int)(((h0 << 5) + 512u + (uint32_t)__mul24((int)(h1 - h0), (int)fy)) >> 10);
+                        out[j0 + j] = lerp_rows(h0, h1, fy);
                     }
                 }
             }
@@ -300,17 +311,17 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
                 ad += xa * CPX;
                 if constexpr (DEPTH == 10) {
                     // (U0 | V0 << 16, U1 | V1 << 16) of both rows
-                    const u32_align2 __attribute__((address_space(3))) *pt = reinterpret_cast<const LdsU32a2 *>(ad), *pb = reinterpret_cast<const LdsU32a2 *>(ad + (uint32_t)pw);
+                    const LdsU32 *pt = reinterpret_cast<const LdsU32 *>(ad), *pb = reinterpret_cast<const LdsU32 *>(ad + (uint32_t)pw);
                     const uint32_t a0 = pt[0], a1 = pt[1], b0 = pb[0], b1 = pb[1];
                     cu[s] = blend4<DEPTH, BLEND>((int)(a0 & 0xffffu), (int)(a1 & 0xffffu), (int)(b0 & 0xffffu), (int)(b1 & 0xffffu), (int)fx, (int)fy);
                     cv[s] = blend4<DEPTH, BLEND>((int)(a0 >> 16), (int)(a1 >> 16), (int)(b0 >> 16), (int)(b1 >> 16), (int)fx, (int)fy);
                 } else {
-                    const uint32_t tt = *reinterpret_cast<const LdsU32a2 *>(ad), tb = *reinterpret_cast<const LdsU32a2 *>(ad + (uint32_t)pw);  // U0 V0 U1 V1
+                    const LdsU16 *pt = reinterpret_cast<const LdsU16 *>(ad), *pb = reinterpret_cast<const LdsU16 *>(ad + (uint32_t)pw);
+                    const uint32_t tt = (uint32_t)pt[0] | ((uint32_t)pt[1] << 16), tb = (uint32_t)pb[0] | ((uint32_t)pb[1] << 16);  // bytes U0 V0 U1 V1
                     const uint32_t wu = fx * 65535u + 32u, wv = wu << 8;  // (32 - fx) at byte 0 / 1, fx at byte 2 / 3
                     const uint32_t hu0 = __builtin_amdgcn_udot4(tt, wu, 0u, false), hu1 = __builtin_amdgcn_udot4(tb, wu, 0u, false);
                     const uint32_t hv0 = __builtin_amdgcn_udot4(tt, wv, 0u, false), hv1 = __builtin_amdgcn_udot4(tb, wv, 0u, false);
-                    cu[s] = (int)(((hu0 << 5) + 512u + (uint32_t)__mul24((int)(hu1 - hu0), (int)fy)) >> 10);
-                    cv[s] = (int)(((hv0 << 5) + 512u + (uint32_t)__mul24((int)(hv1 - hv0), (int)fy)) >> 10);
+                    cu[s] = lerp_rows(hu0, hu1, fy), cv[s] = lerp_rows(hv0, hv1, fy);
                 }
             }
         } else {
