@@ -111,6 +111,7 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
     constexpr int CR = RW / 2;        // chroma rows of a wave
     constexpr int NS = (RW + 3) / 4;  // chroma pixels per thread: CR rows x 32 columns over 64 lanes (RW = 2: the even lanes only)
     constexpr int QB = QMAGIC_BITS;
+    constexpr bool DMA = DEPTH == 8;  // the box is staged by LDS-DMA (bytes as they are); 16-bit samples go through registers
     uint8_t *const scratch = reinterpret_cast<uint8_t *>(smem) + 32;
     uint8_t *const tile = scratch + 4 * P::SCRATCH_PER_WAVE;
     const WarpArgs &a = ta.w;
@@ -135,45 +136,95 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
     const int pw = wb * BPS;                       // LDS row pitch in bytes, of both boxes (a chroma pair takes as much as two luma samples)
     const int luma_bytes = pw * hb;
 
-    // ---- load: this thread's blocks (BW x 2 luma samples + BW / 2 chroma pairs), every load in flight at once -----------
-    const int ux_n = wb / BW, units = use_lds ? ux_n * (hb >> 1) : 0;
-    uint4 y0w[STAGE_MAX], y1w[STAGE_MAX], uvw[STAGE_MAX];
-    int off_y[STAGE_MAX], off_c[STAGE_MAX];  // byte offsets of the block in the two boxes (off_y | ZERO_BLOCK: outside the source); -1 = no block
-    constexpr int ZERO_BLOCK = 1 << 24;
-    if (use_lds) {
-        const float rn = __builtin_amdgcn_rcpf((float)ux_n);
-        int uy = (int)((float)tid * rn), ux = tid - uy * ux_n;  // divmod(tid, ux_n): the float quotient is off by at most one
-        if (ux < 0) ux += ux_n, uy--;
-        if (ux >= ux_n) ux -= ux_n, uy++;
-        int sy_ = (int)(256.0f * rn), sx_ = 256 - sy_ * ux_n;   // uniform: divmod(256, ux_n)
-        if (sx_ < 0) sx_ += ux_n, sy_--;
-        if (sx_ >= ux_n) sx_ -= ux_n, sy_++;
-        const uint32_t pitch_y = (uint32_t)a.pitch_y, pitch_uv = (uint32_t)a.pitch_uv;  // < 2^24, frame < 4 GiB (host check)
-        const int sw_al = a.sw & ~(BW - 1);
-#pragma unroll
-        for (int it = 0; it < STAGE_MAX; it++) {
-            if (it > 0 && units <= it * 256) {  // uniform: most boxes have fewer than 256 blocks
-                y0w[it] = y1w[it] = uvw[it] = uint4(), off_y[it] = off_c[it] = -1;
-                continue;
+    // ---- load.  8-bit: the box goes from global memory straight into LDS (LDS-DMA, global_load_lds_dwordx4: no staging registers, no
+    // ds_write).  One wave-instruction writes 64 consecutive 16-byte chunks of LDS from 64 addresses of its lanes' choosing; the box is rows
+    // of ux_n chunks, so lane i of an instruction takes chunk (i / ux_n, i % ux_n) of a group of 64 / ux_n rows and the LDS image is the box,
+    // row after row.  The lane's part of the source offset is computed ONCE per tile; an instruction adds a scalar row offset.  The four
+    // waves take the row groups of the luma box, then of the chroma box, in turn.  Chunks outside the source (tiles at the frame's edge)
+    // are not fetched but written as limited-range black.  16-bit samples: through registers (below), reduced to ten bits on the way. -----
+    const int ux_n = wb / BW;
+    if constexpr (DMA) {
+        if (use_lds) {
+            const float rn = __builtin_amdgcn_rcpf((float)ux_n);
+            int r0 = (int)((float)lane * rn), col = lane - r0 * ux_n;  // divmod(lane, ux_n): the float quotient is off by at most one
+            if (col < 0) col += ux_n, r0--;
+            if (col >= ux_n) col -= ux_n, r0++;
+            const int rpi_f = __builtin_amdgcn_readfirstlane((int)(64.0f * rn + 0.001f));  // rows per instruction: floor(64 / ux_n)
+            const int rpi = rpi_f * ux_n <= 64 ? rpi_f : rpi_f - 1;
+            const bool active = r0 < rpi;
+            const int colb = bx0 + BWB * col;  // first source byte of the lane's chunk within a row (8-bit: byte = pixel)
+            const int sw_al = a.sw & ~(BW - 1);
+            const bool col_ok = (uint32_t)colb < (uint32_t)sw_al;
+            const uint32_t pitch_y = (uint32_t)a.pitch_y, pitch_uv = (uint32_t)a.pitch_uv;  // < 2^24, frame < 4 GiB (host check)
+            const uint32_t lane_y = (uint32_t)r0 * pitch_y + (uint32_t)colb, lane_c = (uint32_t)r0 * pitch_uv + (uint32_t)colb;
+            const int hc = hb >> 1;
+            const int nl = (hb + rpi - 1) / rpi, nc = (hc + rpi - 1) / rpi;
+            const bool interior = bx0 >= 0 && by0 >= 0 && bx0 + wb <= sw_al && by0 + hb <= a.sh;  // uniform: no chunk outside the source
+#pragma unroll 1
+            for (int t = wave; t < nl + nc; t += 4) {
+                const bool luma = t < nl;                      // uniform
+                const int k = (luma ? t : t - nl) * rpi;       // first box row of the group
+                const int R = k + r0;                          // this lane's box row
+                const int srow = (luma ? by0 : by0 >> 1) + k;  // first source row of the group (may be negative at the frame's edge)
+                bool ok = active && R < (luma ? hb : hc), fill = false;
+                if (!interior) {
+                    const bool in = col_ok && (uint32_t)(srow + r0) < (uint32_t)(luma ? a.sh : a.sh >> 1);
+                    fill = ok && !in, ok = ok && in;
+                }
+                uint8_t *const ldst = tile + (luma ? 0 : luma_bytes) + k * pw;  // uniform; the lanes' chunks follow each other from here
+                if (ok) {
+                    const uint32_t off = (uint32_t)srow * (luma ? pitch_y : pitch_uv) + (luma ? lane_y : lane_c);  // modulo 2^32: a negative srow is made up for by r0
+                    __builtin_amdgcn_global_load_lds((luma ? a.y : a.uv) + (size_t)off, (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+                }
+                if (fill) {
+                    const uint32_t kb = luma ? P::BLACK_Y_DWORD : P::BLACK_C_DWORD;
+                    *reinterpret_cast<uint4 *>(ldst + lane * 16) = make_uint4(kb, kb, kb, kb);
+                }
             }
-            // a thread without a block in this trip, or with a block outside the source (the black border), loads from the
-            // nearest block inside; neither uses what it loaded
-            const bool valid = tid + it * 256 < units;
-            const int gx = bx0 + BW * ux, gy = by0 + 2 * uy;
-            const bool inside = (uint32_t)gx < (uint32_t)sw_al && (uint32_t)gy < (uint32_t)a.sh;
-            const uint32_t cx = (uint32_t)min(max(gx, 0), sw_al - BW), cy = (uint32_t)min(max(gy, 0), a.sh - 2);
-            const uint32_t oy = __umul24(cy, pitch_y) + cx * BPS, ouv = __umul24(cy >> 1, pitch_uv) + cx * BPS;
-            y0w[it] = *reinterpret_cast<const uint4 *>(a.y + oy);
-            y1w[it] = *reinterpret_cast<const uint4 *>(a.y + (oy + pitch_y));
-            uvw[it] = *reinterpret_cast<const uint4 *>(a.uv + ouv);
-            off_y[it] = valid ? (__mul24(2 * uy, pw) + BWB * ux) | (inside ? 0 : ZERO_BLOCK) : -1;
-            off_c[it] = luma_bytes + __mul24(uy, pw) + BWB * ux;
-            ux += sx_, uy += sy_;
-            if (ux >= ux_n) ux -= ux_n, uy++;
         }
-    } else {
+    }
+    // (16-bit samples) this thread's blocks (BW x 2 luma samples + BW / 2 chroma pairs), every load in flight at once
+    constexpr int NSTG = DMA ? 1 : STAGE_MAX;
+    const int units = use_lds && !DMA ? ux_n * (hb >> 1) : 0;
+    uint4 y0w[NSTG], y1w[NSTG], uvw[NSTG];
+    int off_y[NSTG], off_c[NSTG];  // byte offsets of the block in the two boxes (off_y | ZERO_BLOCK: outside the source); -1 = no block
+    constexpr int ZERO_BLOCK = 1 << 24;
+    if constexpr (!DMA) {
+        if (use_lds) {
+            const float rn = __builtin_amdgcn_rcpf((float)ux_n);
+            int uy = (int)((float)tid * rn), ux = tid - uy * ux_n;  // divmod(tid, ux_n): the float quotient is off by at most one
+            if (ux < 0) ux += ux_n, uy--;
+            if (ux >= ux_n) ux -= ux_n, uy++;
+            int sy_ = (int)(256.0f * rn), sx_ = 256 - sy_ * ux_n;   // uniform: divmod(256, ux_n)
+            if (sx_ < 0) sx_ += ux_n, sy_--;
+            if (sx_ >= ux_n) sx_ -= ux_n, sy_++;
+            const uint32_t pitch_y = (uint32_t)a.pitch_y, pitch_uv = (uint32_t)a.pitch_uv;  // < 2^24, frame < 4 GiB (host check)
+            const int sw_al = a.sw & ~(BW - 1);
 #pragma unroll
-        for (int it = 0; it < STAGE_MAX; it++) y0w[it] = y1w[it] = uvw[it] = uint4(), off_y[it] = off_c[it] = -1;
+            for (int it = 0; it < STAGE_MAX; it++) {
+                if (it > 0 && units <= it * 256) {  // uniform: most boxes have fewer than 256 blocks
+                    y0w[it] = y1w[it] = uvw[it] = uint4(), off_y[it] = off_c[it] = -1;
+                    continue;
+                }
+                // a thread without a block in this trip, or with a block outside the source (the black border), loads from the
+                // nearest block inside; neither uses what it loaded
+                const bool valid = tid + it * 256 < units;
+                const int gx = bx0 + BW * ux, gy = by0 + 2 * uy;
+                const bool inside = (uint32_t)gx < (uint32_t)sw_al && (uint32_t)gy < (uint32_t)a.sh;
+                const uint32_t cx = (uint32_t)min(max(gx, 0), sw_al - BW), cy = (uint32_t)min(max(gy, 0), a.sh - 2);
+                const uint32_t oy = __umul24(cy, pitch_y) + cx * BPS, ouv = __umul24(cy >> 1, pitch_uv) + cx * BPS;
+                y0w[it] = *reinterpret_cast<const uint4 *>(a.y + oy);
+                y1w[it] = *reinterpret_cast<const uint4 *>(a.y + (oy + pitch_y));
+                uvw[it] = *reinterpret_cast<const uint4 *>(a.uv + ouv);
+                off_y[it] = valid ? (__mul24(2 * uy, pw) + BWB * ux) | (inside ? 0 : ZERO_BLOCK) : -1;
+                off_c[it] = luma_bytes + __mul24(uy, pw) + BWB * ux;
+                ux += sx_, uy += sy_;
+                if (ux >= ux_n) ux -= ux_n, uy++;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < STAGE_MAX; it++) y0w[it] = y1w[it] = uvw[it] = uint4(), off_y[it] = off_c[it] = -1;
+        }
     }
 
     // ---- map: RW exact evaluations per thread, and the chroma positions of the even rows (vstab_warp_tile.hpp) ---------
@@ -184,10 +235,10 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
 #pragma unroll
     for (int j = 0; j < RW / 2; j++) asm volatile("" : "+v"(qcx[j]), "+v"(qcy[j]));
 
-    // ---- stage: the loaded blocks go to LDS as they are (10 bits: reduced to their significant bits) -------------------
-    if (use_lds) {
+    // ---- stage (16-bit samples): the loaded blocks go to LDS reduced to their ten significant bits ------------------------
+    if (!DMA && use_lds) {
 #pragma unroll
-        for (int it = 0; it < STAGE_MAX; it++) {
+        for (int it = 0; it < NSTG; it++) {
             if (off_y[it] >= ZERO_BLOCK) {
                 uint8_t *d = tile + (off_y[it] - ZERO_BLOCK);
                 const uint4 ky = make_uint4(P::BLACK_Y_DWORD, P::BLACK_Y_DWORD, P::BLACK_Y_DWORD, P::BLACK_Y_DWORD);
@@ -444,8 +495,10 @@ vstab_status launch_warp_planar(const WarpArgs &a, const float params[17], int m
     const int bps = depth == 10 ? 2 : 1;
     const long tiles32 = (long)div_up(a.dw, 64) * div_up(a.dh, 32);
     const int rwb = tiles32 < 1536 ? 4 : 8;
-    const int lds_kb = (rwb == 8 ? 24 : 14) * bps;
-    const double tail_rounds = (double)div_up(a.dw, 64) * div_up(a.dh, 4 * rwb) > 256.0 * std::min(6, 160 / lds_kb) ? 0.5 : 0.0;
+    int lds_kb = (rwb == 8 ? 24 : 14) * bps;
+    double tail_rounds = (double)div_up(a.dw, 64) * div_up(a.dh, 4 * rwb) > 256.0 * std::min(6, 160 / lds_kb) ? 0.5 : 0.0;
+    if (const char *e = getenv("VSTAB_PLANAR_LDS_KB")) lds_kb = atoi(e);
+    if (const char *e = getenv("VSTAB_PLANAR_TAIL")) tail_rounds = atof(e);
     const dim3 grid(tile_schedule(ta, rwb, lds_kb, tail_rounds));
     const size_t lds_bytes = (size_t)lds_kb * 1024;
     ta.lds_capacity_px = (int)((lds_bytes - 32 - 4 * 768 * (size_t)bps) * 2 / (3 * (size_t)bps));
