@@ -498,6 +498,12 @@ VSTAB_API vstab_status vstab_pull_frames(vstab_handle *h, int n, void *const *ds
  * of 2*ceil(width/2) bytes.  BGR and NV12 pulls may be mixed freely on one handle. */
 VSTAB_API vstab_status vstab_pull_frame_nv12(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv,
                                              size_t pitch_uv);
+/* The same pull with the frame warped PLANE BY PLANE -- no colour round trip (VSTAB_OUT_NV12_PLANAR: the Y and UV planes of the
+ * source remapped as they are, limited-range black outside; SURVEY.md 8(f) row 2, the route the CLI's filter takes between NV12
+ * surfaces, render.ts:606-607, 664-665, 688): fewer instructions per pixel than any route through BGR, 23.0 MB instead of 33.6 MB
+ * moved per 4K frame.  Same look-ahead, same rotations, same planes' shapes as vstab_pull_frame_nv12; the map is evaluated for every
+ * frame (the quantised-map cache holds no chroma positions).  May be mixed with the other 8-bit pulls on one handle. */
+VSTAB_API vstab_status vstab_pull_frame_nv12_planar(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv);
 /* pull_frame into HOST memory (what a cv::Mat / imshow consumer of DisplayImage.cpp:63-65 needs): the frame is warped
  * into a buffer of the handle and copied out; returns when the copy has completed. */
 VSTAB_API vstab_status vstab_pull_frame_host(vstab_handle *h, void *dst_bgr_host, size_t pitch_dst);
@@ -508,6 +514,9 @@ VSTAB_API vstab_status vstab_pull_frame_bgr16(vstab_handle *h, void *dst_bgr16, 
  * warped and converted in one kernel (vstab_warp_p010_planes) when the frame's planes allow it, else warped into a 16-bit BGR buffer of the
  * handle and converted by vstab_cvt_bgr16_p010. */
 VSTAB_API vstab_status vstab_pull_frame_p010(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv);
+/* pull_frame of a pixel_depth = 10 handle warped plane by plane (vstab_warp_p010_planar): P010 planes in, P010 planes out, no
+ * conversion to BGR and back; vstab_config.blend selects the blend of each sample. */
+VSTAB_API vstab_status vstab_pull_frame_p010_planar(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv);
 /* FrameSourceWarp::peek_frame (:478-480) IS pull_frame in the reference (destructive); kept. */
 VSTAB_API vstab_status vstab_peek_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
 VSTAB_API void vstab_destroy(vstab_handle *h);

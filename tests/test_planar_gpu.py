@@ -201,3 +201,79 @@ def test_planar_argument_errors(vs, cuda):
     assert e.value.status == vs.ERR_UNSUPPORTED
     with pytest.raises(vs.VstabError):
         vs.warp_p010_planar(torch.zeros((36, 64), dtype=torch.int16, device=cuda), torch.zeros((18, 64), dtype=torch.int16, device=cuda), p, dw, dh, blend=2)
+
+
+def test_pipeline_pull_planar_matches_the_checker_frame_by_frame(vs, cuda):
+    """vstab_pull_frame_nv12_planar on the pipeline object (default map arithmetic): every emitted frame is the plane-wise warp of its
+    input frame under the rotation the handle reports -- the checker: the reference's createMap kernel + the oracle's plane-wise remap.
+    Mixed with BGR pulls on one handle (the same frame either way up to the output format); tracking off bypasses the quantised-map
+    cache; a read-out rotation per frame takes the per-row kernel."""
+    import torch
+    W, H, n, r = 640, 360, 12, 3
+    K = oracle.get_preset_camera(4, W, H)
+    frames, _ = synth.shaky_clip(3, K, W, H, n, sigma=0.004)
+    Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
+    dev_frames = [torch.from_numpy(f).to(cuda) for f in frames]
+    stab = vs.Stabilizer(dev_frames, total=n, smooth_radius=r, seed=5)
+    for i in range(n - 1):
+        p = None
+        if i % 3 == 2:      # a BGR pull in between: same handle, same look-ahead
+            o = stab.pull()
+            assert o is not None
+            p = oracle.map_params(K, Ko, stab.warp_rotation(i))
+            assert np.array_equal(o.cpu().numpy(), expect.warp(frames[i + 1], p, cw, ch)), i
+            continue
+        yuv = stab.pull_nv12(planar=True)
+        assert yuv is not None, i
+        p = oracle.map_params(K, Ko, stab.warp_rotation(i))
+        ey, euv = expect.warp_planar(frames[i + 1], p, cw, ch)
+        assert np.array_equal(yuv[0].cpu().numpy(), ey) and np.array_equal(yuv[1].cpu().numpy(), euv), i
+    assert stab.pull_nv12(planar=True) is None
+    stab.close()
+    # tracking off: constant parameters (the BGR pulls of such a handle take the cached map; the plane-wise warp evaluates its own)
+    stab = vs.Stabilizer(dev_frames, total=6, smooth_radius=1, tracking=0)
+    p = oracle.map_params(K, Ko, np.eye(3))
+    for i in range(5):
+        if i == 2:
+            assert np.array_equal(stab.pull().cpu().numpy(), expect.warp(frames[i + 1], p, cw, ch))
+            continue
+        y, uv = stab.pull_nv12(planar=True)
+        ey, euv = expect.warp_planar(frames[i + 1], p, cw, ch)
+        assert np.array_equal(y.cpu().numpy(), ey) and np.array_equal(uv.cpu().numpy(), euv), i
+    stab.close()
+    # read-out rotations: the warp takes a rotation per output row
+    ro = [oracle.rodrigues((0.002 * (k % 3), -0.003, 0.001 * k)) for k in range(6)]
+    stab = vs.Stabilizer(dev_frames[:6], total=6, smooth_radius=1, tracking=0, readouts=ro)
+    for i in range(5):
+        y, uv = stab.pull_nv12(planar=True)
+        W_rot = stab.warp_rotation(i)
+        p = oracle.map_params(K, Ko, W_rot)
+        rb = oracle.map_params(K, Ko, ro[i + 1] @ W_rot)[8:]
+        ey, euv = expect.warp_planar(frames[i + 1], p, cw, ch, expect.OPENCL, rb)
+        assert np.array_equal(y.cpu().numpy(), ey) and np.array_equal(uv.cpu().numpy(), euv), i
+    stab.close()
+
+
+def test_pipeline_pull_p010_planar(vs, cuda):
+    """pixel_depth = 10 handles: vstab_pull_frame_p010_planar = the plane-wise 10-bit warp of the ORIGINAL 16-bit planes under the
+    handle's rotation, both blends; the 8-bit pulls are refused."""
+    import torch
+    W, H, n, r = 640, 360, 8, 2
+    K = oracle.get_preset_camera(4, W, H)
+    frames8, _ = synth.shaky_clip(3, K, W, H, n, sigma=0.004)
+    rng = np.random.default_rng(9)
+    wide = [((f.astype(np.uint16) << 8) | (rng.integers(0, 4, f.shape, dtype=np.uint16) << 6) | rng.integers(0, 64, f.shape, dtype=np.uint16)) for f in frames8]
+    dev_frames = [torch.from_numpy(x.view(np.int16)).to(cuda) for x in wide]
+    Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
+    for blend in (0, 1):
+        stab = vs.Stabilizer(dev_frames, total=n, bit_depth=10, smooth_radius=r, seed=5, pixel_depth=10, blend=blend)
+        for i in range(n - 1):
+            oy = torch.empty((ch, cw), dtype=torch.int16, device=cuda)
+            ouv = torch.empty(((ch + 1) // 2, 2 * ((cw + 1) // 2)), dtype=torch.int16, device=cuda)
+            assert stab.pull_p010_planar_into(oy, ouv), i
+            p = oracle.map_params(K, Ko, stab.warp_rotation(i))
+            ey, euv = expect.warp_p010_planar(wide[i + 1][:H], wide[i + 1][H:], p, cw, ch, None, blend)
+            assert np.array_equal(oy.cpu().numpy().view(np.uint16), ey) and np.array_equal(ouv.cpu().numpy().view(np.uint16), euv), (blend, i)
+        with pytest.raises(vs.VstabError):
+            stab.pull_nv12(planar=True)
+        stab.close()

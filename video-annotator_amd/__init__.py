@@ -134,6 +134,8 @@ SIGNATURES = {
     "vstab_pull_frame_p010": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "vstab_pull_frames": (_i, [_vp, _i, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t), _i, _i, _c.POINTER(_c.c_int)]),
     "vstab_pull_frame_nv12": (_i, [_vp, _vp, _sz, _vp, _sz]),
+    "vstab_pull_frame_nv12_planar": (_i, [_vp, _vp, _sz, _vp, _sz]),
+    "vstab_pull_frame_p010_planar": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "vstab_pull_frame_host": (_i, [_vp, _vp, _sz]),
     "vstab_lens_camera": (_i, [_i, _d, _i, _i, _d, _d, _dp]),
     "vstab_peek_frame": (_i, [_vp, _vp, _sz]),
@@ -716,17 +718,27 @@ class Stabilizer:
         _check(st, "vstab_pull_frame_host")
         return out
 
-    def pull_nv12_into(self, y, uv):
-        st = _L.vstab_pull_frame_nv12(self._h, y.data_ptr(), y.stride(0), uv.data_ptr(), uv.stride(0))
+    def pull_nv12_into(self, y, uv, planar=False):
+        """planar=True: vstab_pull_frame_nv12_planar, the plane-wise warp (no colour round trip)."""
+        fn, name = (_L.vstab_pull_frame_nv12_planar, "vstab_pull_frame_nv12_planar") if planar else (_L.vstab_pull_frame_nv12, "vstab_pull_frame_nv12")
+        st = fn(self._h, y.data_ptr(), y.stride(0), uv.data_ptr(), uv.stride(0))
         if st == EOF:
             return False
-        _check(st, "vstab_pull_frame_nv12")
+        _check(st, name)
         return True
 
-    def pull_nv12(self):
+    def pull_nv12(self, planar=False):
         """-> (luma, chroma) tensors, or None at end of stream."""
         y, uv = nv12_out_planes(self.out_size[0], self.out_size[1])
-        return (y, uv) if self.pull_nv12_into(y, uv) else None
+        return (y, uv) if self.pull_nv12_into(y, uv, planar) else None
+
+    def pull_p010_planar_into(self, out_y, out_uv):
+        """pixel_depth = 10 handles: the frame warped plane by plane (vstab_pull_frame_p010_planar), P010 planes as pull_p010_into."""
+        st = _L.vstab_pull_frame_p010_planar(self._h, out_y.data_ptr(), out_y.stride(0) * 2, out_uv.data_ptr(), out_uv.stride(0) * 2)
+        if st == EOF:
+            return False
+        _check(st, "vstab_pull_frame_p010_planar")
+        return True
 
     def frame_log(self):
         out = []

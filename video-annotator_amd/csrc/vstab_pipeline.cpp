@@ -1582,13 +1582,16 @@ vstab_status vstab_get_output_info(const vstab_handle *h, int *width, int *heigh
 
 }  // extern "C"
 
-constexpr int OUT_BGR16 = 2;  // internal: the 10-bit path's output (vstab_pull_frame_bgr16)
-constexpr int OUT_P010 = 3;   // internal: the 10-bit path's frame as P010 planes (vstab_pull_frame_p010)
+constexpr int OUT_BGR16 = 16;        // internal: the 10-bit path's output (vstab_pull_frame_bgr16)
+constexpr int OUT_P010 = 17;         // internal: the 10-bit path's frame as P010 planes (vstab_pull_frame_p010)
+constexpr int OUT_P010_PLANAR = 18;  // internal: the 10-bit frame warped plane by plane (vstab_pull_frame_p010_planar)
+static inline bool out_is_10bit(int f) { return f == OUT_BGR16 || f == OUT_P010 || f == OUT_P010_PLANAR; }
+static inline bool out_has_chroma_plane(int f) { return f == VSTAB_OUT_NV12 || f == VSTAB_OUT_NV12_PLANAR || f == OUT_P010 || f == OUT_P010_PLANAR; }
 
 // FrameSourceWarp::pull_frame, :452-476
 static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, size_t pitch_dst, void *dst_uv, size_t pitch_dst_uv) {
-    if (!H || !dst || ((out_format == VSTAB_OUT_NV12 || out_format == OUT_P010) && !dst_uv)) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: null argument");
-    if ((H->cfg.pixel_depth == 10) != (out_format == OUT_BGR16 || out_format == OUT_P010))
+    if (!H || !dst || (out_has_chroma_plane(out_format) && !dst_uv)) return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: null argument");
+    if ((H->cfg.pixel_depth == 10) != out_is_10bit(out_format))
         return fail(VSTAB_ERR_INVALID, "vstab_pull_frame: a pixel_depth 10 handle emits through vstab_pull_frame_bgr16, an 8-bit handle through the others");
     HT t_total(HostTimers::TOTAL);
     while (H->queue.size() <= (size_t)H->cfg.smooth_radius) {  // :453
@@ -1649,7 +1652,8 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
     float p_bottom[17];
     if (S.have_readout) map_params(H->Kin, H->Kout, S.readout * warp_R, p_bottom);
     bool cached = false;
-    if (H->map_cache && !S.have_readout && out_format != OUT_BGR16 && out_format != OUT_P010) {
+    // (the quantised map holds no chroma positions: the plane-wise warp always evaluates its map)
+    if (H->map_cache && !S.have_readout && !out_is_10bit(out_format) && out_format != VSTAB_OUT_NV12_PLANAR) {
         if (H->qmap_valid && std::memcmp(p, H->qmap_params, sizeof(p)) == 0) {
             cached = true;
         } else if (H->have_last_params && std::memcmp(p, H->last_params, sizeof(p)) == 0) {
@@ -1682,6 +1686,9 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
         if (out_format == OUT_BGR16)
             st = vstab_warp_p010(S.y16, S.pitch_y16, S.uv16, S.pitch_uv16, H->w, H->h, p,
                                  S.have_readout ? p_bottom + 8 : nullptr, H->map_mode, H->cfg.blend, dst, pitch_dst, H->ow, H->oh, H->stream);
+        else if (out_format == OUT_P010_PLANAR)
+            st = vstab_warp_p010_planar(S.y16, S.pitch_y16, S.uv16, S.pitch_uv16, H->w, H->h, p, S.have_readout ? p_bottom + 8 : nullptr, H->map_mode,
+                                        H->cfg.blend, dst, pitch_dst, dst_uv, pitch_dst_uv, H->ow, H->oh, H->stream);
         else if (out_format == OUT_P010) {
             st = vstab_warp_p010_planes(S.y16, S.pitch_y16, S.uv16, S.pitch_uv16, H->w, H->h, p, S.have_readout ? p_bottom + 8 : nullptr, H->map_mode,
                                         H->cfg.blend, dst, pitch_dst, dst_uv, pitch_dst_uv, H->ow, H->oh, H->stream);
@@ -1708,7 +1715,7 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
             st = vstab_warp_nv12_ex(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, p, H->map_mode, out_format, dst,
                                     pitch_dst, dst_uv, pitch_dst_uv, H->ow, H->oh, H->stream);
     }
-    if (st == VSTAB_OK && H->cfg.debug && !S.feats.empty() && out_format != OUT_BGR16 && out_format != OUT_P010) {  // (markers are drawn into 8-bit outputs)
+    if (st == VSTAB_OK && H->cfg.debug && !S.feats.empty() && !out_is_10bit(out_format)) {  // (markers are drawn into 8-bit outputs)
         // where the warp sends each tracked feature: input pixel -> ray -> R^T -> output projection (the inverse of the map)
         constexpr int SETS = 16, CAP = 256;
         VSTAB_TRY(H->marker_pts.ensure(sizeof(int) * 2 * CAP * SETS));
@@ -1735,7 +1742,7 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
             host[2 * n] = (int)std::nearbyint(H->Kout(0, 2) + u * H->Kout(0, 0)), host[2 * n + 1] = (int)std::nearbyint(H->Kout(1, 2) + v * H->Kout(1, 1));
             n++;
         }
-        if (out_format == VSTAB_OUT_NV12)
+        if (out_format == VSTAB_OUT_NV12 || out_format == VSTAB_OUT_NV12_PLANAR)
             st = vstab_draw_markers(dst, pitch_dst, H->ow, H->oh, 1, dev, n, 3, 235u, H->stream);
         else
             st = vstab_draw_markers(dst, pitch_dst, H->ow, H->oh, 3, dev, n, 3, 0x0000FF00u, H->stream);
@@ -1799,6 +1806,14 @@ vstab_status vstab_pull_frame_p010(vstab_handle *h, void *dst_y, size_t pitch_y,
 
 vstab_status vstab_pull_frame_nv12(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv) {
     return pull_frame_impl(h, VSTAB_OUT_NV12, dst_y, pitch_y, dst_uv, pitch_uv);
+}
+
+vstab_status vstab_pull_frame_nv12_planar(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv) {
+    return pull_frame_impl(h, VSTAB_OUT_NV12_PLANAR, dst_y, pitch_y, dst_uv, pitch_uv);
+}
+
+vstab_status vstab_pull_frame_p010_planar(vstab_handle *h, void *dst_y, size_t pitch_y, void *dst_uv, size_t pitch_uv) {
+    return pull_frame_impl(h, OUT_P010_PLANAR, dst_y, pitch_y, dst_uv, pitch_uv);
 }
 
 vstab_status vstab_peek_frame(vstab_handle *h, void *dst, size_t pitch_dst) { return vstab_pull_frame(h, dst, pitch_dst); }  // :478-480
