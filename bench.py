@@ -3,9 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p] [--mode auto|warp]
 
-One "step" = one pass of the hot path over one batch of synthetic input: --batch (default 64, the
-input ring) consecutive frames of this rank's clip, each emitted as one output frame; `value` is
-frames/s.  Inputs (a ring of distinct synthetic NV12 frames) are resident in HBM before the timed
+One "step" = one pass of the hot path over one batch of synthetic input: --batch consecutive frames of
+this rank's clip (default 256 in pipeline mode: four passes over the 64-frame input ring), each emitted
+as one output frame; `value` is frames/s, computed from the whole timed region; `step_ms` carries the
+median / min / max of the steps' GPU-side durations (events at the step boundaries).  Inputs (a ring of distinct synthetic NV12 frames) are resident in HBM before the timed
 region, and an untimed pre-roll
 (--preroll, default 1024 frames) ahead of --warmup fills the look-ahead queue and brings clocks,
 prefetch depth and the speculative detector to steady state.  N > 1: one rank per GPU, one
@@ -21,7 +22,8 @@ Rank 0 prints ONE JSON line with the driver's contract plus
   "cpu_baseline": the CPU oracle (a port of the reference's cvtColor -> createMap -> remap path)
                   timed on a bounded sample on this host's cores (all the box's share; "cpu_baseline_1_thread": one), and
   "copy_ingest":  the same pipeline with every frame COPIED into the library's ring (vstab_frame.hold = 0, what a decoder
-                  that recycles its surface gives), measured after the timed region, and
+                  that recycles its surface gives), measured after the timed region in the same windowing (steps x batch), and
+  "host":         what the rank costs the host: CPU seconds (user + system, all threads) per 1000 frames of the timed region, and
   "cpu_baseline_full_pipeline": the oracle's whole consume_frame / pull_frame loop (detector, LK, smoothing, warp), and
   "parity_check": one frame emitted after the timed region compared bit for bit with the oracle's warp of the same input
                   frame under the rotation the pipeline reports for it (the run fails if they differ).
@@ -49,7 +51,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40, help="timed steps; one step = one batch of --batch frames")
     ap.add_argument("--warmup", type=int, default=4, help="untimed steps ahead of the timed region")
-    ap.add_argument("--batch", type=int, default=64, help="frames per step (one pass over the input ring by default)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="frames per step.  Default: 256 in pipeline mode (four passes over the input ring; 20 steps are ~190 ms at 4K, so that one "
+                         "host stall does not move the line), 64 (one pass over the ring) with --mode warp")
     ap.add_argument("--preroll", type=int, default=1024, help="untimed frames ahead of --warmup (pipeline mode): steady state before the driver's window")
     ap.add_argument("--fixed-preroll", action="store_true", help="exactly --preroll untimed frames (default: at least that many, then until the rate is steady)")
     ap.add_argument("--workload", default="4k", choices=["4k", "1080p", "4k-p010"],
@@ -58,9 +62,10 @@ def parse():
     ap.add_argument("--ring", type=int, default=64, help="distinct input frames / output buffers")
     ap.add_argument("--no-tracking", action="store_true",
                     help="BASELINE config 1: undistort only (identity rotations) through the pipeline object")
-    ap.add_argument("--out-format", default="bgr", choices=["bgr", "nv12", "p010"],
-                    help="bgr = what FrameSourceWarp emits (the BASELINE metric); nv12 = encoder hand-off mode (SURVEY.md 8(f) row 2); "
-                         "p010 = the same for --workload 4k-p010 (P010 planes written by the warp kernel itself)")
+    ap.add_argument("--out-format", default="bgr", choices=["bgr", "nv12", "p010", "nv12-planar", "p010-planar"],
+                    help="bgr = what FrameSourceWarp emits (the BASELINE metric); nv12 = encoder hand-off through BGR (the BGR frame converted in the "
+                         "kernel); p010 = the same for --workload 4k-p010; nv12-planar / p010-planar = SURVEY.md 8(f) row 2 as written: the planes "
+                         "remapped as they are, no colour round trip (vstab_pull_frame_nv12_planar / vstab_pull_frame_p010_planar)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo only for rehearsing ranks on one GPU")
@@ -242,6 +247,28 @@ def cpu_baseline_full(frames, K, Ko, cw, ch, w, h, budget_s=12.0):
                       f"cvtColor+createMap+remap (OpenMP), {el:.1f} s"}
 
 
+def side_pass(torch, pull, args, what):
+    """A pipeline variant behind the timed region, in the driver's windowing: 1024 frames of pre-roll, --warmup steps, then --steps steps
+    of --batch frames between synchronisations, with an event at every step boundary."""
+    for i in range(1024 + args.warmup * args.batch):
+        assert pull(i)
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True)]
+    tc = time.perf_counter()
+    evs[0].record()
+    for k in range(args.steps):
+        for i in range(args.batch):
+            assert pull(k * args.batch + i)
+        evs.append(torch.cuda.Event(enable_timing=True))
+        evs[-1].record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - tc
+    ms = [a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:])]
+    return {"value": round(args.steps * args.batch / el, 1), "unit": "frames/s", "steps": args.steps, "frames_per_step": args.batch,
+            "step_ms": {"median": round(float(np.median(ms)), 4), "min": round(min(ms), 4), "max": round(max(ms), 4)},
+            "what": what + f"; {args.steps} steps of {args.batch} frames after a pre-roll of 1024 frames + {args.warmup} steps, behind the timed region"}
+
+
 def launch_ranks(args):
     """`bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child process (nothing in this process has
     touched the GPU), relay rank 0's JSON line and the exit code.  Model: concat.sh:248 (xargs -P N)."""
@@ -329,7 +356,7 @@ def rehearse_launcher(args, rank, local, world, torch, dist):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     shard = importlib.import_module("video-annotator_amd.shard")
     mine = sorted(os.sched_getaffinity(0))
-    n_frames = args.steps * args.batch
+    n_frames = args.steps * (args.batch or 256)
     rec = dict(rank=rank, clip=rank, frames=n_frames, elapsed_ns=int(float(t.item()) * 1e9), crc=shard.crc_of(np.full(16, rank, np.uint8)), cpu_first=mine[0],
                cpu_last=mine[-1], cpu_count=len(mine))
     records = shard.gather_records([rec], device=torch.device("cpu"))
@@ -405,13 +432,14 @@ def main():
 
     w, h = (1920, 1080) if args.workload == "1080p" else (3840, 2160)
     p010 = args.workload == "4k-p010"
-    if p010 and (args.mode == "warp" or args.out_format == "nv12" or args.no_tracking):
+    if p010 and (args.mode == "warp" or args.out_format in ("nv12", "nv12-planar") or args.no_tracking):
         print("bench.py: --workload 4k-p010 runs the full pipeline with 16-bit BGR or P010 output", file=sys.stderr)
         return 2
-    if args.out_format == "p010" and not p010:
-        print("bench.py: --out-format p010 belongs to --workload 4k-p010", file=sys.stderr)
+    if args.out_format in ("p010", "p010-planar") and not p010:
+        print("bench.py: --out-format p010 / p010-planar belongs to --workload 4k-p010", file=sys.stderr)
         return 2
-    p010_out = p010 and args.out_format == "p010"
+    planar = args.out_format in ("nv12-planar", "p010-planar")   # the plane-wise warp: no colour round trip
+    p010_out = p010 and args.out_format in ("p010", "p010-planar")
     preset = vs.GOPRO_H4B_WIDE169_MEASURED
     K = vs.get_preset_camera(preset, w, h)
     Ko, (cw, ch) = vs.get_output_camera(K, w, h, 1.0, False, 1.0)
@@ -421,8 +449,11 @@ def main():
     if mode == "auto":
         mode = "pipeline" if have_pipeline else "warp"
 
+    if args.batch is None:
+        args.batch = 256 if mode == "pipeline" else 64
     ring = synth_ring(torch, dev, w, h, args.ring, seed=rank) if mode == "warp" else None
-    nv12_out = args.out_format == "nv12"
+    nv12_out = args.out_format in ("nv12", "nv12-planar")
+    out_fmt = vs.OUT_NV12_PLANAR if planar else vs.OUT_NV12 if nv12_out else vs.OUT_BGR8
     if nv12_out:
         outs = [vs.nv12_out_planes(cw, ch, dev) for _ in range(args.ring)]
     elif p010_out:
@@ -432,7 +463,7 @@ def main():
         outs = [torch.empty((ch, cw, 3), dtype=torch.int16, device=dev) for _ in range(args.ring)]
     else:
         outs = [torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(args.ring)]
-    out_name = "NV12" if nv12_out else "BGR"
+    out_name = "NV12 (plane-wise warp, no colour round trip)" if planar else "NV12 (the BGR frame converted)" if nv12_out else "BGR"
     if os.environ.get("VSTAB_BENCH_OWN_STREAM"):  # development: the caller works on a stream of its own instead of the default stream (the default stream stays in the process: a fifth stream)
         torch.cuda.set_stream(torch.cuda.Stream())
     stream = torch.cuda.current_stream()
@@ -458,8 +489,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 vs.time_next_launch(e0, e1)
                 kernel_events.append((e0, e1))
-            vs.warp_nv12(ring[i % args.ring], params[i], cw, ch, map_mode, vs.OUT_NV12 if nv12_out else vs.OUT_BGR8,
-                         out=outs[i % args.ring])
+            vs.warp_nv12(ring[i % args.ring], params[i], cw, ch, map_mode, out_fmt, out=outs[i % args.ring])
         workload = f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, fused undistort-remap (createMap+cvtColor+remap), per-frame rotation, tracking/smoothing NOT included"
     else:
         clip, _ = shaky_ring(torch, dev, w, h, K, args.ring, seed=rank)
@@ -486,9 +516,13 @@ def main():
                 stab.profile()               # fold + discard the warm-up stages
                 stab._prof0 = stab.profile()
             assert pull(i)
-        pull = (lambda i: stab.pull_nv12_into(*outs[i % args.ring])) if nv12_out else (lambda i: stab.pull_into(outs[i % args.ring]))
-        if p010:
-            pull = (lambda i: stab.pull_p010_into(*outs[i % args.ring])) if p010_out else (lambda i: stab.pull_bgr16_into(outs[i % args.ring]))
+        def make_pull(st):
+            if p010:
+                if planar:
+                    return lambda i: st.pull_p010_planar_into(*outs[i % args.ring])
+                return (lambda i: st.pull_p010_into(*outs[i % args.ring])) if p010_out else (lambda i: st.pull_bgr16_into(outs[i % args.ring]))
+            return (lambda i: st.pull_nv12_into(*outs[i % args.ring], planar=planar)) if nv12_out else (lambda i: st.pull_into(outs[i % args.ring]))
+        pull = make_pull(stab)
         stab.enable_profiling(1)  # timed region: HIP events around the warp launches only
         ingest_txt = ("frames used in place (upstream holds them: vstab_frame.hold), no pack kernel" if args.ingest == "inplace"
                       else "every frame copied into the library's ring (vstab_frame.hold = 0: vstab_pack_nv12)")
@@ -500,12 +534,21 @@ def main():
             workload = (f"{args.workload} NV12 {w}x{h} -> {out_name} {cw}x{ch}, undistort only (tracking off, identity rotations): {ingest_txt}; "
                         f"fused undistort-remap from the map written once{prec_txt}")
         if p010:
-            workload = (f"4k P010 {w}x{h} -> {'P010 planes' if p010_out else 'BGR 16-bit (10 significant)'} {cw}x{ch}, BASELINE config 5: full pipeline on the narrowed luma (corner detect, "
+            out10 = "P010 planes (plane-wise warp, no colour round trip)" if planar else "P010 planes" if p010_out else "BGR 16-bit (10 significant)"
+            workload = (f"4k P010 {w}x{h} -> {out10} {cw}x{ch}, BASELINE config 5: full pipeline on the narrowed luma (corner detect, "
                         f"pyramidal LK, rotation estimate, SG r=30), 10-bit undistort-remap with fp16 blend and a rotation per output row{prec_txt}")
 
     # pipeline mode, BGR frames: a step is ONE library call that pulls the step's batch of frames into the output ring
     # (vstab_pull_frames: the consumer's frame loop on the C side of the boundary, where the reference has it)
     batched = mode == "pipeline" and args.pull == "batch" and not nv12_out and not p010
+    # every step boundary gets an event on the caller's stream (recorded, never waited for inside the region): the spread of the
+    # steps' GPU-side durations travels in the line, so that one slow step is told from a slower run
+    step_events = []
+
+    def mark():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        step_events.append(e)
     if batched:
         def run_steps(first_frame, n_steps, timed):
             for k in range(n_steps):
@@ -514,10 +557,15 @@ def main():
                     stab.profile()               # fold + discard the warm-up stages
                     stab._prof0 = stab.profile()
                 assert stab.pull_frames_into(outs, i0, args.batch) == args.batch
+                if timed:
+                    mark()
     else:
         def run_steps(first_frame, n_steps, timed):
-            for i in range(first_frame, first_frame + n_steps * args.batch):
-                step(i, timed)
+            for k in range(n_steps):
+                for i in range(first_frame + k * args.batch, first_frame + (k + 1) * args.batch):
+                    step(i, timed)
+                if timed:
+                    mark()
     for i in range(preroll):  # pipeline mode: untimed, ahead of the warm-up the driver asks for
         assert pull(i)
     if mode == "pipeline" and preroll and not args.fixed_preroll:
@@ -545,14 +593,28 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    cpu0 = os.times()
     t0 = time.perf_counter()
+    mark()
     run_steps(n_warm, args.steps, True)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    cpu1 = os.times()
     gc.enable()
+    step_ms = [a.elapsed_time(b) for a, b in zip(step_events[:-1], step_events[1:])]
+    # what a rank costs the HOST: CPU seconds (user + system, every thread of this process: the caller's frame loop, the handle's
+    # estimate worker and corner-selection helper, the runtime's threads) per 1000 frames of the timed region
+    cpu_s = (cpu1.user + cpu1.system) - (cpu0.user + cpu0.system)
+    try:
+        n_threads = int([ln.split()[1] for ln in open("/proc/self/status") if ln.startswith("Threads:")][0])
+    except Exception:
+        n_threads = None
+    host_cost = {"cpu_seconds_per_1000_frames": round(cpu_s / max(1, n_timed) * 1000, 4), "cpu_seconds": round(cpu_s, 4), "wall_seconds": round(el, 4),
+                 "cpus_busy": round(cpu_s / el, 2), "threads": n_threads, "pinned_cpus": len(os.sched_getaffinity(0)),
+                 "what": "user + system time of every thread of this rank's process over the timed region (os.times)"}
     if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -579,7 +641,16 @@ def main():
         src = clip[(n_emit + 1) % len(clip)].cpu().numpy()
         pr = oracle.map_params(K, Ko, stab.warp_rotation(n_emit))
         got = outs[n_emit % args.ring]
-        if p010:
+        if p010 and planar:
+            rb = oracle.map_params(K, Ko, readouts[(n_emit + 1) % len(clip)] @ stab.warp_rotation(n_emit))[8:]
+            s16 = src.view(np.uint16)
+            ey, euv = (oracle.warp_p010_planar_ref_gfx950(s16[:h], s16[h:], pr, cw, ch, rb, 1) if opencl
+                       else oracle.warp_p010_planar(s16[:h], s16[h:], pr, cw, ch, 0, rb, 1))
+            same = np.array_equal(got[0].cpu().numpy().view(np.uint16), ey) and np.array_equal(got[1].cpu().numpy().view(np.uint16), euv)
+        elif planar:
+            ey, euv = oracle.warp_nv12_planar_ref_gfx950(src, pr, cw, ch) if opencl else oracle.warp_nv12_planar(src, pr, cw, ch, 0)
+            same = np.array_equal(got[0].cpu().numpy(), ey) and np.array_equal(got[1].cpu().numpy(), euv)
+        elif p010:
             rb = oracle.map_params(K, Ko, readouts[(n_emit + 1) % len(clip)] @ stab.warp_rotation(n_emit))[8:]
             s16 = src.view(np.uint16)
             # opencl: the reference kernel's map row by row (one launch per output row with that row's matrix), oracle conversion and remap
@@ -604,8 +675,8 @@ def main():
         else:
             same = np.array_equal(got.cpu().numpy(), oracle.warp_nv12(src, pr, cw, ch))
         parity = "ok" if same else "MISMATCH"
-        parity_against = ("the reference's createMap kernel (oracle/_ref/createMap.gfx950.co, run on this GPU) -> oracle cvtColor / remap" if opencl
-                          else "the CPU oracle's IEEE chain")
+        parity_against = ("the reference's createMap kernel (oracle/_ref/createMap.gfx950.co, run on this GPU) -> oracle "
+                          + ("plane-wise remap (vo_remap_plane)" if planar else "cvtColor / remap") if opencl else "the CPU oracle's IEEE chain")
 
     # end-of-run record exchange: the run's only collective (RCCL all-gather over xGMI when N > 1),
     # then rank 0 writes the stitch list (concat.sh / join.ts format)
@@ -615,7 +686,7 @@ def main():
         last = last[0]
     mine = sorted(os.sched_getaffinity(0))
     rec = dict(rank=rank, clip=rank, frames=n_timed, elapsed_ns=int(el * 1e9), crc=shard.crc_of(last[:64].cpu().numpy()), cpu_first=mine[0], cpu_last=mine[-1],
-               cpu_count=len(mine))
+               cpu_count=len(mine), cpu_us=int(cpu_s * 1e6))
     records = shard.gather_records([rec], device=cdev)
     if rank == 0 and world > 1:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -651,15 +722,15 @@ def main():
         alone_us, copy_ingest, ieee_map = None, None, None
         if mode == "pipeline":
             pa = vs.map_params(K, Ko, rot(7))
-            run_alone = lambda i: vs.warp_nv12(clip[i % len(clip)], pa, cw, ch, map_mode, vs.OUT_NV12 if nv12_out else vs.OUT_BGR8,
-                                               out=outs[i % args.ring])  # cycling inputs and outputs: nothing stays in the caches
+            run_alone = lambda i: vs.warp_nv12(clip[i % len(clip)], pa, cw, ch, map_mode, out_fmt, out=outs[i % args.ring])  # cycling inputs and outputs: nothing stays in the caches
             if p010:
                 pb = vs.map_params(K, Ko, rot(8))[8:]
                 run_alone = lambda i: vs.warp_p010(clip[i % len(clip)][:h], clip[i % len(clip)][h:], pa, cw, ch, pb, vs.MAP_CREATEMAP_CL, vs.BLEND_FP16,
                                                    out=outs[i % args.ring])
                 if p010_out:
-                    run_alone = lambda i: vs.warp_p010_planes(clip[i % len(clip)][:h], clip[i % len(clip)][h:], pa, cw, ch, pb, vs.MAP_CREATEMAP_CL, vs.BLEND_FP16,
-                                                              out_y=outs[i % args.ring][0], out_uv=outs[i % args.ring][1])
+                    fn10 = vs.warp_p010_planar if planar else vs.warp_p010_planes
+                    run_alone = lambda i: fn10(clip[i % len(clip)][:h], clip[i % len(clip)][h:], pa, cw, ch, pb, vs.MAP_CREATEMAP_CL, vs.BLEND_FP16,
+                                               out_y=outs[i % args.ring][0], out_uv=outs[i % args.ring][1])
             for i in range(10):
                 run_alone(i)
             torch.cuda.synchronize()
@@ -673,48 +744,33 @@ def main():
                 # what a decoder that recycles its surface gives: hold = 0, every frame through vstab_pack_nv12 into the ring
                 # (untimed region; a short run of its own: pre-roll 200 frames, 10 batches)
                 stab.close()  # two handles alive = eight streams on the runtime's four hardware queues, which slows both
-                cstab = vs.Stabilizer(clip, total=600 + 10 * args.batch + 100, preset=preset, smooth_radius=30, seed=1234 + rank,
+                cstab = vs.Stabilizer(clip, total=1024 + (args.warmup + args.steps) * args.batch + 100, preset=preset, smooth_radius=30, seed=1234 + rank,
                                       tracking=0 if args.no_tracking else 1, ring_hold=0, **extra)
-                cpull = (lambda i: cstab.pull_nv12_into(*outs[i % args.ring])) if nv12_out else (lambda i: cstab.pull_into(outs[i % args.ring]))
-                for i in range(600):
-                    assert cpull(i)
-                torch.cuda.synchronize()
-                tc = time.perf_counter()
-                for i in range(10 * args.batch):
-                    assert cpull(i)
-                torch.cuda.synchronize()
-                copy_ingest = {"value": round(10 * args.batch / (time.perf_counter() - tc), 1), "unit": "frames/s",
-                               "what": "the same pipeline with vstab_frame.hold = 0: every frame copied into the library's ring by vstab_pack_nv12 "
-                                       f"(+{int(w * h * 3)} B of traffic and one kernel per frame); {10 * args.batch} frames after a 600-frame pre-roll, untimed region"}
+                copy_ingest = side_pass(torch, make_pull(cstab), args,
+                                        "the same pipeline with vstab_frame.hold = 0: every frame copied into the library's ring by vstab_pack_nv12 "
+                                        f"(+{int(w * h * 3)} B of traffic and one kernel per frame)")
                 cstab.close()
             if opencl and not p010 and world == 1 and not args.skip_ieee_pass and not args.skip_copy_pass:
                 # the same pipeline with the CPU-reproducible map (every operation IEEE-rounded; vstab_config.map_precision = IEEE): the
                 # rate beside the default's, from a short run of its own in the untimed region
                 stab.close()
-                istab = vs.Stabilizer(clip, total=600 + 10 * args.batch + 100, preset=preset, smooth_radius=30, seed=1234 + rank,
+                istab = vs.Stabilizer(clip, total=1024 + (args.warmup + args.steps) * args.batch + 100, preset=preset, smooth_radius=30, seed=1234 + rank,
                                       tracking=0 if args.no_tracking else 1, ring_hold=ring_hold, **dict(extra, map_precision=vs.MAP_PRECISION_IEEE))
-                ipull = (lambda i: istab.pull_nv12_into(*outs[i % args.ring])) if nv12_out else (lambda i: istab.pull_into(outs[i % args.ring]))
-                for i in range(600):
-                    assert ipull(i)
-                torch.cuda.synchronize()
-                tc = time.perf_counter()
-                for i in range(10 * args.batch):
-                    assert ipull(i)
-                torch.cuda.synchronize()
-                ieee_map = {"value": round(10 * args.batch / (time.perf_counter() - tc), 1), "unit": "frames/s",
-                            "what": "the same pipeline with vstab_config.map_precision = IEEE (createMap.cl with every operation IEEE-rounded, reproducible by a "
-                                    f"CPU; not the reference's GPU arithmetic); {10 * args.batch} frames after a 600-frame pre-roll, untimed region"}
+                ieee_map = side_pass(torch, make_pull(istab), args,
+                                     "the same pipeline with vstab_config.map_precision = IEEE (createMap.cl with every operation IEEE-rounded, reproducible by a "
+                                     "CPU; not the reference's GPU arithmetic)")
                 istab.close()
         alg_bytes = w * h * 1.5 + cw * ch * 3  # NV12 read once + BGR8 written once
         if nv12_out:
             alg_bytes = w * h * 1.5 + cw * ch + 2 * ((cw + 1) // 2) * ((ch + 1) // 2)
-        kernel_name = "k_warp_fused"
+        kernel_name = "k_warp_planar<8, CREATEMAP_CL_OPENCL, DEPTH 8> (plane-wise: luma + chroma planes remapped as they are)" if planar else "k_warp_fused"
         if p010:
             alg_bytes = w * h * 3 + cw * ch * 6  # P010 read once + 16-bit BGR written once
             kernel_name = "k_warp_fused<8, RS_CREATEMAP_CL, BGR16, DEPTH 10, FP16> (the LDS-tiled kernel with a 10:10:10 LDS pixel)"
             if p010_out:
                 alg_bytes = w * h * 3 + cw * ch * 2 + 4 * ((cw + 1) // 2) * ((ch + 1) // 2)  # P010 read once + P010 planes written once
-                kernel_name = "k_warp_fused<8, RS_CREATEMAP_CL, P010, DEPTH 10, FP16> (P010 planes written by the warp kernel)"
+                kernel_name = ("k_warp_planar<8, RS_CREATEMAP_CL, DEPTH 10, FP16> (plane-wise)" if planar
+                               else "k_warp_fused<8, RS_CREATEMAP_CL, P010, DEPTH 10, FP16> (P010 planes written by the warp kernel)")
         base_bytes = alg_bytes  # of the kernel that evaluates the map (what "alone" runs)
         cached = mode == "pipeline" and args.no_tracking
         if cached:
@@ -736,7 +792,10 @@ def main():
         line = {
             "metric": "stabilized frames/sec at 4K NV12, 1/2/4/8 GPU; remap % HBM roofline",
             "value": round(world * n_timed / el, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 5), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 5),
+            "step_ms": {"median": round(float(np.median(step_ms)), 4), "min": round(min(step_ms), 4), "max": round(max(step_ms), 4),
+                        "what": "GPU-side duration of each timed step: events on the caller's stream at the step boundaries"} if step_ms else None,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": ("u10 pixels (fp16 blend)" if p010 else "u8 pixels") + " / f32 map / f64 rotations", "data": "synthetic",
             "config": {"workload": workload, "mode": mode, "clips": len(records), "ring_frames": args.ring, "frames_per_step": args.batch,
                        "frame_loop": ("vstab_pull_frames: one call per step" if batched else "vstab_pull_frame per frame from Python") if mode == "pipeline" else None,
@@ -744,6 +803,8 @@ def main():
             "rank_cpus_all": [f"{r.get('cpu_first', 0)}-{r.get('cpu_last', 0)} ({r.get('cpu_count', 0)})" for r in records] if world > 1 else None,
             "preroll": preroll, "parity_check": parity, "parity_check_against": parity_against if parity else None, "rank_cpus": pinned,
             "collectives": args.dist_backend if use_dist else None,
+            "host": dict(host_cost, all_ranks_cpu_seconds_per_1000_frames=[round(r.get("cpu_us", 0) / 1e6 / max(1, r["frames"]) * 1000, 4) for r in records]
+                         if world > 1 else None),
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
@@ -753,7 +814,7 @@ def main():
                          "timing": "kernel start/end stamps (hipExtLaunchKernelGGL) of every 8th launch in the timed region",
                          "committed_profile": committed,
                          "alone": None if alone_us is None else {"avg_launch_us": round(alone_us, 2),
-                                                                   "kernel": "k_warp_fused (DEPTH 10)" if p010 else "k_warp_fused",
+                                                                   "kernel": kernel_name.split(" (")[0],
                                                                    "achieved": round(base_bytes / alone_us / 1e3, 1),
                                                                    "frac": round(base_bytes / alone_us / 1e3 / HBM_PEAK_GBS, 4)}},
         }

@@ -11,7 +11,8 @@ import zlib
 
 import numpy as np
 
-RECORD_FIELDS = ("rank", "clip", "frames", "elapsed_ns", "crc", "cpu_first", "cpu_last", "cpu_count")  # the last three: the CPUs the rank ran on (0 if not given)
+# cpu_first / cpu_last / cpu_count: the CPUs the rank ran on; cpu_us: user + system time of the rank's process over its timed region (0 if not given)
+RECORD_FIELDS = ("rank", "clip", "frames", "elapsed_ns", "crc", "cpu_first", "cpu_last", "cpu_count", "cpu_us")
 
 
 def assign_clips(n_clips, world_size):
