@@ -143,7 +143,8 @@ __device__ __forceinline__ bool warp_tile(const FusedArgs &ta, uint32_t *smem, c
     int qxb[RW], qyb[RW];  // quantised coordinates + QB
     {
         int unused_cx[RW / 2], unused_cy[RW / 2];
-        map_phase<RW, MODE, CACHED, false>(ta, x, y0, wave, lane, rfx, rfy, qxb, qyb, unused_cx, unused_cy);
+        const float unused_qm[4] = {QMAGIC, QMAGIC, QMAGIC, QMAGIC};
+        map_phase<RW, MODE, CACHED, false>(ta, x, y0, wave, lane, rfx, rfy, qxb, qyb, unused_cx, unused_cy, unused_qm);
     }
 #pragma unroll
     for (int j = 0; j < RW; j++) asm volatile("" : "+v"(qxb[j]), "+v"(qyb[j]) : : "memory");

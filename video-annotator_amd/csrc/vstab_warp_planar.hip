@@ -82,6 +82,15 @@ __device__ __forceinline__ int lerp_rows(uint32_t h0, uint32_t h1, uint32_t fy) 
     return (int)((base + (uint32_t)__mul24((int)(h1 - h0), (int)fy)) >> 10);
 }
 
+// The 8-bit blend with its result left at bits 16..23: 64 * ((h0 (32 - fy) + h1 fy + 512)) = dot2((4 h0, 4 h1), (16 (32 - fy), 16 fy)) + 32768
+// where 4 h = dot4(taps of a row, (4 (32 - fx), 4 fx)) (<= 32640: a 16-bit field); every factor 4 / 16 is a shift, so the byte is the
+// integer cv::remap computes.  wx4 = the horizontal weights at the bytes of the two taps.
+__device__ __forceinline__ uint32_t blend8_scaled(uint32_t t_top, uint32_t t_bot, uint32_t wx4, uint32_t fy) {
+    const uint32_t h0 = __builtin_amdgcn_udot4(t_top, wx4, 0u, false), h1 = __builtin_amdgcn_udot4(t_bot, wx4, 0u, false);
+    const uint32_t wy16 = fy * 1048560u + 512u;  // 16 (32 - fy) | 16 fy << 16
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, h0 | (h1 << 16)), __builtin_bit_cast(u16x2, wy16), 32768u, false);
+}
+
 // NB bytes of this lane from the wave's transposition scratch to global memory (NB = 1, 2, 4, 8, 16)
 // (the scratch is written as samples and read as vectors: may_alias types, so that the reads stay behind the writes)
 typedef uint16_t __attribute__((may_alias)) u16_alias;
@@ -118,7 +127,8 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float rfx = rcp_refined(a.p.ofx), rfy = rcp_refined(a.p.ofy);
 
-    // ---- probe (wave 0; the other waves wait at the barrier) ------------------------------------------------------------
+    // ---- probe (wave 0; the other waves wait at the barrier.  Taking the probing wave in turn by workgroup -- in case the waves of
+    // a workgroup always landed on the same SIMDs -- changes nothing: 26.2 against 26.3 us at 4K) -------------------------------------
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);
         probe_tile<TH, STAGE_MAX, MODE, false, true, BW>(ta, x0, y0, lane, rfx, rfy, smem);
@@ -172,6 +182,9 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
                     fill = ok && !in, ok = ok && in;
                 }
                 uint8_t *const ldst = tile + (luma ? 0 : luma_bytes) + k * pw;  // uniform; the lanes' chunks follow each other from here
+#ifdef VSTAB_DEV
+                if (ta.ablate & 16) ok = false;  // timing only: nothing is staged
+#endif
                 if (ok) {
                     const uint32_t off = (uint32_t)srow * (luma ? pitch_y : pitch_uv) + (luma ? lane_y : lane_c);  // modulo 2^32: a negative srow is made up for by r0
                     __builtin_amdgcn_global_load_lds((luma ? a.y : a.uv) + (size_t)off, (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
@@ -227,9 +240,13 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
         }
     }
 
-    // ---- map: RW exact evaluations per thread, and the chroma positions of the even rows (vstab_warp_tile.hpp) ---------
+    // ---- map: RW exact evaluations per thread, and the chroma positions of the even rows (vstab_warp_tile.hpp).  The rounding constants
+    // carry the origin of the staged box (FOLD): the registers hold positions RELATIVE to the box, in 1/32 pixel -------------------------
     int qxb[RW], qyb[RW], qcx[RW / 2], qcy[RW / 2];
-    map_phase<RW, MODE, false, true>(ta, x, y0, wave, lane, rfx, rfy, qxb, qyb, qcx, qcy);
+    {
+        const float qm[4] = {QMAGIC - (float)(32 * bx0), QMAGIC - (float)(32 * by0), QMAGIC - (float)(32 * (bx0 >> 1)), QMAGIC - (float)(32 * (by0 >> 1))};
+        map_phase<RW, MODE, false, true, true>(ta, x, y0, wave, lane, rfx, rfy, qxb, qyb, qcx, qcy, qm);
+    }
 #pragma unroll
     for (int j = 0; j < RW; j++) asm volatile("" : "+v"(qxb[j]), "+v"(qyb[j]) : : "memory");
 #pragma unroll
@@ -259,41 +276,44 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
     }
     __syncthreads();
 
-    // ---- sample + blend: luma ------------------------------------------------------------------------------------------
+    // ---- sample + blend: luma.  Results leave this block SCALED: out[j] = 64 * (value of the blend) + 32768 for 8-bit samples (the byte is
+    // bits 16..23: ds_write_b8_d16_hi stores it without a shift), the sample value itself for 16-bit samples ---------------------------
     const bool col_live = x < a.dw;
-    const uint32_t tile_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)tile;
+    constexpr int OSH = DEPTH == 10 ? 0 : 16;   // where the result sits in out[] / cu[] / cv[]
     int out[RW];
     {
-        // every footprint of the wave inside the staged box?  in the registers' representation: QB + 32 * bx0 <= q < QB + 32 * (bx0 + wb - 1)
+        // every footprint of the wave inside the staged box?  relative positions: 0 <= X and X + 1 <= wb - 1, i.e. QB <= q < QB + 32 * (wb - 1)
         int mnx = qxb[0], mxx = qxb[0], mny = qyb[0], mxy = qyb[0];
 #pragma unroll
         for (int j = 1; j < RW; j++) mnx = min(mnx, qxb[j]), mxx = max(mxx, qxb[j]), mny = min(mny, qyb[j]), mxy = max(mxy, qyb[j]);
-        const int lox = QB + 32 * bx0, hix = QB + 32 * (bx0 + wb - 1), loy = QB + 32 * by0, hiy = QB + 32 * (by0 + hb - 1);
-        const bool outside_box = !use_lds || mnx < lox || mxx >= hix || mny < loy || mxy >= hiy;
+        const int hix = QB + 32 * (wb - 1), hiy = QB + 32 * (hb - 1);
+        const bool outside_box = !use_lds || mnx < QB || mxx >= hix || mny < QB || mxy >= hiy;
+#ifdef VSTAB_DEV
+        if (ta.ablate & 2) {  // timing only: no taps, no blend
+#pragma unroll
+            for (int j = 0; j < RW; j++) out[j] = qxb[j] ^ qyb[j];
+        } else
+#endif
         if (!__builtin_amdgcn_ballot_w64(outside_box)) {
-            // tap address = tile + (Y - by0) * pw + (X - bx0) * BPS with X = (q >> 5) - (QB >> 5): the constants are ONE register
-            // (K), and v_mad_u32_u24 keeps the low 24 bits of q >> 5 = (QB >> 5) + Y, of which (QB >> 5) & 0xffffff is in K too
-            constexpr uint32_t QH = (uint32_t)QB >> 5, QH24 = QH & 0xffffffu;
-            uint32_t K = tile_lds - (QH24 + (uint32_t)by0) * (uint32_t)pw - (QH + (uint32_t)bx0) * (uint32_t)BPS;
-            uint32_t Kv = K;
-            asm("" : "+v"(Kv));  // (a VGPR: the multiply-add below already has one scalar operand, the pitch)
+            // tap address = tile + Y * pw + X * BPS with X = bits 5..21 of q (QB has none of them set, and X < 2^17): two bit-field
+            // extracts and one multiply-add; the tile's LDS address is a link-time constant and rides in the reads' offset field
             constexpr int TG = RW < 4 ? RW : 4;  // rows whose tap reads are issued before the first blend
 #pragma unroll
             for (int j0 = 0; j0 < RW; j0 += TG) {
                 uint32_t t0[TG], t1[TG];
 #pragma unroll
                 for (int j = 0; j < TG; j++) {
-                    const uint32_t xa = (uint32_t)(qxb[j0 + j] >> 5), ya = (uint32_t)(qyb[j0 + j] >> 5);
+                    const uint32_t xr = __builtin_amdgcn_ubfe((uint32_t)qxb[j0 + j], 5, 17), yr = __builtin_amdgcn_ubfe((uint32_t)qyb[j0 + j], 5, 17);
                     uint32_t ad;
-                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ad) : "v"(ya), "s"(pw), "v"(Kv));
                     // t = (tap X) | (tap X + 1) << 16 of the upper and of the lower row
                     if constexpr (DEPTH == 10) {
-                        ad += xa << 1;
-                        const LdsU16 *u = reinterpret_cast<const LdsU16 *>(ad), *l = reinterpret_cast<const LdsU16 *>(ad + (uint32_t)pw);
+                        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ad) : "v"(yr), "s"(pw), "v"(xr << 1));
+                        const LdsU16 *u = reinterpret_cast<const LdsU16 *>((__attribute__((address_space(3))) uint8_t *)tile + ad);
+                        const LdsU16 *l = reinterpret_cast<const LdsU16 *>((__attribute__((address_space(3))) uint8_t *)tile + (ad + (uint32_t)pw));
                         t0[j] = (uint32_t)u[0] | ((uint32_t)u[1] << 16), t1[j] = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
                     } else {
-                        ad += xa;
-                        const LdsU8 *u = reinterpret_cast<const LdsU8 *>(ad), *l = reinterpret_cast<const LdsU8 *>(ad + (uint32_t)pw);
+                        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ad) : "v"(yr), "s"(pw), "v"(xr));
+                        const LdsU8 *u = (__attribute__((address_space(3))) uint8_t *)tile + ad, *l = (__attribute__((address_space(3))) uint8_t *)tile + (ad + (uint32_t)pw);
                         t0[j] = (uint32_t)u[0] | ((uint32_t)u[1] << 16), t1[j] = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
                     }
                 }
@@ -302,17 +322,13 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
                     const uint32_t fx = (uint32_t)qxb[j0 + j] & 31u, fy = (uint32_t)qyb[j0 + j] & 31u;
                     if constexpr (DEPTH == 10 && BLEND == VSTAB_BLEND_FP16) {
                         out[j0 + j] = blend4<DEPTH, BLEND>((int)(t0[j] & 0xffffu), (int)(t0[j] >> 16), (int)(t1[j] & 0xffffu), (int)(t1[j] >> 16), (int)fx, (int)fy);
-                    } else {
-                        uint32_t h0, h1;
-                        const uint32_t wx = fx * 65535u + 32u;  // (32 - fx) | fx << 16: against the 16-bit fields, or against bytes 0 and 2
-                        if constexpr (DEPTH == 10) {
-                            h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, t0[j]), __builtin_bit_cast(u16x2, wx), 0u, false);
-                            h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, t1[j]), __builtin_bit_cast(u16x2, wx), 0u, false);
-                        } else {
-                            h0 = __builtin_amdgcn_udot4(t0[j], wx, 0u, false);
-                            h1 = __builtin_amdgcn_udot4(t1[j], wx, 0u, false);
-                        }
+                    } else if constexpr (DEPTH == 10) {
+                        const uint32_t wx = fx * 65535u + 32u;  // (32 - fx) | fx << 16
+                        const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, t0[j]), __builtin_bit_cast(u16x2, wx), 0u, false);
+                        const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, t1[j]), __builtin_bit_cast(u16x2, wx), 0u, false);
                         out[j0 + j] = lerp_rows(h0, h1, fy);
+                    } else {
+                        out[j0 + j] = (int)blend8_scaled(t0[j], t1[j], fx * 262140u + 128u, fy);  // 4 (32 - fx) at byte 0, 4 fx at byte 2
                     }
                 }
             }
@@ -323,7 +339,7 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
                 int sx = qxb[0], sy = qyb[0];
 #pragma unroll
                 for (int k = 1; k < RW; k++) sx = j == k ? qxb[k] : sx, sy = j == k ? qyb[k] : sy;
-                const int v = gather_sample<DEPTH, BLEND>(a.y, a.pitch_y, a.sw, a.sh, 1, 0, sx - QB, sy - QB, P::BLACK_Y);
+                const int v = gather_sample<DEPTH, BLEND>(a.y, a.pitch_y, a.sw, a.sh, 1, 0, sx - QB + 32 * bx0, sy - QB + 32 * by0, P::BLACK_Y) << OSH;
 #pragma unroll
                 for (int k = 0; k < RW; k++) out[k] = j == k ? v : out[k];
             }
@@ -346,33 +362,34 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
 #pragma unroll
         for (int s = 1; s < NS; s++) mnx = min(mnx, ccx[s]), mxx = max(mxx, ccx[s]), mny = min(mny, ccy[s]), mxy = max(mxy, ccy[s]);
         const int cbx0 = bx0 >> 1, cby0 = by0 >> 1, cwb = wb >> 1, chb = hb >> 1;  // the chroma box, in chroma pixels (bx0, by0 even, also when negative)
-        const int lox = QB + 32 * cbx0, hix = QB + 32 * (cbx0 + cwb - 1), loy = QB + 32 * cby0, hiy = QB + 32 * (cby0 + chb - 1);
-        const bool outside_box = !use_lds || mnx < lox || mxx >= hix || mny < loy || mxy >= hiy;
+        const int hix = QB + 32 * (cwb - 1), hiy = QB + 32 * (chb - 1);
+        const bool outside_box = !use_lds || mnx < QB || mxx >= hix || mny < QB || mxy >= hiy;
+#ifdef VSTAB_DEV
+        if (ta.ablate & 4) {  // timing only: no chroma taps, no blend
+#pragma unroll
+            for (int s = 0; s < NS; s++) cu[s] = ccx[s], cv[s] = ccy[s];
+        } else
+#endif
         if (!__builtin_amdgcn_ballot_w64(outside_box)) {
-            constexpr uint32_t QH = (uint32_t)QB >> 5, QH24 = QH & 0xffffffu;
             constexpr uint32_t CPX = 2 * BPS;  // bytes of a chroma pair
-            uint32_t Kv = tile_lds + (uint32_t)luma_bytes - (QH24 + (uint32_t)cby0) * (uint32_t)pw - (QH + (uint32_t)cbx0) * CPX;
-            asm("" : "+v"(Kv));
+            const __attribute__((address_space(3))) uint8_t *const ctile = (__attribute__((address_space(3))) uint8_t *)tile + luma_bytes;
 #pragma unroll
             for (int s = 0; s < NS; s++) {
-                const uint32_t xa = (uint32_t)(ccx[s] >> 5), ya = (uint32_t)(ccy[s] >> 5);
+                const uint32_t xr = __builtin_amdgcn_ubfe((uint32_t)ccx[s], 5, 17), yr = __builtin_amdgcn_ubfe((uint32_t)ccy[s], 5, 17);
                 const uint32_t fx = (uint32_t)ccx[s] & 31u, fy = (uint32_t)ccy[s] & 31u;
                 uint32_t ad;
-                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ad) : "v"(ya), "s"(pw), "v"(Kv));
-                ad += xa * CPX;
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ad) : "v"(yr), "s"(pw), "v"(xr * CPX));
                 if constexpr (DEPTH == 10) {
                     // (U0 | V0 << 16, U1 | V1 << 16) of both rows
-                    const LdsU32 *pt = reinterpret_cast<const LdsU32 *>(ad), *pb = reinterpret_cast<const LdsU32 *>(ad + (uint32_t)pw);
+                    const LdsU32 *pt = reinterpret_cast<const LdsU32 *>(ctile + ad), *pb = reinterpret_cast<const LdsU32 *>(ctile + (ad + (uint32_t)pw));
                     const uint32_t a0 = pt[0], a1 = pt[1], b0 = pb[0], b1 = pb[1];
                     cu[s] = blend4<DEPTH, BLEND>((int)(a0 & 0xffffu), (int)(a1 & 0xffffu), (int)(b0 & 0xffffu), (int)(b1 & 0xffffu), (int)fx, (int)fy);
                     cv[s] = blend4<DEPTH, BLEND>((int)(a0 >> 16), (int)(a1 >> 16), (int)(b0 >> 16), (int)(b1 >> 16), (int)fx, (int)fy);
                 } else {
-                    const LdsU16 *pt = reinterpret_cast<const LdsU16 *>(ad), *pb = reinterpret_cast<const LdsU16 *>(ad + (uint32_t)pw);
+                    const LdsU16 *pt = reinterpret_cast<const LdsU16 *>(ctile + ad), *pb = reinterpret_cast<const LdsU16 *>(ctile + (ad + (uint32_t)pw));
                     const uint32_t tt = (uint32_t)pt[0] | ((uint32_t)pt[1] << 16), tb = (uint32_t)pb[0] | ((uint32_t)pb[1] << 16);  // bytes U0 V0 U1 V1
-                    const uint32_t wu = fx * 65535u + 32u, wv = wu << 8;  // (32 - fx) at byte 0 / 1, fx at byte 2 / 3
-                    const uint32_t hu0 = __builtin_amdgcn_udot4(tt, wu, 0u, false), hu1 = __builtin_amdgcn_udot4(tb, wu, 0u, false);
-                    const uint32_t hv0 = __builtin_amdgcn_udot4(tt, wv, 0u, false), hv1 = __builtin_amdgcn_udot4(tb, wv, 0u, false);
-                    cu[s] = lerp_rows(hu0, hu1, fy), cv[s] = lerp_rows(hv0, hv1, fy);
+                    const uint32_t wu = fx * 262140u + 128u;  // 4 (32 - fx) at byte 0, 4 fx at byte 2: against U; << 8: against V
+                    cu[s] = (int)blend8_scaled(tt, tb, wu, fy), cv[s] = (int)blend8_scaled(tt, tb, wu << 8, fy);
                 }
             }
         } else {
@@ -381,8 +398,8 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
                 int sx = ccx[0], sy = ccy[0];
 #pragma unroll
                 for (int k = 1; k < NS; k++) sx = s == k ? ccx[k] : sx, sy = s == k ? ccy[k] : sy;
-                const int u = gather_sample<DEPTH, BLEND>(a.uv, a.pitch_uv, a.sw >> 1, a.sh >> 1, 2, 0, sx - QB, sy - QB, P::BLACK_C);
-                const int v = gather_sample<DEPTH, BLEND>(a.uv, a.pitch_uv, a.sw >> 1, a.sh >> 1, 2, 1, sx - QB, sy - QB, P::BLACK_C);
+                const int u = gather_sample<DEPTH, BLEND>(a.uv, a.pitch_uv, a.sw >> 1, a.sh >> 1, 2, 0, sx - QB + 32 * cbx0, sy - QB + 32 * cby0, P::BLACK_C) << OSH;
+                const int v = gather_sample<DEPTH, BLEND>(a.uv, a.pitch_uv, a.sw >> 1, a.sh >> 1, 2, 1, sx - QB + 32 * cbx0, sy - QB + 32 * cby0, P::BLACK_C) << OSH;
 #pragma unroll
                 for (int k = 0; k < NS; k++) cu[k] = s == k ? u : cu[k], cv[k] = s == k ? v : cv[k];
             }
@@ -390,6 +407,17 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
     }
 
     // ---- store: through the wave's scratch, so that a lane stores contiguous bytes of ONE row ------------------------------
+#ifdef VSTAB_DEV
+    if (ta.ablate & 8) {  // timing only: no stores
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < RW; j++) acc ^= out[j];
+#pragma unroll
+        for (int s = 0; s < NS; s++) acc ^= cu[s] ^ cv[s];
+        if (acc == 0x12345678) a.dst[0] = 1;
+        return true;
+    }
+#endif
     const int yw = y0 + wave * RW;                      // first luma row of this wave (even)
     const int ncols = min(64, a.dw - x0);               // > 0
     constexpr int SH = DEPTH == 10 ? 6 : 0;             // P010 words carry the value at the top
@@ -401,14 +429,14 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
 #pragma unroll
             for (int j = 0; j < RW; j++) {
                 if constexpr (DEPTH == 10) *reinterpret_cast<u16_alias *>(w + j * 128) = (uint16_t)(out[j] << SH);
-                else w[j * 64] = (uint8_t)out[j];
+                else w[j * 64] = (uint8_t)((uint32_t)out[j] >> 16);  // (ds_write_b8_d16_hi)
             }
             uint8_t *wc = scr_c + (lane & 1) * 64 * BPS + (lane >> 1) * 2 * BPS;  // chroma row (lane & 1) + 2 s, pair lane >> 1
             if (CR > 1 || !(lane & 1)) {
 #pragma unroll
                 for (int s = 0; s < NS; s++) {
                     if constexpr (DEPTH == 10) *reinterpret_cast<u32_alias *>(wc + s * 256) = (uint32_t)(cu[s] << SH) | ((uint32_t)(cv[s] << SH) << 16);
-                    else *reinterpret_cast<u16_alias *>(wc + s * 128) = (uint16_t)(cu[s] | (cv[s] << 8));
+                    else *reinterpret_cast<u16_alias *>(wc + s * 128) = (uint16_t)__builtin_amdgcn_perm((uint32_t)cv[s], (uint32_t)cu[s], 0x0c0c0602u);  // U | V << 8 from bits 16..23
                 }
             }
         }
@@ -431,7 +459,7 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
             if (col_live && y < a.dh) {
                 uint8_t *o = a.dst + ((size_t)(uint32_t)y * a.pitch_dst + (uint32_t)x * BPS);
                 if constexpr (DEPTH == 10) o[0] = (uint8_t)((out[j] << SH) & 255), o[1] = (uint8_t)((out[j] << SH) >> 8);
-                else o[0] = (uint8_t)out[j];
+                else o[0] = (uint8_t)((uint32_t)out[j] >> 16);
             }
         }
         const int xc = x0 + (lane & ~1);  // the luma column this lane's chroma pairs belong to
@@ -442,7 +470,7 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
                 uint8_t *o = a.dst_uv + ((size_t)(uint32_t)(y >> 1) * a.pitch_dst_uv + (uint32_t)xc * BPS);
                 const uint32_t u = (uint32_t)cu[s] << SH, v = (uint32_t)cv[s] << SH;
                 if constexpr (DEPTH == 10) o[0] = u & 255, o[1] = u >> 8, o[2] = v & 255, o[3] = v >> 8;
-                else o[0] = (uint8_t)u, o[1] = (uint8_t)v;
+                else o[0] = (uint8_t)(u >> 16), o[1] = (uint8_t)(v >> 16);
             }
         }
     }
@@ -488,17 +516,27 @@ vstab_status launch_warp_planar(const WarpArgs &a, const float params[17], int m
     ta.rs_den = (float)(a.dh > 1 ? a.dh - 1 : 1);
     if (rot_bottom) map_mode = map_mode == VSTAB_MAP_CREATEMAP_CL_OPENCL ? (int)MAP_RS_CREATEMAP_CL_OPENCL : map_mode + (int)MAP_RS_CREATEMAP_CL;
 #ifdef VSTAB_DEV
-    ta.timing = nullptr, ta.ablate = 0, ta.lds_pad = 0;
+    ta.timing = nullptr, ta.lds_pad = 0;
+    ta.ablate = getenv("VSTAB_ABLATE") ? atoi(getenv("VSTAB_ABLATE")) : 0;
 #endif
     // 64 x 32 tiles; LDS per workgroup: header + scratch + 1.5 bytes (3 at 10 bits) per pixel of the box.  24 KB (8-bit) lets six
     // workgroups share a CU -- as many as the register budget admits -- and holds the largest boxes of a 4K fisheye frame.
     const int bps = depth == 10 ? 2 : 1;
     const long tiles32 = (long)div_up(a.dw, 64) * div_up(a.dh, 32);
-    const int rwb = tiles32 < 1536 ? 4 : 8;
+    int rwb = tiles32 < 1536 ? 4 : 8;
+#ifdef VSTAB_DEV
+    if (const char *e = getenv("VSTAB_PLANAR_RWB")) rwb = atoi(e) == 4 ? 4 : 8;
+#endif
     int lds_kb = (rwb == 8 ? 24 : 14) * bps;
-    double tail_rounds = (double)div_up(a.dw, 64) * div_up(a.dh, 4 * rwb) > 256.0 * std::min(6, 160 / lds_kb) ? 0.5 : 0.0;
+    // workgroups a CU holds: by LDS, and by registers (the 64 x 32-tile kernels take up to 72: seven waves per SIMD; the others eight)
+    const int resident = std::min({160 / lds_kb, rwb == 8 ? 7 : 8, 8});
+    double tail_rounds = (double)div_up(a.dw, 64) * div_up(a.dh, 4 * rwb) > 256.0 * resident ? 0.25 : 0.0;
+    // (measured at 4K: 0 / 0.25 / 0.5 / 1 rounds of half-height tiles at the end: 28.1 / 26.3 / 27.1 / 28.0 us; 20 to 28 KB of LDS: the same;
+    //  1080p, everything resident at once: 64 x 16 tiles and no half-height tiles 11.3 us, 64 x 32 tiles 13.0: profiles/r05_planar_warp.txt)
+#ifdef VSTAB_DEV
     if (const char *e = getenv("VSTAB_PLANAR_LDS_KB")) lds_kb = atoi(e);
     if (const char *e = getenv("VSTAB_PLANAR_TAIL")) tail_rounds = atof(e);
+#endif
     const dim3 grid(tile_schedule(ta, rwb, lds_kb, tail_rounds));
     const size_t lds_bytes = (size_t)lds_kb * 1024;
     ta.lds_capacity_px = (int)((lds_bytes - 32 - 4 * 768 * (size_t)bps) * 2 / (3 * (size_t)bps));

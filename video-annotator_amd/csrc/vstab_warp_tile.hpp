@@ -293,13 +293,17 @@ __device__ __forceinline__ void map_pairs_ocl(float icx32, float icy32, float if
 // CHROMA (plane-wise warp): also the quantised position in the chroma plane for the EVEN rows of the thread, meaningful in lanes
 // with an even column: qcx / qcy = the bits of (32 * (map / 2) + QMAGIC) -- the halving is exact, the rounding is cv::remap's again.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void chroma_quantise(float ax32, float ay32, int &qcx, int &qcy) {
-    qcx = __float_as_int(ax32 * 0.5f + QMAGIC), qcy = __float_as_int(ay32 * 0.5f + QMAGIC);
+// FOLD (plane-wise warp): the rounding constants carry the origin of the staged box -- (32 * map - 32 * origin) + QMAGIC rounds to the
+// same integer minus 32 * origin, which is an integer -- so the registers hold box-relative positions and a tap address is two bit-field
+// extracts and a multiply-add.  qm = {QMAGIC - 32 * bx0, QMAGIC - 32 * by0, QMAGIC - 32 * (bx0 / 2), QMAGIC - 32 * (by0 / 2)}.
+__device__ __forceinline__ void chroma_quantise(float ax32, float ay32, float mx, float my, int &qcx, int &qcy) {
+    qcx = __float_as_int(ax32 * 0.5f + mx), qcy = __float_as_int(ay32 * 0.5f + my);
 }
-template <int RW, int MODE, bool CACHED, bool CHROMA>
+template <int RW, int MODE, bool CACHED, bool CHROMA, bool FOLD = false>
 __device__ __forceinline__ void map_phase(const FusedArgs &ta, const int x, const int y0, const int wave, const int lane, const float rfx, const float rfy,
-                                          int (&qxb)[RW], int (&qyb)[RW], int (&qcx)[RW / 2], int (&qcy)[RW / 2]) {
+                                          int (&qxb)[RW], int (&qyb)[RW], int (&qcx)[RW / 2], int (&qcy)[RW / 2], const float (&qm)[4]) {
     static_assert(!(CACHED && CHROMA), "the quantised map holds no chroma positions");
+    const float QMX = FOLD ? qm[0] : QMAGIC, QMY = FOLD ? qm[1] : QMAGIC, QCX = FOLD ? qm[2] : QMAGIC, QCY = FOLD ? qm[3] : QMAGIC;
     constexpr bool RS = map_mode_is_rs(MODE);
     constexpr int BASE = map_mode_base(MODE);
     const WarpArgs &a = ta.w;
@@ -316,7 +320,7 @@ __device__ __forceinline__ void map_phase(const FusedArgs &ta, const int x, cons
 #pragma unroll
         for (int j = 0; j < RW; j++) {
             const float fx = (float)x * (32.0f * (float)a.sw / (float)a.dw), fy = (float)(y0 + wave * RW + j) * (32.0f * (float)a.sh / (float)a.dh);
-            qxb[j] = __float_as_int(fx + QMAGIC), qyb[j] = __float_as_int(fy + QMAGIC);
+            qxb[j] = __float_as_int(fx + QMX), qyb[j] = __float_as_int(fy + QMY);
         }
     } else
 #endif
@@ -365,8 +369,8 @@ __device__ __forceinline__ void map_phase(const FusedArgs &ta, const int x, cons
 #pragma unroll
                 for (int c = 0; c < NP; c++) {
                     const int j = 2 * (g0 + c);
-                    if constexpr (CHROMA) chroma_quantise(ax[c].x, ay[c].x, qcx[g0 + c], qcy[g0 + c]);
-                    ax[c] += splat2(QMAGIC), ay[c] += splat2(QMAGIC);
+                    if constexpr (CHROMA) chroma_quantise(ax[c].x, ay[c].x, QCX, QCY, qcx[g0 + c], qcy[g0 + c]);
+                    ax[c] += splat2(QMX), ay[c] += splat2(QMY);
                     qxb[j] = __float_as_int(ax[c].x), qxb[j + 1] = __float_as_int(ax[c].y);
                     qyb[j] = __float_as_int(ay[c].x), qyb[j + 1] = __float_as_int(ay[c].y);
                 }
@@ -395,8 +399,8 @@ __device__ __forceinline__ void map_phase(const FusedArgs &ta, const int x, cons
 #pragma unroll
                 for (int c = 0; c < NP; c++) {
                     const int j = 2 * (g0 + c);
-                    if constexpr (CHROMA) chroma_quantise(ax[c].x, ay[c].x, qcx[g0 + c], qcy[g0 + c]);
-                    ax[c] += splat2(QMAGIC), ay[c] += splat2(QMAGIC);
+                    if constexpr (CHROMA) chroma_quantise(ax[c].x, ay[c].x, QCX, QCY, qcx[g0 + c], qcy[g0 + c]);
+                    ax[c] += splat2(QMX), ay[c] += splat2(QMY);
                     qxb[j] = __float_as_int(ax[c].x), qxb[j + 1] = __float_as_int(ax[c].y);
                     qyb[j] = __float_as_int(ay[c].x), qyb[j + 1] = __float_as_int(ay[c].y);
                 }
@@ -413,12 +417,12 @@ __device__ __forceinline__ void map_phase(const FusedArgs &ta, const int x, cons
                     } else {
                         map_pixel_ocl_literal(icx32, icy32, ifx32, ify32, a.p.r, ct.a0, ct.a1, ct.a2, bcast(vy_l, j), fx, fy);
                     }
-                    const int ix = __float_as_int(fx + QMAGIC), iy = __float_as_int(fy + QMAGIC);
+                    const int ix = __float_as_int(fx + QMX), iy = __float_as_int(fy + QMY);
 #pragma unroll
                     for (int k = 0; k < RW; k++) qxb[k] = j == k ? ix : qxb[k], qyb[k] = j == k ? iy : qyb[k];
                     if constexpr (CHROMA) {
                         int cx, cy;
-                        chroma_quantise(fx, fy, cx, cy);
+                        chroma_quantise(fx, fy, QCX, QCY, cx, cy);
 #pragma unroll
                         for (int k = 0; k < RW / 2; k++) qcx[k] = j == 2 * k ? cx : qcx[k], qcy[k] = j == 2 * k ? cy : qcy[k];
                     }
@@ -431,9 +435,9 @@ __device__ __forceinline__ void map_phase(const FusedArgs &ta, const int x, cons
                 const RowTerm rt = {bcast(b0_l, j), bcast(b1_l, j), bcast(b2_l, j)};
                 float fx, fy;
                 map_pixel_ex<BASE>(ta.p32, a.p, ct, rt, vx, vy, fx, fy);
-                qxb[j] = __float_as_int(fx + QMAGIC), qyb[j] = __float_as_int(fy + QMAGIC);
+                qxb[j] = __float_as_int(fx + QMX), qyb[j] = __float_as_int(fy + QMY);
                 if constexpr (CHROMA) {
-                    if (!(j & 1)) chroma_quantise(fx, fy, qcx[j / 2], qcy[j / 2]);
+                    if (!(j & 1)) chroma_quantise(fx, fy, QCX, QCY, qcx[j / 2], qcy[j / 2]);
                 }
             }
         }
