@@ -60,8 +60,11 @@ VSTAB_API int vstab_struct_size(int which);
  * (vstab_config.abi_version, written by vstab_config_default) and vstab_create refuses any other value -- so a vstab_config MUST be
  * initialised with vstab_config_default() and then modified, never zero-filled or assembled by hand.  vstab_frame is always
  * allocated and zeroed by the library before a source callback fills it in.  Version 4: abi_version, vstab_frame.dmabuf_modifier;
- * map_precision defaults to VSTAB_MAP_PRECISION_OPENCL. */
-#define VSTAB_ABI_VERSION 4
+ * map_precision defaults to VSTAB_MAP_PRECISION_OPENCL.  Version 5: vstab_config.read_ahead, two more counters in vstab_profile.
+ * The value is "VSB" + the version in the low byte: no field an older layout had at this offset (a preset 0..5) can hold it, so a
+ * struct filled in against an older header is refused whatever its contents -- and with it every later call that would write a
+ * larger vstab_profile into that caller's smaller one, since no handle is ever created for it. */
+#define VSTAB_ABI_VERSION 0x56534205
 VSTAB_API int vstab_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -462,6 +465,11 @@ typedef struct vstab_config {
                             the narrowed luma exactly as in the 8-bit path, the frame is warped from the 16-bit planes with
                             vstab_warp_p010 and emitted by vstab_pull_frame_bgr16. */
     int blend;           /* pixel_depth 10: VSTAB_BLEND_EXACT (default) or VSTAB_BLEND_FP16 */
+    int read_ahead;      /* frames the library pulls from upstream AHEAD of the frame it returns, beyond smooth_radius: 0 = the default
+                            (12), else 1 .. 16.  The read-ahead is what lets copy, pyramid, corner detection and tracking overlap the
+                            host's work; every output is identical for any value.  A live source sees a latency of
+                            smooth_radius + read_ahead + 2 frames (the reference: smooth_radius) -- a capture pipeline that cares
+                            lowers it (1: 30 + 3 frames at the reference's radius) and pays in frames/s. */
     int map_precision;   /* lens_mode 0: VSTAB_MAP_PRECISION_OPENCL (default; VSTAB_MAP_CREATEMAP_CL_OPENCL: the arithmetic the reference's
                             own kernel -- createMap.cl through ROCm's OpenCL compiler -- has on this GPU, bit-identical to it) or
                             VSTAB_MAP_PRECISION_IEEE (createMap.cl with every operation IEEE-rounded: reproducible by a CPU, a few
@@ -485,7 +493,8 @@ VSTAB_API vstab_status vstab_get_output_info(const vstab_handle *h, int *width, 
  * dst is complete once vstab_config.stream is synchronised.  Upstream frames handed to the callbacks
  * must already be complete in memory when the callback returns (they are read on an internal stream).
  * Read-ahead: to overlap copy, pyramid, corner detection and tracking with the host work, the library pulls
- * upstream up to fourteen frames earlier than the reference's loop would (same frames, same order, same outputs). */
+ * upstream up to vstab_config.read_ahead + 2 (by default fourteen) frames earlier than the reference's loop would (same frames,
+ * same order, same outputs). */
 VSTAB_API vstab_status vstab_pull_frame(vstab_handle *h, void *dst_bgr, size_t pitch_dst);
 /* The consumer's loop (DisplayImage.cpp:60-70: `while (true) { frame = source.pull_frame(); ... }`) as one call: n consecutive
  * vstab_pull_frame calls, frame i into dst[(first + i) % n_dst] with pitch[(first + i) % n_dst] -- an encoder's ring of output
@@ -550,6 +559,8 @@ typedef struct vstab_profile {
     long warp_timed;     /* warp launches that gpu_warp_ms sums over (level 1 samples every 8th) */
     long dmabuf_imports, dmabuf_evictions, dmabuf_cached; /* VSTAB_MEM_DMABUF: objects imported so far, unmapped again (least recently
                             used, once more than 256 are cached and none of the window's frames can still refer to them), mapped now */
+    long corner_selections_by_caller, corner_selections_by_helper; /* speculative corner detections (planned key frames) whose corners were
+                            selected by the calling thread itself because the helper thread had not woken up / by the helper thread */
 } vstab_profile;
 /* level 0 = off, 1 = time every 8th warp launch only (event records are expensive host calls), 2 = every GPU stage */
 VSTAB_API vstab_status vstab_enable_profiling(vstab_handle *h, int level);

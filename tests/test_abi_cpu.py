@@ -122,14 +122,17 @@ def test_abi_version_gates_vstab_create(vs):
     zero-filled or assembled against another header (before anything touches the device), and the header, the library and
     the binding agree on the number."""
     text = open(os.path.join(ROOT, "include", "vstab.h")).read()
-    assert int(re.search(r"#define VSTAB_ABI_VERSION (\d+)", text).group(1)) == vs.lib.vstab_abi_version() == vs.ABI_VERSION
+    ver = int(re.search(r"#define VSTAB_ABI_VERSION (0x[0-9a-fA-F]+|\d+)", text).group(1), 0)
+    assert ver == vs.lib.vstab_abi_version() == vs.ABI_VERSION
+    assert ver >> 8 == 0x565342 and ver & 255 >= 5   # "VSB" + the layout version: not a value any field of an older layout can hold
     cfg = vs.default_config()
     assert cfg.abi_version == vs.ABI_VERSION and cfg.map_precision == vs.MAP_PRECISION_OPENCL
     calls = []
     cb = vs.PULL_FN(lambda user, out: calls.append(1) or vs.EOF)
     src = vs.Source(cb, cb, None)
     h = ctypes.c_void_p()
-    for bad in (vs.Config(), vs.default_config(abi_version=vs.ABI_VERSION - 1)):   # zero-filled; another header's layout
+    for bad in (vs.Config(), vs.default_config(abi_version=vs.ABI_VERSION - 1), vs.default_config(abi_version=4),   # zero-filled; other headers' layouts
+                vs.default_config(read_ahead=17), vs.default_config(read_ahead=-1)):
         assert vs.lib.vstab_create(ctypes.byref(bad), ctypes.byref(src), ctypes.byref(h)) == vs.ERR_INVALID
-        assert b"vstab_config_default" in vs.lib.vstab_last_error() and not h.value
+        assert (b"vstab_config_default" in vs.lib.vstab_last_error() or b"read_ahead" in vs.lib.vstab_last_error()) and not h.value
     assert not calls   # refused before upstream was touched

@@ -988,22 +988,36 @@ def test_caller_on_a_stream_of_its_own(vs, cuda, clip, monkeypatch, env):
 
 def test_corner_selection_by_the_caller_when_the_helper_thread_wakes_up_late(vs, cuda, monkeypatch):
     """The speculative detection's corners are selected by a helper thread that sleeps between two detections; when it has not woken up by
-    the time the corners are looked for, the caller selects them itself.  A helper that wakes up 300 ms late (VSTAB_SPEC_HELPER_DELAY_US)
-    leaves every selection of a 70-frame clip (three planned key frames) to the caller: the frames are those of the run in which the helper
-    selects, and nobody waited for the helper (three waits would take 0.9 s)."""
-    import time
-    w, h = 640, 360
+    the time the corners are looked for, the caller selects them itself.  720p, 70 frames of the bench's clip: 200 corners survive, so the
+    key frames are the ones the counter plans (every 21st frame) and their detections run ahead, speculatively.  A helper that wakes up
+    300 ms late (VSTAB_SPEC_HELPER_DELAY_US) leaves every one of those selections to the caller: the frames and the key-frame list are
+    those of the run in which the helper selects, and the handle's counters say who selected (no wall-clock bound)."""
+    import torch
+    import bench
+    w, h, n = 1280, 720, 70
     K = oracle.get_preset_camera(4, w, h)
-    frames, _ = synth.shaky_clip(23, K, w, h, 70, sigma=0.003)
-    ref_stab, ref = run_product(vs, cuda, frames, smooth_radius=2, seed=4)
-    assert sum(1 for l in ref_stab.frame_log() if l["key"]) >= 3
-    monkeypatch.setenv("VSTAB_SPEC_HELPER_DELAY_US", "300000")
-    t0 = time.perf_counter()
-    stab, outs = run_product(vs, cuda, frames, smooth_radius=2, seed=4)
-    dt = time.perf_counter() - t0
-    assert len(outs) == len(ref) == 69 and all(np.array_equal(a, b) for a, b in zip(outs, ref))
+    dev_frames, _ = bench.shaky_ring(torch, cuda, w, h, K, n, seed=5)
+
+    def run():
+        stab = vs.Stabilizer(dev_frames, total=n, smooth_radius=2, seed=4)
+        outs = []
+        while True:
+            o = stab.pull()
+            if o is None:
+                break
+            outs.append(o.cpu().numpy())
+        return stab, outs
+    ref_stab, ref = run()
+    keys = [k for k, l in enumerate(ref_stab.frame_log()) if l["key"]]
+    assert len(keys) >= 3 and len({b - a for a, b in zip(keys, keys[1:])}) == 1, keys   # the counter's key frames only: planned, hence speculated
+    base = ref_stab.profile()
+    assert base["corner_selections_by_caller"] + base["corner_selections_by_helper"] >= len(keys), base
+    monkeypatch.setenv("VSTAB_SPEC_HELPER_DELAY_US", "300000")   # (read when the handle's tracker is constructed)
+    stab, outs = run()
+    assert len(outs) == len(ref) == n - 1 and all(np.array_equal(a, b) for a, b in zip(outs, ref))
     assert [l["key"] for l in stab.frame_log()] == [l["key"] for l in ref_stab.frame_log()]
-    assert dt < 0.6, dt
+    late = stab.profile()
+    assert late["corner_selections_by_caller"] >= len(keys) and late["corner_selections_by_helper"] == 0, late
 
 
 def test_pull_into_host_memory_equals_device_pull(vs, cuda, clip):

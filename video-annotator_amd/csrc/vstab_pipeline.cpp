@@ -287,6 +287,8 @@ class Tracker {
         return VSTAB_OK;
     }
     long spec_tag() const { return spec_tag_; }
+    long selections_by_caller() const { return selections_by_caller_; }
+    long selections_by_helper() const { return selections_by_helper_.load(std::memory_order_relaxed); }
     void set_two_pass_detector(bool on) { two_pass_detector_ = on; }
     long fused_overflows() const { return fused_overflows_; }
     // Host half of the speculative detection on a helper thread: waits for the kernels' results and runs the
@@ -307,9 +309,9 @@ class Tracker {
                     if (spec_quit_) return;
                     spec_job_ = false;
                     {
-                        // (development: VSTAB_SPEC_HELPER_DELAY_US=n makes this thread wake up late, so that a test reaches spec_poll_inline)
-                        const char *late = getenv("VSTAB_SPEC_HELPER_DELAY_US");  // (read per job, once in twenty frames: a test sets it for one handle)
-                        const long late_us = late ? atol(late) : 0;
+                        // (development: VSTAB_SPEC_HELPER_DELAY_US=n makes this thread wake up late, so that a test reaches spec_poll_inline;
+                        //  read ONCE, when the Tracker is constructed -- getenv beside a setenv of the host process is undefined behaviour)
+                        const long late_us = spec_late_us_;
                         if (late_us > 0) {
                             lk.unlock();
                             std::this_thread::sleep_for(std::chrono::microseconds(late_us));
@@ -318,6 +320,7 @@ class Tracker {
                         }
                         int unclaimed = 0;  // the caller may have done this selection itself while this thread was waking up
                         if (!spec_owner_.compare_exchange_strong(unclaimed, 1, std::memory_order_acq_rel)) continue;
+                        selections_by_helper_.fetch_add(1, std::memory_order_relaxed);
                     }
                     lk.unlock();
                     int result = 3;
@@ -362,6 +365,7 @@ class Tracker {
         }
         int unclaimed = 0;
         if (!spec_owner_.compare_exchange_strong(unclaimed, 2, std::memory_order_acq_rel)) return;  // the helper thread has it
+        selections_by_caller_++;
         int result = 3;
         const unsigned int n = spec_host_.as<unsigned int>()[0];
         if (n <= SPEC_CAP) {
@@ -573,6 +577,9 @@ class Tracker {
     std::condition_variable spec_cv_;
     std::atomic<int> spec_state_{0};
     std::atomic<int> spec_owner_{0};  // who runs the posted selection: 0 nobody yet, 1 the helper thread, 2 the caller (spec_poll_inline)
+    const long spec_late_us_ = getenv("VSTAB_SPEC_HELPER_DELAY_US") ? atol(getenv("VSTAB_SPEC_HELPER_DELAY_US")) : 0;  // development: the helper wakes up late
+    long selections_by_caller_ = 0;                 // speculative detections whose corners the caller selected itself / the helper thread selected
+    std::atomic<long> selections_by_helper_{0};
     int spec_max_ = 200;
     double spec_dist_ = 30.0;
     std::vector<float> spec_xy_;
@@ -1475,6 +1482,7 @@ void vstab_config_default(vstab_config *cfg) {
     cfg->pixel_depth = 8, cfg->blend = VSTAB_BLEND_EXACT;
     // the reference's map is what ITS kernel computes on this GPU (createMap.cl through ROCm's OpenCL compiler): the default
     cfg->map_precision = VSTAB_MAP_PRECISION_OPENCL;
+    cfg->read_ahead = 0;  // the library's default (PREFETCH_DEPTH)
 }
 
 vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vstab_handle **out) {
@@ -1494,6 +1502,8 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (cfg->blend != VSTAB_BLEND_EXACT && cfg->blend != VSTAB_BLEND_FP16) return fail(VSTAB_ERR_INVALID, "vstab_create: unknown blend");
     if (cfg->map_precision != VSTAB_MAP_PRECISION_IEEE && cfg->map_precision != VSTAB_MAP_PRECISION_OPENCL)
         return fail(VSTAB_ERR_INVALID, "vstab_create: unknown map_precision");
+    if (cfg->read_ahead < 0 || cfg->read_ahead > PREFETCH_MAX)
+        return fail(VSTAB_ERR_INVALID, "vstab_create: read_ahead must be 0 (the default, " + std::to_string(PREFETCH_DEPTH) + ") or 1 .. " + std::to_string(PREFETCH_MAX));
     // (lens_mode 1 ignores map_precision: those maps are this library's own definitions, IEEE arithmetic throughout)
     std::unique_ptr<vstab_handle> H(new vstab_handle);
     H->cfg = *cfg, H->src = *src;
@@ -1555,7 +1565,8 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     }
     if (H->ow <= 0 || H->oh <= 0 || H->ow > 32767 || H->oh > 32767) return fail(VSTAB_ERR_INVALID, "vstab_create: output size out of range");
     if (cfg->smoother == VSTAB_SMOOTHER_SG) H->sg.reset(new RotationFilterSG(cfg->smooth_radius));
-    if (const char *e = getenv("VSTAB_PREFETCH")) H->prefetch_depth = std::max(1, std::min(atoi(e), PREFETCH_MAX));
+    if (cfg->read_ahead > 0) H->prefetch_depth = cfg->read_ahead;  // vstab_config.read_ahead: the caller's latency / throughput choice
+    else if (const char *e = getenv("VSTAB_PREFETCH")) H->prefetch_depth = std::max(1, std::min(atoi(e), PREFETCH_MAX));  // (development sweeps)
     if (const char *e = getenv("VSTAB_LK_SEG_TARGET")) H->seg_target = std::max(1, std::min(atoi(e), H->seg_max));
     // queue (r + 1) + the frame whose estimate runs + the one whose results are read + the one in flight + first/last gray + 1 spare
     // + the read-ahead + the slots that wait for a shared warp event
@@ -1702,8 +1713,12 @@ static vstab_status pull_frame_impl(vstab_handle *H, int out_format, void *dst, 
             }
         }
         else if (H->cfg.interpolation == 0) {
-            // (this kernel does not take the profiler's event pair: ~GpuStage then records stream positions around the launch)
-            if (out_format != VSTAB_OUT_BGR8 || S.have_readout) st = fail(VSTAB_ERR_INVALID, "INTER_NEAREST emits 8-bit BGR frames without a read-out rotation");
+            // (vstab_warp_nv12_nearest_ex takes the profiler's event pair like the other warp kernels; a refused request launches nothing,
+            //  so the pair armed by GpuStage is taken back here instead of staying pending for somebody else's launch)
+            if (out_format != VSTAB_OUT_BGR8 || S.have_readout) {
+                (void)take_launch_events();
+                st = fail(VSTAB_ERR_INVALID, "INTER_NEAREST emits 8-bit BGR frames without a read-out rotation");
+            }
             else st = vstab_warp_nv12_nearest_ex(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, p, H->map_mode, dst, pitch_dst, H->ow, H->oh, H->stream);
         } else if (cached)
             st = vstab_warp_nv12_mapped(S.y, S.pitch_y, S.uv, S.pitch_uv, H->w, H->h, H->qmap.p, out_format, dst, pitch_dst, dst_uv, pitch_dst_uv,
@@ -1828,6 +1843,7 @@ vstab_status vstab_get_profile(vstab_handle *h, vstab_profile *out) {
     if (!h || !out) return fail(VSTAB_ERR_INVALID, "vstab_get_profile: null argument");
     h->fold_pending();
     h->prof.dmabuf_imports = h->dmabufs.imports, h->prof.dmabuf_evictions = h->dmabufs.evictions, h->prof.dmabuf_cached = (long)h->dmabufs.size();
+    h->prof.corner_selections_by_caller = h->tracker.selections_by_caller(), h->prof.corner_selections_by_helper = h->tracker.selections_by_helper();
     *out = h->prof;
     return VSTAB_OK;
 }

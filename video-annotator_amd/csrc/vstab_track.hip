@@ -1368,6 +1368,7 @@ vstab_status launch_pyr_down(const uint8_t *src, size_t spitch, int sw, int sh, 
 bool pack_pyr_ok(const void *y, size_t pitch_y, const void *uv, size_t pitch_uv, int w, int h, const void *ring, const void *dst, size_t dpitch) {
     return w >= 16 && h >= 4 && !(w & 7) && !(h & 1) && reinterpret_cast<uintptr_t>(y) % 4 == 0 && pitch_y % 4 == 0 && reinterpret_cast<uintptr_t>(ring) % 8 == 0 &&
            reinterpret_cast<uintptr_t>(dst) % 4 == 0 && dpitch % 4 == 0 && pitch_y < (1u << 24) && pitch_uv < (1u << 24) && (uint64_t)pitch_y * (uint64_t)h < (1ull << 32) &&
+           (uint64_t)pitch_uv * (uint64_t)(h / 2) < (1ull << 32) &&  // (k_pack_pyr forms row * pitch_uv in 32 bits)
            (uint64_t)w * (uint64_t)h * 3 / 2 < (1ull << 32);
 }
 vstab_status launch_pack_pyr(const uint8_t *y, size_t pitch_y, const uint8_t *uv, size_t pitch_uv, int sw, int sh, uint8_t *ring, uint8_t *dst, size_t dpitch,
