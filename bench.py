@@ -593,7 +593,7 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    cpu0 = os.times()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     mark()
     run_steps(n_warm, args.steps, True)
@@ -602,19 +602,22 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    cpu1 = os.times()
+    cpu1 = time.process_time()
+    el_own = el  # this rank's own wall time (el becomes the maximum over the ranks below)
     gc.enable()
     step_ms = [a.elapsed_time(b) for a, b in zip(step_events[:-1], step_events[1:])]
     # what a rank costs the HOST: CPU seconds (user + system, every thread of this process: the caller's frame loop, the handle's
     # estimate worker and corner-selection helper, the runtime's threads) per 1000 frames of the timed region
-    cpu_s = (cpu1.user + cpu1.system) - (cpu0.user + cpu0.system)
+    cpu_s = cpu1 - cpu0
     try:
         n_threads = int([ln.split()[1] for ln in open("/proc/self/status") if ln.startswith("Threads:")][0])
     except Exception:
         n_threads = None
-    host_cost = {"cpu_seconds_per_1000_frames": round(cpu_s / max(1, n_timed) * 1000, 4), "cpu_seconds": round(cpu_s, 4), "wall_seconds": round(el, 4),
-                 "cpus_busy": round(cpu_s / el, 2), "threads": n_threads, "pinned_cpus": len(os.sched_getaffinity(0)),
-                 "what": "user + system time of every thread of this rank's process over the timed region (os.times)"}
+    host_cost = {"cpu_seconds_per_1000_frames": round(cpu_s / max(1, n_timed) * 1000, 4), "cpu_seconds": round(cpu_s, 4), "wall_seconds": round(el_own, 4),
+                 "cpus_busy": round(cpu_s / el_own, 2), "threads": n_threads, "pinned_cpus": len(os.sched_getaffinity(0)),
+                 "what": "user + system time of every thread of this rank's process over the timed region (time.process_time); cpus_busy = that / "
+                         "wall time: the CPUs one rank keeps busy (its frame loop + the handle's estimate worker and corner-selection helper, which "
+                         "spin before they sleep) -- the figure that says whether N ranks fit one host; seconds per 1000 frames = cpus_busy / rate"}
     if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -685,7 +688,7 @@ def main():
     if nv12_out or p010_out:
         last = last[0]
     mine = sorted(os.sched_getaffinity(0))
-    rec = dict(rank=rank, clip=rank, frames=n_timed, elapsed_ns=int(el * 1e9), crc=shard.crc_of(last[:64].cpu().numpy()), cpu_first=mine[0], cpu_last=mine[-1],
+    rec = dict(rank=rank, clip=rank, frames=n_timed, elapsed_ns=int(el_own * 1e9), crc=shard.crc_of(last[:64].cpu().numpy()), cpu_first=mine[0], cpu_last=mine[-1],
                cpu_count=len(mine), cpu_us=int(cpu_s * 1e6))
     records = shard.gather_records([rec], device=cdev)
     if rank == 0 and world > 1:
@@ -804,7 +807,8 @@ def main():
             "preroll": preroll, "parity_check": parity, "parity_check_against": parity_against if parity else None, "rank_cpus": pinned,
             "collectives": args.dist_backend if use_dist else None,
             "host": dict(host_cost, all_ranks_cpu_seconds_per_1000_frames=[round(r.get("cpu_us", 0) / 1e6 / max(1, r["frames"]) * 1000, 4) for r in records]
-                         if world > 1 else None),
+                         if world > 1 else None,
+                         all_ranks_cpus_busy=[round(r.get("cpu_us", 0) * 1e3 / max(1, r["elapsed_ns"]), 2) for r in records] if world > 1 else None),
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),

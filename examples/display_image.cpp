@@ -18,13 +18,38 @@
 class SyntheticSource : public vstab::NV12FrameSource {  // stands in for FrameSourceFfmpegOpenCl
   public:
     // gyro: also stand in for the GPMF "GYRO" stream the reference never got to read (gpmf.cpp:5-11): 3.2 kHz samples of a
-    // hand-held shake, integrated per frame into the rotation since the previous frame and the rotation during read-out
+    // hand-held shake, delivered as GPMF packets, parsed, and integrated per frame into the rotation since the previous frame and the
+    // rotation during read-out
     SyntheticSource(int w, int h, int n, bool gyro = false) : w_(w), h_(h), left_(n), gyro_(gyro) {
         if (gyro) {
-            const double hz = 3200.0, fps = 30.0;
-            for (int i = 0; i < (int)((n + 2) / fps * hz); i++) {
-                const double t = (i + 0.5) / hz;
-                samples_.push_back({i / hz, (i + 1) / hz, 0.5 * std::sin(23 * t + 1.1), 0.9 * std::sin(40 * t), 0.7 * std::cos(31 * t + 0.3)});
+            // The camera's metadata track as the demuxer would hand it over (AvFrameSourceFileVaapi.cpp:121-123: the GPMF packets the
+            // reference leaves as a TODO): one packet per second, DEVC > STRM > {SCAL, GYRO}, 3200 int16 triples (Z, X, Y) scaled by 1000,
+            // everything big-endian.  vstab_gpmf_parse_gyro turns each packet into GyroFrame records (gpmf.cpp:95-101).
+            const int hz = 3200;
+            const double fps = 30.0, scal = 1000.0;
+            const int packets = (int)((n + 2) / fps) + 1;
+            for (int pk = 0; pk < packets; pk++) {
+                std::vector<unsigned char> gy;
+                auto be16 = [&gy](int v) { gy.push_back((unsigned char)((v >> 8) & 255)), gy.push_back((unsigned char)(v & 255)); };
+                for (int i = 0; i < hz; i++) {
+                    const double t = pk + (i + 0.5) / hz;
+                    be16((int)std::lround(scal * 0.5 * std::sin(23 * t + 1.1))), be16((int)std::lround(scal * 0.9 * std::sin(40 * t))), be16((int)std::lround(scal * 0.7 * std::cos(31 * t + 0.3)));
+                }
+                auto item = [](const char *key, unsigned char type, int size, int repeat, const std::vector<unsigned char> &data) {
+                    std::vector<unsigned char> v(key, key + 4);
+                    v.push_back(type), v.push_back((unsigned char)size), v.push_back((unsigned char)(repeat >> 8)), v.push_back((unsigned char)(repeat & 255));
+                    v.insert(v.end(), data.begin(), data.end());
+                    while (v.size() % 4) v.push_back(0);
+                    return v;
+                };
+                std::vector<unsigned char> strm = item("SCAL", 's', 2, 1, {(unsigned char)((int)scal >> 8), (unsigned char)((int)scal & 255)});
+                const std::vector<unsigned char> g = item("GYRO", 's', 6, hz, gy);
+                strm.insert(strm.end(), g.begin(), g.end());
+                const std::vector<unsigned char> devc = item("DEVC", 0, 4, (int)(item("STRM", 0, 4, (int)strm.size() / 4, strm).size() / 4), item("STRM", 0, 4, (int)strm.size() / 4, strm));
+                std::vector<vstab_gyro_sample> got(hz);
+                int found = 0;
+                if (vstab_gpmf_parse_gyro(devc.data(), devc.size(), (double)pk, 1.0, got.data(), hz, &found) != VSTAB_OK || found != hz) throw -1;
+                samples_.insert(samples_.end(), got.begin(), got.end());
             }
         }
         std::vector<unsigned char> host((size_t)w * h * 3 / 2);

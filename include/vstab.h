@@ -329,6 +329,23 @@ VSTAB_API vstab_status vstab_gyro_integrate(const vstab_gyro_sample *samples, in
                                             double t_prev_first_row, double t_first_row, double t_last_row,
                                             double R_delta[9], double R_readout[9]);
 
+/* GPMF payload -> gyro samples: the reader the reference sketched and left commented out (opencv/gpmf.cpp:33-114, with gpmf-parser;
+ * AvFrameSourceFileVaapi.cpp:121-123 "TODO process GPMF packet").  payload / n: one packet of the camera's metadata stream as the
+ * demuxer hands it over; pkt_ts / pkt_dur: the packet's time stamp and duration in seconds (AVPacket.pts / .duration times the
+ * stream's time base).  GoPro's published KLV layout is walked directly (no gpmf-parser): items of {FourCC key, type character,
+ * structure size (1 byte), repeat count (2 bytes)} + repeat * size bytes, everything big-endian and padded to four bytes; type 0
+ * nests (DEVC > STRM > items).  Inside a stream, SCAL holds the divisor -- one for all elements or one per element -- that turns
+ * the raw GYRO integers (type 's', three per sample; 'S' 'l' 'L' 'b' 'B' 'f' 'd' are accepted too) into rad/s.  As gpmf.cpp:95-101
+ * intends, a block's samples share the packet's span evenly -- sample i of m: start_ts = pkt_ts + pkt_dur * i / m, end_ts = start_ts
+ * + pkt_dur / m -- and elements 0, 1, 2 go to roll, pitch, yaw: the order GoPro documents for HERO5 and later, Z (the optical axis),
+ * X (to the right), Y (downwards), which is vstab_gyro_sample's convention.  The result feeds vstab_gyro_integrate (rate_scale = -1
+ * for these body rates).  Up to `cap` samples are written to out; *n_out = the number found (call again with a larger buffer if it
+ * exceeds cap).  Every GYRO block of the payload is taken, in order.  VSTAB_ERR_INVALID for a payload that is not well formed: an
+ * item that runs past its container, a truncated header, nesting deeper than eight levels, a GYRO block that does not have three
+ * elements per sample, a SCAL of zero.  Host only; reads nothing outside [payload, payload + n). */
+VSTAB_API vstab_status vstab_gpmf_parse_gyro(const void *payload, size_t n, double pkt_ts, double pkt_dur, vstab_gyro_sample *out, int cap,
+                                             int *n_out);
+
 /* A map that does not change between frames (tracking off: undistort only, the CLI's stab=none re-projections) need
  * not be evaluated per frame as the reference does (FrameSourceWarp.cpp:283-304): vstab_quantised_map writes, once,
  * what cv::remap makes of every map entry (32 * map rounded to int; vstab_quantised_map_bytes() bytes, 16-byte aligned

@@ -1241,14 +1241,24 @@ def test_bench_four_ranks_share_one_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--share-gpu", "--dist-backend", "gloo", "--workload", "1080p",
-                        "--steps", "2", "--warmup", "1", "--batch", "8", "--preroll", "40", "--fixed-preroll", "--ring", "8", "--no-cpu-baseline"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    line = json.loads(lines[0])
+    shape = ["--workload", "1080p", "--steps", "4", "--warmup", "1", "--batch", "64", "--preroll", "200", "--fixed-preroll", "--ring", "16", "--no-cpu-baseline",
+             "--skip-copy-pass"]
+
+    def bench_line(extra):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra + shape, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        return json.loads(lines[0])
+    one = bench_line(["--gpus", "1"])
+    line = bench_line(["--gpus", "4", "--share-gpu", "--dist-backend", "gloo"])
     assert line["n_gpus"] == 4 and line["config"]["clips"] == 4 and line["parity_check"] == "ok" and len(line["rank_cpus_all"]) == 4
+    # what a rank costs the host: the CPUs it keeps busy (its frame loop and the handle's two helper threads spin before they sleep).
+    # Four ranks on ONE card run at a quarter of the rate each, so their CPU-seconds PER FRAME are four times the single rank's; what
+    # has to hold for N ranks to fit a host is that a rank's busy CPUs do not grow with N and stay inside the CPUs it is pinned to.
+    busy1, busy4 = one["host"]["cpus_busy"], line["host"]["all_ranks_cpus_busy"]
+    assert one["host"]["cpu_seconds_per_1000_frames"] > 0 and one["host"]["threads"] >= 4 and one["host"]["pinned_cpus"] == 8
+    assert len(busy4) == 4 and all(0 < b <= 1.5 * busy1 and b <= 8 for b in busy4), (busy1, busy4)
     sets = []
     for txt in line["rank_cpus_all"]:
         first, last = (int(v) for v in txt.split(" ")[0].split("-"))

@@ -121,6 +121,7 @@ SIGNATURES = {
     "vstab_time_next_launch": (None, [_vp, _vp]),
     "vstab_sg_weights": (_i, [_i, _dp]),
     "vstab_gyro_integrate": (_i, [_vp, _i, _d, _d, _d, _d, _dp, _dp]),
+    "vstab_gpmf_parse_gyro": (_i, [_vp, _sz, _d, _d, _vp, _i, _ip]),
     "vstab_rotation_filter_create": (_i, [_i, _pp]),
     "vstab_rotation_filter_add": (_i, [_vp, _dp]),
     "vstab_rotation_filter_filter": (_i, [_vp, _dp]),
@@ -563,6 +564,16 @@ def gyro_integrate(samples, rate_scale, t_prev_first_row, t_first_row, t_last_ro
     _check(_L.vstab_gyro_integrate(a.ctypes.data_as(_vp), a.shape[0], float(rate_scale), float(t_prev_first_row), float(t_first_row),
                                    float(t_last_row), Rd.ctypes.data_as(_dp), Rr.ctypes.data_as(_dp)), "vstab_gyro_integrate")
     return Rd.reshape(3, 3), Rr.reshape(3, 3)
+
+
+def gpmf_parse_gyro(payload, pkt_ts, pkt_dur, cap=None):
+    """vstab_gpmf_parse_gyro: bytes of one GPMF packet -> (n, 5) array of {start_ts, end_ts, roll, pitch, yaw} samples."""
+    buf = bytes(payload)
+    n = _c.c_int(0)
+    cap = (len(buf) // 2 + 1) if cap is None else int(cap)
+    out = np.zeros((max(cap, 1), 5), np.float64)
+    _check(_L.vstab_gpmf_parse_gyro(buf, len(buf), float(pkt_ts), float(pkt_dur), out.ctypes.data, cap, _c.byref(n)), "vstab_gpmf_parse_gyro")
+    return out[: min(n.value, cap)].copy(), n.value
 
 
 def sg_weights(m):

@@ -343,3 +343,118 @@ extern "C" vstab_status vstab_gyro_integrate(const vstab_gyro_sample *samples, i
     }
     return VSTAB_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GPMF payload -> gyro samples: what opencv/gpmf.cpp:33-114 sketches with gpmf-parser (commented out there) and
+// AvFrameSourceFileVaapi.cpp:121-123 leaves as "TODO process GPMF packet".  gpmf-parser is not in the image; the payload format
+// is GoPro's published KLV: every item is a FourCC key, a type character, the size of one sample structure (1 byte), a
+// repeat count (2 bytes, big-endian) and repeat * size bytes of big-endian data, padded to a multiple of four; type 0 nests
+// (DEVC device > STRM stream > items).  Inside a STRM, SCAL holds the divisor(s) that turn the raw GYRO integers into rad/s.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct GpmfItem {
+    uint32_t key;
+    char type;
+    uint32_t size, repeat;
+    const uint8_t *data;
+    size_t bytes;  // repeat * size (unpadded)
+};
+constexpr uint32_t fourcc(char a, char b, char c, char d) { return (uint32_t)(uint8_t)a << 24 | (uint32_t)(uint8_t)b << 16 | (uint32_t)(uint8_t)c << 8 | (uint32_t)(uint8_t)d; }
+
+// size of one element of a simple numeric type, 0 for anything else
+int gpmf_elem_size(char t) {
+    switch (t) {
+        case 'b': case 'B': return 1;
+        case 's': case 'S': return 2;
+        case 'l': case 'L': case 'f': return 4;
+        case 'd': case 'j': case 'J': return 8;
+        default: return 0;
+    }
+}
+double gpmf_elem(const uint8_t *p, char t) {
+    uint64_t v = 0;
+    const int n = gpmf_elem_size(t);
+    for (int i = 0; i < n; i++) v = v << 8 | p[i];
+    switch (t) {
+        case 'b': return (double)(int8_t)v;
+        case 'B': return (double)(uint8_t)v;
+        case 's': return (double)(int16_t)v;
+        case 'S': return (double)(uint16_t)v;
+        case 'l': return (double)(int32_t)v;
+        case 'L': return (double)(uint32_t)v;
+        case 'j': return (double)(int64_t)v;
+        case 'J': return (double)v;
+        case 'f': { const uint32_t u = (uint32_t)v; float f; std::memcpy(&f, &u, 4); return (double)f; }
+        default: { double d; std::memcpy(&d, &v, 8); return d; }  // 'd'
+    }
+}
+
+struct GpmfGyroSink {
+    double ts, dur;
+    vstab_gyro_sample *out;
+    int cap, n = 0;
+    std::string err;
+};
+
+// one level of the tree: the items of [p, p + n); scal = the divisors of the enclosing STRM seen so far
+bool gpmf_walk(const uint8_t *p, size_t n, int depth, GpmfGyroSink &sink) {
+    if (depth > 8) return sink.err = "nesting deeper than 8 levels", false;
+    double scal[3] = {1, 1, 1};
+    size_t pos = 0;
+    while (pos < n) {
+        if (n - pos < 4) return sink.err = "truncated item header", false;
+        GpmfItem it;
+        it.key = (uint32_t)p[pos] << 24 | (uint32_t)p[pos + 1] << 16 | (uint32_t)p[pos + 2] << 8 | p[pos + 3];
+        if (it.key == 0) break;  // zero padding at the end of a payload
+        if (n - pos < 8) return sink.err = "truncated item header", false;
+        it.type = (char)p[pos + 4], it.size = p[pos + 5], it.repeat = (uint32_t)p[pos + 6] << 8 | p[pos + 7];
+        it.bytes = (size_t)it.size * it.repeat;
+        const size_t padded = (it.bytes + 3) & ~(size_t)3;
+        if (padded > n - pos - 8) return sink.err = "item longer than its container", false;
+        it.data = p + pos + 8;
+        if (it.type == 0) {  // nested container
+            if (!gpmf_walk(it.data, it.bytes, depth + 1, sink)) return false;
+        } else if (it.key == fourcc('S', 'C', 'A', 'L')) {
+            const int es = gpmf_elem_size(it.type);
+            if (es == 0 || it.size == 0 || it.size % es) return sink.err = "SCAL of a type that is not a plain number", false;
+            const uint32_t count = it.size / es * it.repeat;  // one divisor for all elements, or one per element
+            if (count != 1 && count != 3) {
+                scal[0] = scal[1] = scal[2] = 1;  // some other stream's scale (GPS5 has five): not a gyro's
+            } else {
+                for (int k = 0; k < 3; k++) scal[k] = gpmf_elem(it.data + (count == 3 ? k * es : 0), it.type);
+                if (scal[0] == 0 || scal[1] == 0 || scal[2] == 0) return sink.err = "SCAL of zero", false;
+            }
+        } else if (it.key == fourcc('G', 'Y', 'R', 'O')) {
+            const int es = gpmf_elem_size(it.type);
+            if (es == 0 || it.size != 3u * es) return sink.err = "Unexpected number of elements for GYRO data", false;  // gpmf.cpp:88-92
+            for (uint32_t s = 0; s < it.repeat; s++) {
+                if (sink.n < sink.cap) {
+                    vstab_gyro_sample &g = sink.out[sink.n];
+                    const uint8_t *e = it.data + (size_t)s * it.size;
+                    // gpmf.cpp:95-101: the packet's time span dealt evenly to its samples; elements 0, 1, 2 -> roll, pitch, yaw
+                    // (GoPro documents the order Z, X, Y for HERO5 and later: about the optical axis, to the right, downwards)
+                    g.start_ts = sink.ts + sink.dur * s / it.repeat;
+                    g.end_ts = g.start_ts + sink.dur / it.repeat;
+                    g.roll = gpmf_elem(e, it.type) / scal[0], g.pitch = gpmf_elem(e + es, it.type) / scal[1], g.yaw = gpmf_elem(e + 2 * es, it.type) / scal[2];
+                }
+                sink.n++;
+            }
+        }
+        pos += 8 + padded;
+    }
+    return true;
+}
+
+}  // namespace
+
+using vstab::fail;
+extern "C" vstab_status vstab_gpmf_parse_gyro(const void *payload, size_t n, double pkt_ts, double pkt_dur, vstab_gyro_sample *out, int cap, int *n_out) {
+    if (n_out) *n_out = 0;
+    if (!payload || !n_out || cap < 0 || (cap > 0 && !out)) return fail(VSTAB_ERR_INVALID, "vstab_gpmf_parse_gyro: null argument");
+    if (!(pkt_dur >= 0) || !(pkt_ts == pkt_ts)) return fail(VSTAB_ERR_INVALID, "vstab_gpmf_parse_gyro: packet duration must be >= 0");
+    GpmfGyroSink sink{pkt_ts, pkt_dur, out, cap};
+    if (!gpmf_walk(static_cast<const uint8_t *>(payload), n, 0, sink)) return fail(VSTAB_ERR_INVALID, "vstab_gpmf_parse_gyro: " + sink.err);
+    *n_out = sink.n;
+    return VSTAB_OK;
+}
