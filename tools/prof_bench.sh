@@ -1,14 +1,14 @@
 #!/bin/bash
-# usage (on the GPU box): bash tools/prof_bench.sh <tag>
+# usage (on the GPU box): [EXTRA="--out-format nv12-planar" WARP_KERNEL=k_warp_planar] bash tools/prof_bench.sh <tag>
 # kernel-trace stats + separate PMC passes (FETCH_SIZE / WRITE_SIZE each alone) of the default bench
-# command, plus the PMC calibration kernels.  Output: gpurun_out/prof_<tag>/
+# command (plus EXTRA arguments), plus the PMC calibration kernels.  Output: gpurun_out/prof_<tag>/
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-bench}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="$R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --skip-copy-pass"
+ARGS="$R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --skip-copy-pass $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1
