@@ -16,3 +16,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAI
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -- python3 $R/tools/calib_traffic.py > $OUT/cal_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -- python3 $R/tools/calib_traffic.py > $OUT/cal_write.log 2>&1
 python3 $R/tools/summarize_bench_prof.py $OUT
+# the per-dispatch tables are tens of MB each (gpurun copies back at most 64 MiB): keep the statistics, the summary and the logs
+find $OUT/trace -name "*kernel_trace.csv" -delete
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/cal_fetch $OUT/cal_write
+du -sh $OUT

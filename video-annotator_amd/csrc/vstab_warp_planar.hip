@@ -7,14 +7,15 @@
 //           entry of luma pixel (2 cx, 2 cy), halved (exact) and quantised again: cvRound(32 * (map / 2)).
 // The kernel is k_warp_fused's structure (vstab_warp_fused.hip) without its colour conversion: probe -> load -> map -> stage -> sample
 // -> store, one workgroup per 64-column tile, lane = output column, a wave owns RW consecutive rows.  What differs:
-//   stage   the box is staged AS IT IS -- luma bytes and chroma byte pairs, 1.5 bytes per source pixel instead of a 4-byte BGRx pixel
-//           -- in blocks of 16 bytes x 2 luma rows + 16 bytes of chroma (three 16-byte loads, three ds_write_b128 per thread);
-//           blocks outside the source are written as limited-range black;
-//   sample  a luma pixel is two unaligned ds_read_u16 (the two taps of a row), two v_dot4_u32_u8 and one multiply-add; a thread's
-//           eight luma pixels come with TWO chroma pixels (the even-row map entries of the even lanes, dealt to lane pairs with DPP),
-//           each two ds_read_b32 and four dot products;
+//   stage   the box is staged AS IT IS -- luma samples and chroma pairs, 1.5 samples per source pixel instead of a 4-byte BGRx pixel
+//           -- by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write); chunks outside the source are written as
+//           limited-range black;
+//   sample  a luma pixel is four byte reads (the two taps of two rows, each at its natural alignment), two v_dot4_u32_u8 and one
+//           v_dot2_u32_u16; a thread's eight luma pixels come with TWO chroma pixels (the even-row map entries of the even lanes, dealt
+//           to lane pairs with DPP), each four 16-bit reads and six dot products;
 //   store   result bytes are transposed through 768 bytes of LDS per wave, so every lane stores 8 (luma) + 4 (chroma) contiguous bytes.
-// 10-bit samples (P010 words, DEPTH 10): staged as their ten significant bits in 16-bit fields, v_dot2_u32_u16 in place of v_dot4.
+// 10-bit samples (DEPTH 10): the box holds the P010 WORDS as they came; a pair of taps becomes two ten-bit values with one packed shift
+// (v_pk_lshrrev_b16), the exact blend is v_dot2_u32_u16 in place of v_dot4, the binary16 blend is packed two samples (or U and V) wide.
 // Bit-exactness never depends on the box: a footprint outside it is sampled from global memory with the same integers.
 #include <algorithm>
 #include <climits>
@@ -45,8 +46,8 @@ struct Planar {
     static constexpr int BW = 16 / BPS;                        // luma pixels of a staging block row (one 16-byte load)
     static constexpr int BLACK_Y = DEPTH == 10 ? 64 : 16;      // limited-range black: what cv::remap's Scalar(0) border of the BGR path is here
     static constexpr int BLACK_C = DEPTH == 10 ? 512 : 128;
-    static constexpr uint32_t BLACK_Y_DWORD = DEPTH == 10 ? 0x00400040u : 0x10101010u;  // as staged in LDS (10 bits: values, not words)
-    static constexpr uint32_t BLACK_C_DWORD = DEPTH == 10 ? 0x02000200u : 0x80808080u;
+    static constexpr uint32_t BLACK_Y_DWORD = DEPTH == 10 ? 0x10001000u : 0x10101010u;  // as staged in LDS (10 bits: P010 words, value << 6)
+    static constexpr uint32_t BLACK_C_DWORD = DEPTH == 10 ? 0x80008000u : 0x80808080u;
     static constexpr int SCRATCH_PER_WAVE = 768 * BPS;         // 8 rows x 64 luma + 4 rows x 32 chroma pairs
 };
 
@@ -91,6 +92,33 @@ __device__ __forceinline__ uint32_t blend8_scaled(uint32_t t_top, uint32_t t_bot
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, h0 | (h1 << 16)), __builtin_bit_cast(u16x2, wy16), 32768u, false);
 }
 
+// ---- 16-bit samples.  Two P010 words -> their two ten-bit values (one v_pk_lshrrev_b16) --------------------------------------------
+__device__ __forceinline__ uint32_t sig10_x2(uint32_t words) {
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, words) >> (u16x2){6, 6}));
+}
+// two ten-bit values -> two binary16 numbers: the pattern 0x6400 | v is 1024 + v
+__device__ __forceinline__ half2v half_of10_x2(uint32_t v) {
+    return __builtin_bit_cast(half2v, v | 0x64006400u) - (half2v){(_Float16)1024.0f, (_Float16)1024.0f};
+}
+// two five-bit fractions f -> f / 32 in binary16: (1024 + f) / 32 - 32 in one fused multiply-add (32 + f / 32 has ulp 1 / 32: exact)
+__device__ __forceinline__ half2v frac_half_x2(uint32_t f2) {
+    return __builtin_elementwise_fma(__builtin_bit_cast(half2v, f2 | 0x64006400u), (half2v){(_Float16)0.03125f, (_Float16)0.03125f},
+                                     (half2v){(_Float16)-32.0f, (_Float16)-32.0f});
+}
+// VSTAB_BLEND_FP16 (vstab_device10.hpp blend_fp16: four fused multiply-adds in the order 00, 01, 10, 11 with weights w / 1024 -- products
+// of multiples of 1 / 32, exact in binary16 --, round to nearest even, clamp) on TWO independent samples at once, one per half; taps and
+// fractions as binary16 pairs.  Returns the two ten-bit values (value | value << 16); as blend_bgr10h does it for B and G.
+__device__ __forceinline__ uint32_t blend10h_x2(half2v p00, half2v p01, half2v p10, half2v p11, half2v fx, half2v fy) {
+    const half2v one = {(_Float16)1.0f, (_Float16)1.0f};
+    const half2v gx = one - fx, gy = one - fy;
+    half2v acc = p00 * (gx * gy);  // fma(p, w, 0)
+    acc = __builtin_elementwise_fma(p01, fx * gy, acc);
+    acc = __builtin_elementwise_fma(p10, gx * fy, acc);
+    acc = __builtin_elementwise_fma(p11, fx * fy, acc);
+    const half2v top = {(_Float16)1023.0f, (_Float16)1023.0f}, magic = {(_Float16)1024.0f, (_Float16)1024.0f};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(acc, top) + magic) & 0x03ff03ffu;  // ulp 1 at 1024: the adder rounds
+}
+
 // NB bytes of this lane from the wave's transposition scratch to global memory (NB = 1, 2, 4, 8, 16)
 // (the scratch is written as samples and read as vectors: may_alias types, so that the reads stay behind the writes)
 typedef uint16_t __attribute__((may_alias)) u16_alias;
@@ -120,7 +148,6 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
     constexpr int CR = RW / 2;        // chroma rows of a wave
     constexpr int NS = (RW + 3) / 4;  // chroma pixels per thread: CR rows x 32 columns over 64 lanes (RW = 2: the even lanes only)
     constexpr int QB = QMAGIC_BITS;
-    constexpr bool DMA = DEPTH == 8;  // the box is staged by LDS-DMA (bytes as they are); 16-bit samples go through registers
     uint8_t *const scratch = reinterpret_cast<uint8_t *>(smem) + 32;
     uint8_t *const tile = scratch + 4 * P::SCRATCH_PER_WAVE;
     const WarpArgs &a = ta.w;
@@ -146,14 +173,14 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
     const int pw = wb * BPS;                       // LDS row pitch in bytes, of both boxes (a chroma pair takes as much as two luma samples)
     const int luma_bytes = pw * hb;
 
-    // ---- load.  8-bit: the box goes from global memory straight into LDS (LDS-DMA, global_load_lds_dwordx4: no staging registers, no
+    // ---- load: the box goes from global memory straight into LDS (LDS-DMA, global_load_lds_dwordx4: no staging registers, no
     // ds_write).  One wave-instruction writes 64 consecutive 16-byte chunks of LDS from 64 addresses of its lanes' choosing; the box is rows
     // of ux_n chunks, so lane i of an instruction takes chunk (i / ux_n, i % ux_n) of a group of 64 / ux_n rows and the LDS image is the box,
     // row after row.  The lane's part of the source offset is computed ONCE per tile; an instruction adds a scalar row offset.  The four
     // waves take the row groups of the luma box, then of the chroma box, in turn.  Chunks outside the source (tiles at the frame's edge)
-    // are not fetched but written as limited-range black.  16-bit samples: through registers (below), reduced to ten bits on the way. -----
+    // are not fetched but written as limited-range black. --------------------------------------------------------------------------------
     const int ux_n = wb / BW;
-    if constexpr (DMA) {
+    {
         if (use_lds) {
             const float rn = __builtin_amdgcn_rcpf((float)ux_n);
             int r0 = (int)((float)lane * rn), col = lane - r0 * ux_n;  // divmod(lane, ux_n): the float quotient is off by at most one
@@ -162,11 +189,11 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
             const int rpi_f = __builtin_amdgcn_readfirstlane((int)(64.0f * rn + 0.001f));  // rows per instruction: floor(64 / ux_n)
             const int rpi = rpi_f * ux_n <= 64 ? rpi_f : rpi_f - 1;
             const bool active = r0 < rpi;
-            const int colb = bx0 + BWB * col;  // first source byte of the lane's chunk within a row (8-bit: byte = pixel)
+            const int colp = bx0 + BW * col;  // first source sample of the lane's chunk within a row (a chroma row: the same bytes per luma column)
             const int sw_al = a.sw & ~(BW - 1);
-            const bool col_ok = (uint32_t)colb < (uint32_t)sw_al;
+            const bool col_ok = (uint32_t)colp < (uint32_t)sw_al;
             const uint32_t pitch_y = (uint32_t)a.pitch_y, pitch_uv = (uint32_t)a.pitch_uv;  // < 2^24, frame < 4 GiB (host check)
-            const uint32_t lane_y = (uint32_t)r0 * pitch_y + (uint32_t)colb, lane_c = (uint32_t)r0 * pitch_uv + (uint32_t)colb;
+            const uint32_t lane_y = (uint32_t)r0 * pitch_y + (uint32_t)(colp * BPS), lane_c = (uint32_t)r0 * pitch_uv + (uint32_t)(colp * BPS);
             const int hc = hb >> 1;
             const int nl = (hb + rpi - 1) / rpi, nc = (hc + rpi - 1) / rpi;
             const bool interior = bx0 >= 0 && by0 >= 0 && bx0 + wb <= sw_al && by0 + hb <= a.sh;  // uniform: no chunk outside the source
@@ -196,50 +223,6 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
             }
         }
     }
-    // (16-bit samples) this thread's blocks (BW x 2 luma samples + BW / 2 chroma pairs), every load in flight at once
-    constexpr int NSTG = DMA ? 1 : STAGE_MAX;
-    const int units = use_lds && !DMA ? ux_n * (hb >> 1) : 0;
-    uint4 y0w[NSTG], y1w[NSTG], uvw[NSTG];
-    int off_y[NSTG], off_c[NSTG];  // byte offsets of the block in the two boxes (off_y | ZERO_BLOCK: outside the source); -1 = no block
-    constexpr int ZERO_BLOCK = 1 << 24;
-    if constexpr (!DMA) {
-        if (use_lds) {
-            const float rn = __builtin_amdgcn_rcpf((float)ux_n);
-            int uy = (int)((float)tid * rn), ux = tid - uy * ux_n;  // divmod(tid, ux_n): the float quotient is off by at most one
-            if (ux < 0) ux += ux_n, uy--;
-            if (ux >= ux_n) ux -= ux_n, uy++;
-            int sy_ = (int)(256.0f * rn), sx_ = 256 - sy_ * ux_n;   // uniform: divmod(256, ux_n)
-            if (sx_ < 0) sx_ += ux_n, sy_--;
-            if (sx_ >= ux_n) sx_ -= ux_n, sy_++;
-            const uint32_t pitch_y = (uint32_t)a.pitch_y, pitch_uv = (uint32_t)a.pitch_uv;  // < 2^24, frame < 4 GiB (host check)
-            const int sw_al = a.sw & ~(BW - 1);
-#pragma unroll
-            for (int it = 0; it < STAGE_MAX; it++) {
-                if (it > 0 && units <= it * 256) {  // uniform: most boxes have fewer than 256 blocks
-                    y0w[it] = y1w[it] = uvw[it] = uint4(), off_y[it] = off_c[it] = -1;
-                    continue;
-                }
-                // a thread without a block in this trip, or with a block outside the source (the black border), loads from the
-                // nearest block inside; neither uses what it loaded
-                const bool valid = tid + it * 256 < units;
-                const int gx = bx0 + BW * ux, gy = by0 + 2 * uy;
-                const bool inside = (uint32_t)gx < (uint32_t)sw_al && (uint32_t)gy < (uint32_t)a.sh;
-                const uint32_t cx = (uint32_t)min(max(gx, 0), sw_al - BW), cy = (uint32_t)min(max(gy, 0), a.sh - 2);
-                const uint32_t oy = __umul24(cy, pitch_y) + cx * BPS, ouv = __umul24(cy >> 1, pitch_uv) + cx * BPS;
-                y0w[it] = *reinterpret_cast<const uint4 *>(a.y + oy);
-                y1w[it] = *reinterpret_cast<const uint4 *>(a.y + (oy + pitch_y));
-                uvw[it] = *reinterpret_cast<const uint4 *>(a.uv + ouv);
-                off_y[it] = valid ? (__mul24(2 * uy, pw) + BWB * ux) | (inside ? 0 : ZERO_BLOCK) : -1;
-                off_c[it] = luma_bytes + __mul24(uy, pw) + BWB * ux;
-                ux += sx_, uy += sy_;
-                if (ux >= ux_n) ux -= ux_n, uy++;
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < STAGE_MAX; it++) y0w[it] = y1w[it] = uvw[it] = uint4(), off_y[it] = off_c[it] = -1;
-        }
-    }
-
     // ---- map: RW exact evaluations per thread, and the chroma positions of the even rows (vstab_warp_tile.hpp).  The rounding constants
     // carry the origin of the staged box (FOLD): the registers hold positions RELATIVE to the box, in 1/32 pixel -------------------------
     int qxb[RW], qyb[RW], qcx[RW / 2], qcy[RW / 2];
@@ -252,35 +235,14 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
 #pragma unroll
     for (int j = 0; j < RW / 2; j++) asm volatile("" : "+v"(qcx[j]), "+v"(qcy[j]));
 
-    // ---- stage (16-bit samples): the loaded blocks go to LDS reduced to their ten significant bits ------------------------
-    if (!DMA && use_lds) {
-#pragma unroll
-        for (int it = 0; it < NSTG; it++) {
-            if (off_y[it] >= ZERO_BLOCK) {
-                uint8_t *d = tile + (off_y[it] - ZERO_BLOCK);
-                const uint4 ky = make_uint4(P::BLACK_Y_DWORD, P::BLACK_Y_DWORD, P::BLACK_Y_DWORD, P::BLACK_Y_DWORD);
-                *reinterpret_cast<uint4 *>(d) = ky, *reinterpret_cast<uint4 *>(d + pw) = ky;
-                *reinterpret_cast<uint4 *>(tile + off_c[it]) = make_uint4(P::BLACK_C_DWORD, P::BLACK_C_DWORD, P::BLACK_C_DWORD, P::BLACK_C_DWORD);
-            } else if (off_y[it] >= 0) {
-                uint8_t *d = tile + off_y[it];
-                if constexpr (DEPTH == 10) {
-                    auto sig = [](uint4 v) { return make_uint4((v.x >> 6) & 0x03ff03ffu, (v.y >> 6) & 0x03ff03ffu, (v.z >> 6) & 0x03ff03ffu, (v.w >> 6) & 0x03ff03ffu); };
-                    *reinterpret_cast<uint4 *>(d) = sig(y0w[it]), *reinterpret_cast<uint4 *>(d + pw) = sig(y1w[it]);
-                    *reinterpret_cast<uint4 *>(tile + off_c[it]) = sig(uvw[it]);
-                } else {
-                    *reinterpret_cast<uint4 *>(d) = y0w[it], *reinterpret_cast<uint4 *>(d + pw) = y1w[it];
-                    *reinterpret_cast<uint4 *>(tile + off_c[it]) = uvw[it];
-                }
-            }
-        }
-    }
     __syncthreads();
 
     // ---- sample + blend: luma.  Results leave this block SCALED: out[j] = 64 * (value of the blend) + 32768 for 8-bit samples (the byte is
-    // bits 16..23: ds_write_b8_d16_hi stores it without a shift), the sample value itself for 16-bit samples ---------------------------
+    // bits 16..23: ds_write_b8_d16_hi stores it without a shift); 16-bit samples: outw[j / 2] = the P010 words of rows j and j + 1 ------
     const bool col_live = x < a.dw;
     constexpr int OSH = DEPTH == 10 ? 0 : 16;   // where the result sits in out[] / cu[] / cv[]
     int out[RW];
+    uint32_t outw[(RW + 1) / 2];                // (16-bit samples)
     {
         // every footprint of the wave inside the staged box?  relative positions: 0 <= X and X + 1 <= wb - 1, i.e. QB <= q < QB + 32 * (wb - 1)
         int mnx = qxb[0], mxx = qxb[0], mny = qyb[0], mxy = qyb[0];
@@ -291,7 +253,7 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
 #ifdef VSTAB_DEV
         if (ta.ablate & 2) {  // timing only: no taps, no blend
 #pragma unroll
-            for (int j = 0; j < RW; j++) out[j] = qxb[j] ^ qyb[j];
+            for (int j = 0; j < RW; j++) out[j] = qxb[j] ^ qyb[j], outw[j / 2] = (uint32_t)(qxb[j] ^ qyb[j]);
         } else
 #endif
         if (!__builtin_amdgcn_ballot_w64(outside_box)) {
@@ -317,17 +279,36 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
                         t0[j] = (uint32_t)u[0] | ((uint32_t)u[1] << 16), t1[j] = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
                     }
                 }
+                if constexpr (DEPTH == 10) {
+                    // rows j and j + 1 together: their words leave as one register
 #pragma unroll
-                for (int j = 0; j < TG; j++) {
-                    const uint32_t fx = (uint32_t)qxb[j0 + j] & 31u, fy = (uint32_t)qyb[j0 + j] & 31u;
-                    if constexpr (DEPTH == 10 && BLEND == VSTAB_BLEND_FP16) {
-                        out[j0 + j] = blend4<DEPTH, BLEND>((int)(t0[j] & 0xffffu), (int)(t0[j] >> 16), (int)(t1[j] & 0xffffu), (int)(t1[j] >> 16), (int)fx, (int)fy);
-                    } else if constexpr (DEPTH == 10) {
-                        const uint32_t wx = fx * 65535u + 32u;  // (32 - fx) | fx << 16
-                        const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, t0[j]), __builtin_bit_cast(u16x2, wx), 0u, false);
-                        const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, t1[j]), __builtin_bit_cast(u16x2, wx), 0u, false);
-                        out[j0 + j] = lerp_rows(h0, h1, fy);
-                    } else {
+                    for (int j = 0; j < TG; j += 2) {
+                        const uint32_t qa = (uint32_t)qxb[j0 + j], qb = (uint32_t)qxb[j0 + j + 1], ra = (uint32_t)qyb[j0 + j], rb = (uint32_t)qyb[j0 + j + 1];
+                        uint32_t v2;
+                        if constexpr (BLEND == VSTAB_BLEND_FP16) {
+                            // tap 00 of both samples in one register, tap 01 in the next, ..: the blend runs two samples wide
+                            const uint32_t p00 = sig10_x2(__builtin_amdgcn_perm(t0[j + 1], t0[j], 0x05040100u)), p01 = sig10_x2(__builtin_amdgcn_perm(t0[j + 1], t0[j], 0x07060302u));
+                            const uint32_t p10 = sig10_x2(__builtin_amdgcn_perm(t1[j + 1], t1[j], 0x05040100u)), p11 = sig10_x2(__builtin_amdgcn_perm(t1[j + 1], t1[j], 0x07060302u));
+                            const uint32_t fx2 = __builtin_amdgcn_perm(qb, qa, 0x05040100u) & 0x001f001fu, fy2 = __builtin_amdgcn_perm(rb, ra, 0x05040100u) & 0x001f001fu;
+                            v2 = blend10h_x2(half_of10_x2(p00), half_of10_x2(p01), half_of10_x2(p10), half_of10_x2(p11), frac_half_x2(fx2), frac_half_x2(fy2));
+                        } else {
+                            uint32_t v[2];
+#pragma unroll
+                            for (int k = 0; k < 2; k++) {
+                                const uint32_t fx = (k ? qb : qa) & 31u, fy = (k ? rb : ra) & 31u;
+                                const uint32_t wx = fx * 65535u + 32u;  // (32 - fx) | fx << 16
+                                const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, sig10_x2(t0[j + k])), __builtin_bit_cast(u16x2, wx), 0u, false);
+                                const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, sig10_x2(t1[j + k])), __builtin_bit_cast(u16x2, wx), 0u, false);
+                                v[k] = (uint32_t)lerp_rows(h0, h1, fy);
+                            }
+                            v2 = v[0] | (v[1] << 16);
+                        }
+                        outw[(j0 + j) / 2] = v2 << 6;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TG; j++) {
+                        const uint32_t fx = (uint32_t)qxb[j0 + j] & 31u, fy = (uint32_t)qyb[j0 + j] & 31u;
                         out[j0 + j] = (int)blend8_scaled(t0[j], t1[j], fx * 262140u + 128u, fy);  // 4 (32 - fx) at byte 0, 4 fx at byte 2
                     }
                 }
@@ -343,12 +324,17 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
 #pragma unroll
                 for (int k = 0; k < RW; k++) out[k] = j == k ? v : out[k];
             }
+            if constexpr (DEPTH == 10) {
+#pragma unroll
+                for (int k = 0; k < RW; k += 2) outw[k / 2] = ((uint32_t)out[k] | ((uint32_t)out[k + 1] << 16)) << 6;
+            }
         }
     }
 
     // ---- sample + blend: chroma.  Lane pair (2k, 2k + 1) shares chroma column k; the even lane holds its map entries for the even
     // rows j = 0, 2, ..: the even lane keeps rows j = 4 s, the odd lane takes rows j = 4 s + 2 (chroma rows 2 s and 2 s + 1) -------------
     int cu[NS], cv[NS];
+    uint32_t cw[NS];  // (16-bit samples) the pair's P010 words, U | V << 16
     {
         int ccx[NS], ccy[NS];
         const bool odd = lane & 1;
@@ -367,7 +353,7 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
 #ifdef VSTAB_DEV
         if (ta.ablate & 4) {  // timing only: no chroma taps, no blend
 #pragma unroll
-            for (int s = 0; s < NS; s++) cu[s] = ccx[s], cv[s] = ccy[s];
+            for (int s = 0; s < NS; s++) cu[s] = ccx[s], cv[s] = ccy[s], cw[s] = (uint32_t)(ccx[s] ^ ccy[s]);
         } else
 #endif
         if (!__builtin_amdgcn_ballot_w64(outside_box)) {
@@ -382,9 +368,19 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
                 if constexpr (DEPTH == 10) {
                     // (U0 | V0 << 16, U1 | V1 << 16) of both rows
                     const LdsU32 *pt = reinterpret_cast<const LdsU32 *>(ctile + ad), *pb = reinterpret_cast<const LdsU32 *>(ctile + (ad + (uint32_t)pw));
-                    const uint32_t a0 = pt[0], a1 = pt[1], b0 = pb[0], b1 = pb[1];
-                    cu[s] = blend4<DEPTH, BLEND>((int)(a0 & 0xffffu), (int)(a1 & 0xffffu), (int)(b0 & 0xffffu), (int)(b1 & 0xffffu), (int)fx, (int)fy);
-                    cv[s] = blend4<DEPTH, BLEND>((int)(a0 >> 16), (int)(a1 >> 16), (int)(b0 >> 16), (int)(b1 >> 16), (int)fx, (int)fy);
+                    const uint32_t a0 = sig10_x2(pt[0]), a1 = sig10_x2(pt[1]), b0 = sig10_x2(pb[0]), b1 = sig10_x2(pb[1]);
+                    uint32_t v2;
+                    if constexpr (BLEND == VSTAB_BLEND_FP16) {
+                        // U and V side by side as they lie in memory: the blend runs on the pair
+                        v2 = blend10h_x2(half_of10_x2(a0), half_of10_x2(a1), half_of10_x2(b0), half_of10_x2(b1), frac_half_x2(fx * 0x10001u), frac_half_x2(fy * 0x10001u));
+                    } else {
+                        const u16x2 wx = __builtin_bit_cast(u16x2, fx * 65535u + 32u);  // (32 - fx) | fx << 16
+                        auto row = [&](uint32_t l, uint32_t r, uint32_t sel) { return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(r, l, sel)), wx, 0u, false); };
+                        const uint32_t u = (uint32_t)lerp_rows(row(a0, a1, 0x05040100u), row(b0, b1, 0x05040100u), fy);
+                        const uint32_t v = (uint32_t)lerp_rows(row(a0, a1, 0x07060302u), row(b0, b1, 0x07060302u), fy);
+                        v2 = u | (v << 16);
+                    }
+                    cw[s] = v2 << 6;
                 } else {
                     const LdsU16 *pt = reinterpret_cast<const LdsU16 *>(ctile + ad), *pb = reinterpret_cast<const LdsU16 *>(ctile + (ad + (uint32_t)pw));
                     const uint32_t tt = (uint32_t)pt[0] | ((uint32_t)pt[1] << 16), tb = (uint32_t)pb[0] | ((uint32_t)pb[1] << 16);  // bytes U0 V0 U1 V1
@@ -403,6 +399,10 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
 #pragma unroll
                 for (int k = 0; k < NS; k++) cu[k] = s == k ? u : cu[k], cv[k] = s == k ? v : cv[k];
             }
+            if constexpr (DEPTH == 10) {
+#pragma unroll
+                for (int k = 0; k < NS; k++) cw[k] = ((uint32_t)cu[k] | ((uint32_t)cv[k] << 16)) << 6;
+            }
         }
     }
 
@@ -411,16 +411,15 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
     if (ta.ablate & 8) {  // timing only: no stores
         int acc = 0;
 #pragma unroll
-        for (int j = 0; j < RW; j++) acc ^= out[j];
+        for (int j = 0; j < RW; j++) acc ^= DEPTH == 10 ? (int)outw[j / 2] : out[j];
 #pragma unroll
-        for (int s = 0; s < NS; s++) acc ^= cu[s] ^ cv[s];
+        for (int s = 0; s < NS; s++) acc ^= DEPTH == 10 ? (int)cw[s] : cu[s] ^ cv[s];
         if (acc == 0x12345678) a.dst[0] = 1;
         return true;
     }
 #endif
     const int yw = y0 + wave * RW;                      // first luma row of this wave (even)
     const int ncols = min(64, a.dw - x0);               // > 0
-    constexpr int SH = DEPTH == 10 ? 6 : 0;             // P010 words carry the value at the top
     if (ta.dst_vec_ok && ncols == 64 && yw + RW <= a.dh) {
         uint8_t *const scr = scratch + wave * P::SCRATCH_PER_WAVE;
         uint8_t *const scr_c = scr + RW * 64 * BPS;
@@ -428,14 +427,14 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
             uint8_t *w = scr + lane * BPS;
 #pragma unroll
             for (int j = 0; j < RW; j++) {
-                if constexpr (DEPTH == 10) *reinterpret_cast<u16_alias *>(w + j * 128) = (uint16_t)(out[j] << SH);
+                if constexpr (DEPTH == 10) *reinterpret_cast<u16_alias *>(w + j * 128) = (uint16_t)(j & 1 ? outw[j / 2] >> 16 : outw[j / 2]);  // (ds_write_b16, _d16_hi)
                 else w[j * 64] = (uint8_t)((uint32_t)out[j] >> 16);  // (ds_write_b8_d16_hi)
             }
             uint8_t *wc = scr_c + (lane & 1) * 64 * BPS + (lane >> 1) * 2 * BPS;  // chroma row (lane & 1) + 2 s, pair lane >> 1
             if (CR > 1 || !(lane & 1)) {
 #pragma unroll
                 for (int s = 0; s < NS; s++) {
-                    if constexpr (DEPTH == 10) *reinterpret_cast<u32_alias *>(wc + s * 256) = (uint32_t)(cu[s] << SH) | ((uint32_t)(cv[s] << SH) << 16);
+                    if constexpr (DEPTH == 10) *reinterpret_cast<u32_alias *>(wc + s * 256) = cw[s];
                     else *reinterpret_cast<u16_alias *>(wc + s * 128) = (uint16_t)__builtin_amdgcn_perm((uint32_t)cv[s], (uint32_t)cu[s], 0x0c0c0602u);  // U | V << 8 from bits 16..23
                 }
             }
@@ -458,8 +457,10 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
             const int y = yw + j;
             if (col_live && y < a.dh) {
                 uint8_t *o = a.dst + ((size_t)(uint32_t)y * a.pitch_dst + (uint32_t)x * BPS);
-                if constexpr (DEPTH == 10) o[0] = (uint8_t)((out[j] << SH) & 255), o[1] = (uint8_t)((out[j] << SH) >> 8);
-                else o[0] = (uint8_t)((uint32_t)out[j] >> 16);
+                if constexpr (DEPTH == 10) {
+                    const uint32_t wd = j & 1 ? outw[j / 2] >> 16 : outw[j / 2];
+                    o[0] = (uint8_t)(wd & 255u), o[1] = (uint8_t)(wd >> 8);
+                } else o[0] = (uint8_t)((uint32_t)out[j] >> 16);
             }
         }
         const int xc = x0 + (lane & ~1);  // the luma column this lane's chroma pairs belong to
@@ -468,9 +469,8 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
             const int y = yw + 2 * ((lane & 1) + 2 * s);  // the luma row
             if (xc < a.dw && y < a.dh && (lane & 1) + 2 * s < CR) {
                 uint8_t *o = a.dst_uv + ((size_t)(uint32_t)(y >> 1) * a.pitch_dst_uv + (uint32_t)xc * BPS);
-                const uint32_t u = (uint32_t)cu[s] << SH, v = (uint32_t)cv[s] << SH;
-                if constexpr (DEPTH == 10) o[0] = u & 255, o[1] = u >> 8, o[2] = v & 255, o[3] = v >> 8;
-                else o[0] = (uint8_t)(u >> 16), o[1] = (uint8_t)(v >> 16);
+                if constexpr (DEPTH == 10) o[0] = (uint8_t)cw[s], o[1] = (uint8_t)(cw[s] >> 8), o[2] = (uint8_t)(cw[s] >> 16), o[3] = (uint8_t)(cw[s] >> 24);
+                else o[0] = (uint8_t)((uint32_t)cu[s] >> 16), o[1] = (uint8_t)((uint32_t)cv[s] >> 16);
             }
         }
     }
