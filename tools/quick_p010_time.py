@@ -5,7 +5,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np, torch
 import oracle
-vs = importlib.import_module("video-annotator_amd")
+if os.environ.get("QDEV"):   # QDEV=1: the development build (tools/dev/libvstab_dev.so) and its VSTAB_PLANAR_* switches
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import devlib
+    vs = devlib.load()
+else:
+    vs = importlib.import_module("video-annotator_amd")
+only = os.environ.get("QONLY")   # "planar" / "bgr16": that operator only
 w, h = 3840, 2160
 K = oracle.get_preset_camera(4, w, h)
 Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
@@ -24,6 +30,8 @@ def run(planar, i, rot, blend):
     else:
         vs.warp_p010(ys[i], us[i], p, cw, ch, rot, mode, blend, out=outs[i])
 for planar in (False, True):
+  if only and only != ("planar" if planar else "bgr16"):
+      continue
   for name, blend, rot in (("exact", 0, None), ("fp16", 1, None), ("exact+rs", 0, rb), ("fp16+rs", 1, rb)):
     name = ("planar " if planar else "bgr16  ") + name
     for i in range(8):
@@ -31,7 +39,7 @@ for planar in (False, True):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    n = 80
+    n = 400
     for i in range(n):
         run(planar, i % 8, rot, blend)
     e1.record(); torch.cuda.synchronize()

@@ -270,8 +270,9 @@ __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *
                     // t = (tap X) | (tap X + 1) << 16 of the upper and of the lower row
                     if constexpr (DEPTH == 10) {
                         asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ad) : "v"(yr), "s"(pw), "v"(xr << 1));
-                        const LdsU16 *u = reinterpret_cast<const LdsU16 *>((__attribute__((address_space(3))) uint8_t *)tile + ad);
-                        const LdsU16 *l = reinterpret_cast<const LdsU16 *>((__attribute__((address_space(3))) uint8_t *)tile + (ad + (uint32_t)pw));
+                        // (volatile: left alone, the compiler joins the two reads of a row into ONE ds_read_b32 at a 2-byte boundary -- 64 cycles)
+                        const volatile LdsU16 *u = reinterpret_cast<const volatile LdsU16 *>((__attribute__((address_space(3))) uint8_t *)tile + ad);
+                        const volatile LdsU16 *l = reinterpret_cast<const volatile LdsU16 *>((__attribute__((address_space(3))) uint8_t *)tile + (ad + (uint32_t)pw));
                         t0[j] = (uint32_t)u[0] | ((uint32_t)u[1] << 16), t1[j] = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
                     } else {
                         asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ad) : "v"(yr), "s"(pw), "v"(xr));
@@ -527,7 +528,8 @@ vstab_status launch_warp_planar(const WarpArgs &a, const float params[17], int m
 #ifdef VSTAB_DEV
     if (const char *e = getenv("VSTAB_PLANAR_RWB")) rwb = atoi(e) == 4 ? 4 : 8;
 #endif
-    int lds_kb = (rwb == 8 ? 24 : 14) * bps;
+    // (10 bits, 4K alone, binary16 blend: 48 KB -- the 8-bit kernel's box, three workgroups per CU -- 43.1 us; 40 KB, four: 37.0; 32 KB, five: 36.9)
+    int lds_kb = rwb == 8 ? (bps == 2 ? 40 : 24) : 14 * bps;
     // workgroups a CU holds: by LDS, and by registers (the 64 x 32-tile kernels take up to 72: seven waves per SIMD; the others eight)
     const int resident = std::min({160 / lds_kb, rwb == 8 ? 7 : 8, 8});
     double tail_rounds = (double)div_up(a.dw, 64) * div_up(a.dh, 4 * rwb) > 256.0 * resident ? 0.25 : 0.0;
