@@ -391,7 +391,8 @@ typedef struct vstab_frame {
                           until the next callback -- the library then waits for its copy of this frame to finish before
                           it calls upstream again (a decoder that recycles one output surface).  Ref-counted or pooled
                           frames can say how deep the pool is and the wait disappears from the frame loop.  From
-                          smooth_radius + 18 on, the planes are not copied at all but read in place by the tracker and
+                          smooth_radius + read_ahead + 6 on (smooth_radius + 18 with the default read-ahead of twelve), the
+                          planes are not copied at all but read in place by the tracker and
                           by the warp (which runs on vstab_config.stream): the callback at which the promise runs out
                           first waits, on the host, for that warp to finish.  1 << 29 or more: never waited for.
                           That threshold is the 8-BIT rule.  16-bit (P010) frames are always narrowed into library

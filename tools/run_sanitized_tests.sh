@@ -1,11 +1,11 @@
 #!/bin/bash
 # The CPU test suite (-m "not gpu") over the sanitizer build of libvstab.so: host code under AddressSanitizer + UBSan (make san).
-# CPU box only -- GPU sanitizers are not available on the pool and this script never runs there.  Writes profiles/r04_sanitizer_cpu_suite.txt.
+# CPU box only -- GPU sanitizers are not available on the pool and this script never runs there.  Writes profiles/r05_sanitizer_cpu_suite.txt (or the file given as first argument).
 set -o pipefail
 cd "$(dirname "$0")/.."
 make -C video-annotator_amd san -j6 > /dev/null || exit 1
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
-LOG=${1:-profiles/r04_sanitizer_cpu_suite.txt}
+LOG=${1:-profiles/r05_sanitizer_cpu_suite.txt}
 {
   echo "# CPU suite over tools/dev/libvstab_san.so (host objects: -fsanitize=address,undefined -fno-sanitize-recover=undefined; device code unsanitized)"
   echo "# LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1"
