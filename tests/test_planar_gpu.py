@@ -188,6 +188,49 @@ def test_planar_p010_both_blends_per_row_and_default_arithmetic(vs, cuda):
     assert np.array_equal(gy, ey) and np.array_equal(guv, euv)
 
 
+def test_planar_p010_gather_path_extreme_boxes_and_unaligned_planes(vs, cuda):
+    """The 10-bit kernel off its fast path: boxes over the LDS budget (split tiles, then samples straight from global memory), tiles wholly
+    outside the source, planes the 16-byte LDS-DMA cannot take (base offset / pitch not multiples of 16 bytes); both blends."""
+    import torch
+    w, h = 1280, 720
+    y, uv, _, _ = p010_frame(21, w, h)
+    K = oracle.get_preset_camera(4, w, h)
+    for scale, rv, (dw, dh), blend in [(0.25, (0.0, 0.0, 0.0), (448, 252), 1), (1.0, (0.0, 0.0, 1.5708), (1100, 700), 0), (3.0, (0.01, 0.0, 0.0), (1500, 900), 1),
+                                       (1.0, (0.9, 0.0, 0.0), (800, 450), 0)]:
+        Ko, _ = oracle.get_output_camera(K, w, h, scale=scale)
+        p = oracle.map_params(K, Ko, oracle.rodrigues(rv))
+        gy, guv = run10(vs, cuda, y, uv, p, dw, dh, vs.MAP_CREATEMAP_CL, blend)
+        ey, euv = oracle.warp_p010_planar(y, uv, p, dw, dh, 0, None, blend)
+        assert np.array_equal(gy, ey) and np.array_equal(guv, euv), (scale, rv, blend)
+    for (w, h, off, pitch) in [(328, 180, 0, 328), (320, 180, 4, 344), (320, 180, 2, 322)]:   # off / pitch in 16-bit samples (chroma pairs stay 4-byte aligned)
+        y, uv, _, _ = p010_frame(31 + off, w, h)
+        p, dw, dh, _, _ = cams(w, h, (0.02, -0.03, 0.01))
+        rows = h * 3 // 2
+        buf = torch.zeros(rows * pitch + 64, dtype=torch.int16, device=cuda)
+        view = buf[off:off + rows * pitch].view(rows, pitch)[:, :w]
+        view.copy_(dev(np.concatenate([y, uv]).view(np.int16), cuda))
+        for blend in (0, 1):
+            yb, cb, yv, cv = planes(vs, cuda, dw, dh, pad=6, dtype=torch.int16)
+            vs.warp_p010_planar(view[:h], view[h:], p, dw, dh, None, vs.MAP_CREATEMAP_CL, blend, out_y=yv, out_uv=cv)
+            ey, euv = oracle.warp_p010_planar(y, uv, p, dw, dh, 0, None, blend)
+            assert np.array_equal(yv.cpu().numpy().view(np.uint16), ey) and np.array_equal(cv.cpu().numpy().view(np.uint16), euv), (w, off, pitch, blend)
+
+
+def test_planar_p010_4k_config_5_shape(vs, cuda):
+    """BASELINE config 5's operator at full size with P010 planes out: binary16 blend, a rotation per output row, the reference kernel's
+    arithmetic row by row (tests/expect.py); and the exact blend in the CPU-reproducible arithmetic against the oracle."""
+    w, h = 3840, 2160
+    y, uv, _, _ = p010_frame(5, w, h)
+    p, dw, dh, K, Ko = cams(w, h, (0.004, -0.002, 0.001))
+    rb = oracle.map_params(K, Ko, oracle.rodrigues((0.006, -0.001, 0.002)))[8:]
+    gy, guv = run10(vs, cuda, y, uv, p, dw, dh, vs.MAP_CREATEMAP_CL_OPENCL, 1, rb)
+    ey, euv = expect.warp_p010_planar(y, uv, p, dw, dh, rb, 1, expect.OPENCL)
+    assert np.array_equal(gy, ey) and np.array_equal(guv, euv), (int((gy != ey).sum()), int((guv != euv).sum()))
+    gy, guv = run10(vs, cuda, y, uv, p, dw, dh, vs.MAP_CREATEMAP_CL, 0)
+    ey, euv = oracle.warp_p010_planar(y, uv, p, dw, dh, 0, None, 0)
+    assert np.array_equal(gy, ey) and np.array_equal(guv, euv)
+
+
 def test_planar_argument_errors(vs, cuda):
     import torch
     f = dev(synth.nv12(1, 64, 36), cuda)
