@@ -1288,3 +1288,31 @@ def test_bench_rccl_branch_runs_on_one_rank():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["parity_check"] == "ok" and line["config"]["clips"] == 1 and line["value"] > 0
     assert line["collectives"] == "nccl"
+
+
+@pytest.mark.gpu
+def test_bench_line_of_the_plane_wise_outputs():
+    """bench.py --out-format nv12-planar / p010-planar (short runs): one JSON line, the roofline object priced on the PLANE-WISE kernel's
+    algorithmic bytes (source planes + output planes, no BGR frame), the emitted frame checked against the plane-wise checker, per-step
+    durations and the host cost in the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for workload, fmt, bytes_per_launch in (("1080p", "nv12-planar", 1920 * 1080 * 3 // 2 + 1759 * 998 + 2 * 880 * 499),
+                                            ("4k-p010", "p010-planar", 2 * (3840 * 2160 * 3 // 2 + 3524 * 1999 + 2 * 1762 * 1000))):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--out-format", fmt, "--steps", "3", "--warmup", "1",
+                            "--batch", "16", "--preroll", "80", "--fixed-preroll", "--ring", "16", "--no-cpu-baseline"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
+        line = json.loads(lines[0])
+        assert line["parity_check"] == "ok" and line["value"] > 0 and line["unit"] == "frames/s", line
+        roof = line["roofline"]
+        assert "k_warp_planar" in roof["kernel"] and roof["bound"] == "hbm" and roof["unit"] == "GB/s", roof
+        assert roof["algorithmic_bytes_per_launch"] == bytes_per_launch, (roof["algorithmic_bytes_per_launch"], bytes_per_launch)
+        assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+        assert len(line["step_ms"]["all"]) == 3 and line["step_ms"]["min"] <= line["step_ms"]["median"] <= line["step_ms"]["max"]
+        assert line["host"]["cpu_seconds_per_1000_frames"] > 0 and line["host"]["pinned_cpus"] >= 1
