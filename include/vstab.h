@@ -579,6 +579,8 @@ typedef struct vstab_profile {
                             used, once more than 256 are cached and none of the window's frames can still refer to them), mapped now */
     long corner_selections_by_caller, corner_selections_by_helper; /* speculative corner detections (planned key frames) whose corners were
                             selected by the calling thread itself because the helper thread had not woken up / by the helper thread */
+    long epochs_in_turn; /* planned key frames whose detection and tracker launches ran on the second of the handle's two epoch streams, beside
+                            the epoch still being tracked on the first (frames up to 1920 x 1200 with a caller on the default stream; 0 otherwise) */
 } vstab_profile;
 /* level 0 = off, 1 = time every 8th warp launch only (event records are expensive host calls), 2 = every GPU stage */
 VSTAB_API vstab_status vstab_enable_profiling(vstab_handle *h, int level);

@@ -949,7 +949,7 @@ def test_pipeline_degenerate_clips(vs, cuda):
 
 
 @pytest.mark.parametrize("env", [{}, {"VSTAB_LK_SEGMENT": "1"}, {"VSTAB_LK_SEGMENT": "3", "VSTAB_PREFETCH": "2"}, {"VSTAB_PREFETCH": "16", "VSTAB_LK_SEG_TARGET": "8"},
-                                 {"VSTAB_CHAIN_LK": "0", "VSTAB_PREFETCH": "1"}])
+                                 {"VSTAB_CHAIN_LK": "0", "VSTAB_PREFETCH": "1"}, {"VSTAB_EPOCH_OVERLAP": "0"}, {"VSTAB_EPOCH_OVERLAP": "1", "VSTAB_PREFETCH": "16"}])
 def test_every_clip_length_and_radius_against_the_state_machine(vs, cuda, monkeypatch, env):
     """Clips of 1 .. 26 frames (shorter than, equal to and longer than the look-ahead; across the 21-frame key-frame counter) with
     smoothing radii 1, 2, 5 (radius 0 has no reference behaviour: gram_sg divides by zero there), under the launch-ahead settings a handle can be created with (frames per tracker launch, read-ahead depth,
@@ -1018,6 +1018,43 @@ def test_corner_selection_by_the_caller_when_the_helper_thread_wakes_up_late(vs,
     assert [l["key"] for l in stab.frame_log()] == [l["key"] for l in ref_stab.frame_log()]
     late = stab.profile()
     assert late["corner_selections_by_caller"] >= len(keys) and late["corner_selections_by_helper"] == 0, late
+
+
+def test_epochs_in_turn_second_stream_is_used_and_changes_nothing(vs, cuda, monkeypatch):
+    """What follows a planned key frame (its speculative detection, the tracker launch from those corners, the launches chained behind it) depends
+    on nothing tracked before it; for frames up to 1920 x 1200 it runs on the second of the handle's two epoch streams beside the epoch still
+    being tracked (the tracker's chain sets the frame period there).  720p, 110 frames of the bench's clip: the handle's counter says the second
+    stream took epochs, and frames, key frames and per-frame counts are those of the run with everything on one stream (VSTAB_EPOCH_OVERLAP=0)
+    -- and of a run with the deepest read-ahead, where the two chains overlap longest."""
+    import torch
+    import bench
+    w, h, n = 1280, 720, 110
+    K = oracle.get_preset_camera(4, w, h)
+    dev_frames, _ = bench.shaky_ring(torch, cuda, w, h, K, n, seed=7)
+
+    def run():
+        stab = vs.Stabilizer(dev_frames, total=n, smooth_radius=2, seed=4)
+        outs = []
+        while True:
+            o = stab.pull()
+            if o is None:
+                break
+            outs.append(o.cpu().numpy())
+        return stab, outs
+    stab, outs = run()
+    log = [(l["key"], l["n_corners"], l["n_tracked"], l["inliers"]) for l in stab.frame_log()]
+    keys = [k for k, l in enumerate(log) if l[0]]
+    assert len(keys) >= 5, keys
+    assert stab.profile()["epochs_in_turn"] >= 2, stab.profile()          # every other planned key frame, once launches run ahead
+    for env, expect_second in (({"VSTAB_EPOCH_OVERLAP": "0"}, False), ({"VSTAB_PREFETCH": "16"}, True)):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        stab2, outs2 = run()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert (stab2.profile()["epochs_in_turn"] > 0) == expect_second, (env, stab2.profile())
+        assert [(l["key"], l["n_corners"], l["n_tracked"], l["inliers"]) for l in stab2.frame_log()] == log, env
+        assert len(outs2) == len(outs) == n - 1 and all(np.array_equal(a, b) for a, b in zip(outs2, outs)), env
 
 
 def test_pull_into_host_memory_equals_device_pull(vs, cuda, clip):
@@ -1201,7 +1238,9 @@ def test_unplanned_key_frames_drop_the_tracker_launches_enqueued_ahead(vs, cuda,
     assert keys[0] == 20                                        # log index i is frame i + 1: the counter's key frame (frame 21)
     assert sum(24 <= k <= 34 for k in keys) >= 2, keys          # and key frames nobody planned for: into the fade and out of it
     ref = [(l["key"], l["n_corners"], l["n_tracked"], l["inliers"]) for l in log]
-    for env in ({"VSTAB_LK_SEGMENT": "1"}, {"VSTAB_CHAIN_LK": "0"}, {"VSTAB_LK_SEGMENT": "3", "VSTAB_LK_SEG_TARGET": "2"}):
+    # (1080p: planned key frames' detection and tracking alternate between two streams by default -- epochs in turn; "0": one stream)
+    for env in ({"VSTAB_LK_SEGMENT": "1"}, {"VSTAB_CHAIN_LK": "0"}, {"VSTAB_LK_SEGMENT": "3", "VSTAB_LK_SEG_TARGET": "2"}, {"VSTAB_EPOCH_OVERLAP": "0"},
+                {"VSTAB_EPOCH_OVERLAP": "1", "VSTAB_PREFETCH": "16"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         log2 = _bench_shaped_run(vs, cuda, w, h, 5, 64, 3, transform=fade)
@@ -1258,7 +1297,9 @@ def test_bench_four_ranks_share_one_gpu():
     # has to hold for N ranks to fit a host is that a rank's busy CPUs do not grow with N and stay inside the CPUs it is pinned to.
     busy1, busy4 = one["host"]["cpus_busy"], line["host"]["all_ranks_cpus_busy"]
     assert one["host"]["cpu_seconds_per_1000_frames"] > 0 and one["host"]["threads"] >= 4 and one["host"]["pinned_cpus"] == 8
-    assert len(busy4) == 4 and all(0 < b <= 1.5 * busy1 and b <= 8 for b in busy4), (busy1, busy4)
+    # (bound: 1.5 x the single rank's figure, or the four threads of a rank that work at all -- frame loop, estimate worker, corner-selection
+    #  helper, runtime -- whichever is larger: a single rank that waits less spins less, 1.5 - 2.8 busy CPUs from run to run)
+    assert len(busy4) == 4 and all(0 < b <= max(1.5 * busy1, 4.0) and b <= 8 for b in busy4), (busy1, busy4)
     sets = []
     for txt in line["rank_cpus_all"]:
         first, last = (int(v) for v in txt.split(" ")[0].split("-"))

@@ -73,7 +73,7 @@ class Profile(_c.Structure):  # vstab_profile
                 ("host_corners_ms", _d), ("host_track_wait_ms", _d), ("host_estimate_ms", _d), ("host_smooth_ms", _d),
                 ("warp_launches", _c.c_long), ("warp_timed", _c.c_long),
                 ("dmabuf_imports", _c.c_long), ("dmabuf_evictions", _c.c_long), ("dmabuf_cached", _c.c_long),
-                ("corner_selections_by_caller", _c.c_long), ("corner_selections_by_helper", _c.c_long)]
+                ("corner_selections_by_caller", _c.c_long), ("corner_selections_by_helper", _c.c_long), ("epochs_in_turn", _c.c_long)]
 
 
 SMOOTHER_SG, SMOOTHER_KALMAN, SMOOTHER_NONE, SMOOTHER_FIXED = 0, 1, 2, 3

@@ -685,6 +685,7 @@ struct vstab_handle {
             if (s.copied) (void)hipEventDestroy(s.copied);
         for (hipEvent_t e : warp_events)
             if (e) (void)hipEventDestroy(e);
+        if (epoch_tail) (void)hipEventDestroy(epoch_tail);
         for (hipStream_t s : {dstream, pstream, tstream})
             if (s) (void)hipStreamDestroy(s);
         dmabufs.clear([](hipExternalMemory_t &e) { (void)hipDestroyExternalMemory(e); });
@@ -869,6 +870,7 @@ struct vstab_handle {
         int n = 0;                 // frames covered
         bool key = false;          // starts from fresh corners detected on frame first - 1 (a planned key frame); else chained
         long last_key_after = -1;  // what last_key will be once the host has passed this segment
+        int stream = 0;            // epoch stream it was enqueued on (vstab_handle::estream)
         std::vector<float> corners;  // key segments: the corners it was launched with
         Tracker::Launch launch;
     };
@@ -888,6 +890,18 @@ struct vstab_handle {
     PinnedBuf marker_pts;           // vstab_config.debug: rotating sets of marker centres, read by the kernel in place
     unsigned marker_set = 0;
     hipStream_t dstream = nullptr;  // speculative corner detection (137 us of kernels every 21st frame) beside everything else
+    // EPOCHS IN TURN (when dstream exists): what follows a planned key frame -- its speculative detection, the tracker segment launched from
+    // those corners and the segments chained behind it -- depends on nothing tracked before it, so it runs on the OTHER of the two streams
+    // {tstream, dstream} than the epoch still being tracked: two dependent chains side by side for as long as the read-ahead reaches into
+    // the next epoch.  The tracker's chain sets the frame period at 1080p (profiles/r05_epochs_in_turn.txt).  VSTAB_EPOCH_OVERLAP=0 (read
+    // once, in vstab_create) keeps everything on tstream.
+    bool epoch_overlap = false;
+    int epoch_stream = 0;            // stream (0 = tstream, 1 = dstream) of the most recently launched epoch
+    int spec_stream = 1;             // stream the pending speculative detection was enqueued on
+    int inflight_stream = 0;         // stream of the launch whose results the host waits for next
+    long epochs_on_second_stream = 0;
+    hipEvent_t epoch_tail = nullptr; // a fresh start waits for what is still queued on the other epoch stream (dropped launches precede their replacement)
+    hipStream_t estream(int i) const { return i && dstream ? dstream : tstream; }
     // DMA-BUF objects imported so far (vstab_frame.mem == VSTAB_MEM_DMABUF), keyed by the inode of the object
     DmaBufCache<hipExternalMemory_t> dmabufs;  // vstab_hostlogic.hpp; VSTAB_DMABUF_CACHE=n (tests) shrinks its 256 entries
     bool chain_lk = true;        // VSTAB_CHAIN_LK=0: no launches ahead of the host's frame (one frame per launch, on demand)
@@ -1209,6 +1223,7 @@ static vstab_status prefetch_next(vstab_handle *H) {
         if (debug_spec()) std::fprintf(stderr, "spec launch for frame %ld (last_key %ld)\n", H->prefetch_count, H->last_key);
         HT t(HostTimers::SPEC_DETECT);
         hipStream_t ds = H->dstream ? H->dstream : H->pstream;
+        if (H->epoch_overlap) H->spec_stream = 1 - H->epoch_stream, ds = H->estream(H->spec_stream);  // the epoch after the newest one enqueued
         // the detector reads the frame's luma plane, nothing else: it waits for the copy into the ring (if there was one), not for the
         // pyramid enqueued behind it -- beside a saturating warp the detection needs most of the read-ahead's lead as it is
         if (ds != H->pstream) {
@@ -1285,18 +1300,19 @@ static vstab_status launch_tracking(vstab_handle *H) {
         };
         // enqueue a segment of n frames from `first` on: from `start` (host points) or chained behind `parent`
         auto launch_segment = [&](long first, int n, bool key, const std::vector<float> *start, const Tracker::Launch *parent, long last_key_after,
-                                  bool timed) -> vstab_status {
+                                  bool timed, int stream_idx) -> vstab_status {
             LkPyramid pyrs[LK_SEG_MAX + 1];
             for (int i = 0; i <= n; i++) pyrs[i] = pyr_of(first - 1 + i);
+            const hipStream_t es = H->estream(stream_idx);
             // copy + pyramid of the segment's frames: they are enqueued in frame order on the prefetch stream, the last one covers all
-            VSTAB_TRY(vstab_handle::wait_if_pending(H->tstream, H->slots[slot_of(first + n - 1)].ingested));
+            VSTAB_TRY(vstab_handle::wait_if_pending(es, H->slots[slot_of(first + n - 1)].ingested));
             vstab_handle::Segment sg;
-            sg.first = first, sg.n = n, sg.key = key, sg.last_key_after = last_key_after;
+            sg.first = first, sg.n = n, sg.key = key, sg.last_key_after = last_key_after, sg.stream = stream_idx;
             if (start) {
                 if (key) sg.corners = *start;
-                VSTAB_TRY(H->tracker.track_launch(pyrs, n, *start, H->tstream, timed, sg.launch));
+                VSTAB_TRY(H->tracker.track_launch(pyrs, n, *start, es, timed, sg.launch));
             } else {
-                VSTAB_TRY(H->tracker.track_launch_chained(pyrs, n, *parent, H->tstream, sg.launch));
+                VSTAB_TRY(H->tracker.track_launch_chained(pyrs, n, *parent, es, sg.launch));  // (behind its parent: the same stream)
             }
             H->segs_launched++, H->seg_frames_launched += n;
             H->segs.push_back(std::move(sg));
@@ -1341,9 +1357,14 @@ static vstab_status launch_tracking(vstab_handle *H) {
             HT t(HostTimers::LK_LAUNCH);
             const long kc = H->last_key + 21;  // the next frame the counter makes a key frame
             const int n = (int)std::max<long>(1, std::min<long>({(long)seg_max, reach - F + 1, kc - F}));
-            VSTAB_TRY(launch_segment(F, n, false, &H->corners, nullptr, H->last_key, H->profiling >= 2));
+            if (H->epoch_overlap) {  // whatever is still queued on the other epoch stream was dropped a moment ago (or is long finished): behind it
+                VSTAB_HIP_TRY(hipEventRecord(H->epoch_tail, H->dstream));
+                VSTAB_HIP_TRY(hipStreamWaitEvent(H->tstream, H->epoch_tail, 0));
+            }
+            H->epoch_stream = 0;
+            VSTAB_TRY(launch_segment(F, n, false, &H->corners, nullptr, H->last_key, H->profiling >= 2, 0));
         }
-        H->inflight_launch = H->segs.front().launch, H->inflight_idx = (int)(F - H->segs.front().first);
+        H->inflight_launch = H->segs.front().launch, H->inflight_idx = (int)(F - H->segs.front().first), H->inflight_stream = H->segs.front().stream;
         H->have_inflight = true;
         // Enqueue further segments as far as the read-ahead reaches: chained behind the last one up to the next key frame the
         // counter half of the rule (:415) predicts, and -- once that key frame's corners (detected speculatively on the frame before
@@ -1365,13 +1386,16 @@ static vstab_status launch_tracking(vstab_handle *H) {
                 std::vector<float> fresh;
                 H->tracker.spec_take(fresh);
                 const int n = (int)std::min<long>({(long)seg_max, avail, 21});
-                VSTAB_TRY(launch_segment(next, n, true, &fresh, nullptr, next - 1, false));
+                const int es = H->epoch_overlap ? H->spec_stream : 0;  // where its detection ran: not the stream of the epoch before it
+                VSTAB_TRY(launch_segment(next, n, true, &fresh, nullptr, next - 1, false, es));
+                H->epoch_stream = es;
+                if (es == 1) H->epochs_on_second_stream++;
                 continue;
             }
             const int n = (int)std::min<long>({(long)seg_max, avail, kc - next});
             // full segments; shorter ones only up to a key frame, or when nothing is enqueued beyond the host's frame
             if (n < H->seg_target && next + n != kc && tail > F) break;
-            VSTAB_TRY(launch_segment(next, n, false, nullptr, &back.launch, back.last_key_after, false));
+            VSTAB_TRY(launch_segment(next, n, false, nullptr, &back.launch, back.last_key_after, false, back.stream));
         }
     }
     H->cur_pyr = pyr;
@@ -1393,7 +1417,7 @@ static vstab_status finish_wait(vstab_handle *H) {
     std::vector<uint8_t> st;
     {
         HostStage hs(&H->prof.host_track_wait_ms);
-        VSTAB_TRY(H->tracker.track_wait(H->inflight_launch, H->inflight_idx, T.prev.size() / 2, nxt, st, H->tstream,
+        VSTAB_TRY(H->tracker.track_wait(H->inflight_launch, H->inflight_idx, T.prev.size() / 2, nxt, st, H->estream(H->inflight_stream),
                                         H->profiling >= 2 ? &H->prof.gpu_lk_ms : nullptr));
     }
     // :261-268 keep pairs with status != 0
@@ -1535,6 +1559,7 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
         // of its own only beside a caller on the default stream; VSTAB_DETECT_STREAM=1 / 0 overrides.
         const char *ds_env = getenv("VSTAB_DETECT_STREAM");
         const bool detect_stream = ds_env ? atoi(ds_env) != 0 : H->stream == nullptr;
+        // (epochs in turn, below: the stream keeps the low priority -- at the tracker's priority the 4K rate lost 1.5 %, the 1080p rate gained nothing)
         if (detect_stream) VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->dstream, hipStreamNonBlocking, lo));
         for (auto &e : H->warp_events) VSTAB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
@@ -1547,6 +1572,16 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     if (f.width <= 0 || f.height <= 0 || (f.width & 1) || (f.height & 1) || f.width > 32767 || f.height > 32767)
         return fail(VSTAB_ERR_INVALID, "vstab_create: frame size must be even and <= 32767");
     H->w = f.width, H->h = f.height;
+    {
+        // Epochs in turn (vstab_handle::epoch_overlap) pay where the tracker's dependent chain is longer than a frame's warp: 1080p + 10 - 13 %
+        // (44.3 -> 49.5 k frames/s); at 4K the warp sets the period and a second tracker chain beside it costs 0.5 %.  Bit-identical either way.
+        // VSTAB_EPOCH_OVERLAP=1 / 0 (development) overrides the size rule.
+        const char *const eo = getenv("VSTAB_EPOCH_OVERLAP");  // (read here, on the caller's thread, like the other launch-shape switches)
+        const int eo_forced = eo ? (atoi(eo) != 0 ? 1 : 0) : -1;
+        const bool small_frame = (long)H->w * H->h <= 1920L * 1200;
+        H->epoch_overlap = H->dstream && cfg->tracking && (eo_forced < 0 ? small_frame : eo_forced == 1);
+        if (H->epoch_overlap) VSTAB_HIP_TRY(hipEventCreateWithFlags(&H->epoch_tail, hipEventDisableTiming));
+    }
     if (cfg->lens_mode == 0) {
         if (!preset_camera(cfg->preset, H->w, H->h, H->Kin)) return fail(VSTAB_ERR_INVALID, "vstab_create: unknown preset");
         output_camera(H->Kin, H->w, H->h, cfg->scale, cfg->crop_borders != 0, cfg->zoom, H->Kout, H->ow, H->oh);
@@ -1844,6 +1879,7 @@ vstab_status vstab_get_profile(vstab_handle *h, vstab_profile *out) {
     h->fold_pending();
     h->prof.dmabuf_imports = h->dmabufs.imports, h->prof.dmabuf_evictions = h->dmabufs.evictions, h->prof.dmabuf_cached = (long)h->dmabufs.size();
     h->prof.corner_selections_by_caller = h->tracker.selections_by_caller(), h->prof.corner_selections_by_helper = h->tracker.selections_by_helper();
+    h->prof.epochs_in_turn = h->epochs_on_second_stream;
     *out = h->prof;
     return VSTAB_OK;
 }
