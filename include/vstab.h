@@ -342,7 +342,8 @@ VSTAB_API vstab_status vstab_gyro_integrate(const vstab_gyro_sample *samples, in
  * for these body rates).  Up to `cap` samples are written to out; *n_out = the number found (call again with a larger buffer if it
  * exceeds cap).  Every GYRO block of the payload is taken, in order.  VSTAB_ERR_INVALID for a payload that is not well formed: an
  * item that runs past its container, a truncated header, nesting deeper than eight levels, a GYRO block that does not have three
- * elements per sample, a SCAL of zero.  Host only; reads nothing outside [payload, payload + n). */
+ * elements per sample, a SCAL of zero or not finite, a packet time stamp or duration that is not finite.  Host only; reads nothing
+ * outside [payload, payload + n). */
 VSTAB_API vstab_status vstab_gpmf_parse_gyro(const void *payload, size_t n, double pkt_ts, double pkt_dur, vstab_gyro_sample *out, int cap,
                                              int *n_out);
 

@@ -96,8 +96,12 @@ def test_malformed_payloads_are_refused_not_read_past(vs):
         with pytest.raises(vs.VstabError) as e:
             vs.gpmf_parse_gyro(b, 0.0, 1.0)
         assert e.value.status == vs.ERR_INVALID, k
-    with pytest.raises(vs.VstabError):
-        vs.gpmf_parse_gyro(good, 0.0, -1.0)
+    for ts, dur in ((0.0, -1.0), (float("nan"), 1.0), (0.0, float("inf")), (float("inf"), 1.0)):   # the packet's span has to be finite, the duration >= 0
+        with pytest.raises(vs.VstabError):
+            vs.gpmf_parse_gyro(good, ts, dur)
+    for scal in (float("nan"), float("inf")):                                       # a divisor that is not a finite number
+        with pytest.raises(vs.VstabError):
+            vs.gpmf_parse_gyro(nest("DEVC", gyro_stream(raw, scal, scal_type="f")), 0.0, 1.0)
     # a sweep of damaged payloads: every prefix, and every single-byte corruption of the header bytes -- each either parses or is
     # refused; nothing crashes and nothing is read beyond the buffer (the sanitizer build runs this test too: tools/run_sanitized_tests.sh)
     rng = np.random.default_rng(3)
@@ -112,6 +116,6 @@ def test_malformed_payloads_are_refused_not_read_past(vs):
             b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
         try:
             got, n = vs.gpmf_parse_gyro(bytes(b), 0.0, 1.0)
-            assert n >= 0 and np.isfinite(got[:, :2]).all()
+            assert n >= 0 and np.isfinite(got).all()   # (integer samples over a finite non-zero divisor: every field finite)
         except vs.VstabError as e:
             assert e.status == vs.ERR_INVALID

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstring>
 
@@ -423,7 +424,8 @@ bool gpmf_walk(const uint8_t *p, size_t n, int depth, GpmfGyroSink &sink) {
                 scal[0] = scal[1] = scal[2] = 1;  // some other stream's scale (GPS5 has five): not a gyro's
             } else {
                 for (int k = 0; k < 3; k++) scal[k] = gpmf_elem(it.data + (count == 3 ? k * es : 0), it.type);
-                if (scal[0] == 0 || scal[1] == 0 || scal[2] == 0) return sink.err = "SCAL of zero", false;
+                for (int k = 0; k < 3; k++)
+                    if (!(std::isfinite(scal[k]) && scal[k] != 0)) return sink.err = "SCAL of zero (or not a finite number)", false;
             }
         } else if (it.key == fourcc('G', 'Y', 'R', 'O')) {
             const int es = gpmf_elem_size(it.type);
@@ -438,6 +440,7 @@ bool gpmf_walk(const uint8_t *p, size_t n, int depth, GpmfGyroSink &sink) {
                     g.end_ts = g.start_ts + sink.dur / it.repeat;
                     g.roll = gpmf_elem(e, it.type) / scal[0], g.pitch = gpmf_elem(e + es, it.type) / scal[1], g.yaw = gpmf_elem(e + 2 * es, it.type) / scal[2];
                 }
+                if (sink.n == INT_MAX) return sink.err = "more samples than an int counts", false;
                 sink.n++;
             }
         }
@@ -452,7 +455,8 @@ using vstab::fail;
 extern "C" vstab_status vstab_gpmf_parse_gyro(const void *payload, size_t n, double pkt_ts, double pkt_dur, vstab_gyro_sample *out, int cap, int *n_out) {
     if (n_out) *n_out = 0;
     if (!payload || !n_out || cap < 0 || (cap > 0 && !out)) return fail(VSTAB_ERR_INVALID, "vstab_gpmf_parse_gyro: null argument");
-    if (!(pkt_dur >= 0) || !(pkt_ts == pkt_ts)) return fail(VSTAB_ERR_INVALID, "vstab_gpmf_parse_gyro: packet duration must be >= 0");
+    if (!std::isfinite(pkt_ts) || !std::isfinite(pkt_dur) || pkt_dur < 0)
+        return fail(VSTAB_ERR_INVALID, "vstab_gpmf_parse_gyro: packet time stamp and duration must be finite, the duration >= 0");
     GpmfGyroSink sink{pkt_ts, pkt_dur, out, cap};
     if (!gpmf_walk(static_cast<const uint8_t *>(payload), n, 0, sink)) return fail(VSTAB_ERR_INVALID, "vstab_gpmf_parse_gyro: " + sink.err);
     *n_out = sink.n;
