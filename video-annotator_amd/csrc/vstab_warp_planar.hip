@@ -142,9 +142,9 @@ __device__ __forceinline__ void scratch_to_global(const uint8_t *lds, uint8_t *d
 template <int RWB, int RW, int MODE, bool SPLIT, int DEPTH, int BLEND>
 __device__ __forceinline__ bool warp_tile_planar(const FusedArgs &ta, uint32_t *smem, const int x0, const int y0) {
     using P = Planar<DEPTH>;
-    constexpr int BPS = P::BPS, BW = P::BW, BWB = 16;  // block row: BW samples = 16 bytes
+    constexpr int BPS = P::BPS, BW = P::BW;  // a staging chunk: BW samples = 16 bytes
     constexpr int TH = 4 * RW;
-    constexpr int STAGE_MAX = 2;
+    constexpr int STAGE_MAX = 1 << 12;  // (the probe's bound on staging blocks per thread belongs to register staging: LDS-DMA takes any number of row groups)
     constexpr int CR = RW / 2;        // chroma rows of a wave
     constexpr int NS = (RW + 3) / 4;  // chroma pixels per thread: CR rows x 32 columns over 64 lanes (RW = 2: the even lanes only)
     constexpr int QB = QMAGIC_BITS;
