@@ -201,6 +201,28 @@ def cpu_baseline(w, h, K, Ko, cw, ch, budget_s=10.0, threads=None):
                       f"(cvtColor+createMap+remap, identity rotation), OpenMP over rows, {el:.1f} s"}
 
 
+def cpu_baseline_planar(frame, w, h, K, Ko, cw, ch, depth, blend=0, budget_s=10.0, threads=None):
+    """The plane-wise warp's CPU restatement (createMap -> remap of the luma plane -> remap of the chroma plane: oracle/vstab_oracle.c
+    vo_warp_planar_mapped), timed like cpu_baseline; frame = the NV12 frame (depth 8) or the stacked P010 planes as uint16 (depth 10)."""
+    import oracle
+    p = oracle.map_params(K, Ko, np.eye(3))
+    threads = box_cpu_share() if threads is None else threads
+    oracle.lib().vo_set_num_threads(threads)
+    run = (lambda: oracle.warp_nv12_planar(frame, p, cw, ch, 0)) if depth == 8 else (lambda: oracle.warp_p010_planar(frame[:h], frame[h:], p, cw, ch, 0, None, blend))
+    run()  # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        run()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 2000:
+            break
+    what = "NV12 -> NV12 planes" if depth == 8 else "P010 -> P010 planes, " + ("binary16" if blend else "exact") + " blend"
+    return {"value": round(n / el, 3), "unit": "frames/s", "cores": threads, "kind": "port", "share": share_txt() if threads > 1 else "1 thread",
+            "sample": f"{n} frames of {w}x{h} {what} {cw}x{ch}, plane-wise undistort-remap only (createMap + remap of the luma plane + remap of the "
+                      f"chroma plane, identity rotation), OpenMP over rows, {el:.1f} s"}
+
+
 def cpu_baseline_p010(frame16, w, h, K, Ko, cw, ch, budget_s=10.0):
     """The oracle's definition of the config-5 warp (10-bit conversion, per-row map, fp16 blend) on the host cores."""
     import oracle
@@ -836,7 +858,12 @@ def main():
             os.sched_setaffinity(0, cpu_mask)  # the CPU legs run on this GPU's share of the host, not on the few CPUs the handle's threads were kept on
         except OSError:
             pass
-        if world == 1 and not args.no_cpu_baseline and p010:
+        if world == 1 and not args.no_cpu_baseline and planar:  # the plane-wise outputs are priced against the plane-wise restatement
+            f0 = clip[0].cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline_planar(f0.view(np.uint16) if p010 else f0, w, h, K, Ko, cw, ch, 10 if p010 else 8, blend=1 if p010 else 0)
+            line["cpu_baseline_1_thread"] = cpu_baseline_planar(f0.view(np.uint16) if p010 else f0, w, h, K, Ko, cw, ch, 10 if p010 else 8, blend=1 if p010 else 0,
+                                                                budget_s=6.0, threads=1)
+        elif world == 1 and not args.no_cpu_baseline and p010:
             line["cpu_baseline"] = cpu_baseline_p010(clip[0].cpu().numpy().view(np.uint16), w, h, K, Ko, cw, ch)
         elif world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, h, K, Ko, cw, ch)
