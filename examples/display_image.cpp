@@ -95,11 +95,12 @@ class SyntheticSource : public vstab::NV12FrameSource {  // stands in for FrameS
     double delta_[9], readout_[9];
 };
 
-int run(vstab::FrameSourceWarp &warped, int n);
+int run(vstab::FrameSourceWarp &warped, int n, bool nv12_planes = false);
 
 int main(int argc, char **argv) {
     const int n = argc > 1 ? std::atoi(argv[1]) : 100;
     const bool gyro = argc > 2 && std::string(argv[2]) == "gyro";
+    const bool nv12 = argc > 2 && std::string(argv[2]) == "nv12";  // frames leave as NV12 planes, remapped plane-wise: what an encoder takes (render.ts:275-281)
     auto source = std::make_shared<SyntheticSource>(1920, 1440, n, gyro);
     if (gyro) {  // motion from the (synthetic) gyro stream instead of optical flow
         vstab::FrameSourceWarp warped(source, VSTAB_GOPRO_H4B_WIDE43_MEASURED, vstab::FrameSourceWarp::SensorMotion{}, 0.5, false, 1.0, 30);
@@ -107,19 +108,23 @@ int main(int argc, char **argv) {
     }
     // DisplayImage.cpp:55: FrameSourceWarp(ffmpeg_source, GOPRO_H4B_WIDE43_MEASURED, 0.5, false, 1.0, 30)
     vstab::FrameSourceWarp warped(source, VSTAB_GOPRO_H4B_WIDE43_MEASURED, 0.5, false, 1.0, 30);
-    return run(warped, n);
+    return run(warped, n, nv12);
 }
 
-int run(vstab::FrameSourceWarp &warped, int n) {
+int run(vstab::FrameSourceWarp &warped, int n, bool nv12_planes) {
     void *out = nullptr;
-    const size_t pitch = (size_t)warped.output_width() * 3;
-    if (hipMalloc(&out, pitch * warped.output_height()) != hipSuccess) return 1;
+    // BGR: width * 3 bytes per row; NV12: a luma plane of `width` bytes per row and, behind it, a chroma plane of 2 * ceil(width / 2)
+    const int ow = warped.output_width(), oh = warped.output_height();
+    const size_t pitch = nv12_planes ? (((size_t)ow + 1) & ~(size_t)1) : (size_t)ow * 3;
+    const size_t rows = nv12_planes ? (size_t)oh + ((size_t)oh + 1) / 2 : (size_t)oh;
+    if (hipMalloc(&out, pitch * rows) != hipSuccess) return 1;
     warped.set_output(out, pitch);
     int frames = 0;
     const auto t0 = std::chrono::steady_clock::now();
     while (true) {
         try {
-            warped.pull_frame();
+            if (nv12_planes) warped.pull_frame_nv12(out, pitch, static_cast<uint8_t *>(out) + pitch * oh, pitch, /*plane_wise=*/true);
+            else warped.pull_frame();
             frames++;
         } catch (int err) {
             if (err == EOF) break;

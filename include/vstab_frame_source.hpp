@@ -152,9 +152,12 @@ class FrameSourceWarp : public FrameSource {
         return BGRFrame{host_bgr, pitch, m_out_w, m_out_h};
     }
 
-    // the next frame as NV12 (planes provided by the caller: width bytes per luma row, 2*ceil(width/2) per chroma row)
-    NV12Out pull_frame_nv12(void *device_y, size_t pitch_y, void *device_uv, size_t pitch_uv) {
-        const vstab_status st = vstab_pull_frame_nv12(m_handle, device_y, pitch_y, device_uv, pitch_uv);
+    // the next frame as NV12 (planes provided by the caller: width bytes per luma row, 2*ceil(width/2) per chroma row).
+    // plane_wise = true: the luma and chroma planes remapped as they are (vstab_pull_frame_nv12_planar: no colour conversion at all -- the
+    // encoder hand-off of render.ts:606-607,664-665,688 and the fastest output); false: the NV12 conversion of the BGR frame
+    NV12Out pull_frame_nv12(void *device_y, size_t pitch_y, void *device_uv, size_t pitch_uv, bool plane_wise = false) {
+        const vstab_status st = plane_wise ? vstab_pull_frame_nv12_planar(m_handle, device_y, pitch_y, device_uv, pitch_uv)
+                                           : vstab_pull_frame_nv12(m_handle, device_y, pitch_y, device_uv, pitch_uv);
         if (st == VSTAB_EOF) throw (int)EOF;
         if (st == VSTAB_ERR_SOURCE && m_pending_error) throw m_pending_error;
         if (st != VSTAB_OK) {

@@ -705,6 +705,9 @@ def test_cpp_adapter_example_runs(vs, cuda):
     # the gyro path the reference stubs (gpmf.cpp:5-11): samples -> vstab_gyro_integrate -> delta / read-out rotations per frame
     r = subprocess.run([exe, "40", "gyro"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "39 frames of" in r.stderr, r.stderr
+    # frames handed on as NV12 planes, remapped plane-wise (FrameSourceWarp::pull_frame_nv12(..., plane_wise = true)): the encoder's input
+    r = subprocess.run([exe, "40", "nv12"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "39 frames of" in r.stderr, r.stderr
 
 
 def test_p010_input_equals_8bit_input_of_the_truncated_frames(vs, cuda, clip):
