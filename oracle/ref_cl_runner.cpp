@@ -12,8 +12,34 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <string>
 
 namespace {
+
+// The code object is loaded ONCE per process and path and never unloaded.  A hipModuleLoad / hipModuleUnload pair per call was what this
+// file did until round 5: on this ROCm a module loaded lazily LATER (the product's own fat binary, at its first kernel launch) can then be
+// copied to a device address the unloaded code object had occupied, which the GPU still maps read-only -- "Memory access fault ... Write
+// access to a read-only page" during that load, in one run out of three or four (24 load / unload cycles of the reference kernel, then the
+// first launch of any kernel of libvstab.so: no kernel of the library need have run before).
+hipError_t reference_kernel(const char *co_path, hipFunction_t *fn) {
+    static std::mutex m;
+    static std::string loaded_path;
+    static hipModule_t mod = nullptr;
+    static hipFunction_t cached = nullptr;
+    std::lock_guard<std::mutex> lk(m);
+    if (!cached || loaded_path != co_path) {
+        hipModule_t fresh = nullptr;  // (another path: a second module; the first one stays loaded)
+        hipError_t e = hipModuleLoad(&fresh, co_path);
+        if (e != hipSuccess) return e;
+        hipFunction_t f = nullptr;
+        e = hipModuleGetFunction(&f, fresh, "createMap");
+        if (e != hipSuccess) return e;
+        mod = fresh, cached = f, loaded_path = co_path;
+    }
+    *fn = cached;
+    return hipSuccess;
+}
 
 struct __attribute__((packed)) CreateMapArgs {
     void *map_x;
@@ -35,7 +61,6 @@ int fail(char *err, int errlen, const char *what, hipError_t e) {
     do {                                                      \
         hipError_t e_ = (expr);                               \
         if (e_ != hipSuccess) {                               \
-            if (mod) (void)hipModuleUnload(mod);              \
             if (dx) (void)hipFree(dx);                        \
             if (dy) (void)hipFree(dy);                        \
             return fail(err, errlen, #expr, e_);              \
@@ -47,15 +72,13 @@ int fail(char *err, int errlen, const char *what, hipError_t e) {
 extern "C" __attribute__((visibility("default"))) int refcl_create_map(const char *co_path, int cols, int rows, const float params[17],
                                                                        float *out_x, float *out_y, int block_x, int block_y, char *err,
                                                                        int errlen) {
-    hipModule_t mod = nullptr;
     void *dx = nullptr, *dy = nullptr;
     if (cols <= 0 || rows <= 0 || cols > 32767 || rows > 32767 || block_x <= 0 || block_y <= 0 || block_x * block_y > 1024) {
         if (err && errlen > 0) snprintf(err, (size_t)errlen, "bad size");
         return -1;
     }
-    RC_TRY(hipModuleLoad(&mod, co_path));
     hipFunction_t fn = nullptr;
-    RC_TRY(hipModuleGetFunction(&fn, mod, "createMap"));
+    RC_TRY(reference_kernel(co_path, &fn));
     const size_t bytes = (size_t)cols * rows * sizeof(float);
     RC_TRY(hipMalloc(&dx, bytes));
     RC_TRY(hipMalloc(&dy, bytes));
@@ -74,7 +97,6 @@ extern "C" __attribute__((visibility("default"))) int refcl_create_map(const cha
     RC_TRY(hipMemcpy(out_y, dy, bytes, hipMemcpyDeviceToHost));
     (void)hipFree(dx);
     (void)hipFree(dy);
-    (void)hipModuleUnload(mod);
     return 0;
 }
 
@@ -87,7 +109,6 @@ extern "C" __attribute__((visibility("default"))) int refcl_create_map(const cha
 extern "C" __attribute__((visibility("default"))) int refcl_create_map_rs(const char *co_path, int cols, int rows, const float params[17],
                                                                           const float rot_bottom[9], float *out_x, float *out_y, char *err,
                                                                           int errlen) {
-    hipModule_t mod = nullptr;
     void *dx = nullptr, *dy = nullptr;  // scratch planes of one launch
     void *rx = nullptr, *ry = nullptr;  // the assembled result
 #undef RC_TRY
@@ -95,7 +116,6 @@ extern "C" __attribute__((visibility("default"))) int refcl_create_map_rs(const 
     do {                                                      \
         hipError_t e_ = (expr);                               \
         if (e_ != hipSuccess) {                               \
-            if (mod) (void)hipModuleUnload(mod);              \
             for (void *p_ : {dx, dy, rx, ry})                 \
                 if (p_) (void)hipFree(p_);                    \
             return fail(err, errlen, #expr, e_);              \
@@ -105,9 +125,8 @@ extern "C" __attribute__((visibility("default"))) int refcl_create_map_rs(const 
         if (err && errlen > 0) snprintf(err, (size_t)errlen, "bad size");
         return -1;
     }
-    RC_TRY(hipModuleLoad(&mod, co_path));
     hipFunction_t fn = nullptr;
-    RC_TRY(hipModuleGetFunction(&fn, mod, "createMap"));
+    RC_TRY(reference_kernel(co_path, &fn));
     const size_t row_bytes = (size_t)cols * sizeof(float), bytes = row_bytes * rows;
     RC_TRY(hipMalloc(&dx, bytes));
     RC_TRY(hipMalloc(&dy, bytes));
@@ -136,6 +155,5 @@ extern "C" __attribute__((visibility("default"))) int refcl_create_map_rs(const 
     RC_TRY(hipMemcpy(out_x, rx, bytes, hipMemcpyDeviceToHost));
     RC_TRY(hipMemcpy(out_y, ry, bytes, hipMemcpyDeviceToHost));
     for (void *p_ : {dx, dy, rx, ry}) (void)hipFree(p_);
-    (void)hipModuleUnload(mod);
     return 0;
 }

@@ -257,6 +257,15 @@ def test_pipeline_pull_planar_matches_the_checker_frame_by_frame(vs, cuda):
     frames, _ = synth.shaky_clip(3, K, W, H, n, sigma=0.004)
     Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
     dev_frames = [torch.from_numpy(f).to(cuda) for f in frames]
+    # every frame copied into the library's ring (a decoder that recycles its surfaces; a callback source that promises nothing): the same planes out
+    for kw, src in (({"ring_hold": 0, "total": n}, dev_frames), ({"hold": 0}, iter(dev_frames))):
+        stab = vs.Stabilizer(src, smooth_radius=r, seed=5, **kw)
+        for i in range(n - 1):
+            yuv = stab.pull_nv12(planar=True)
+            p = oracle.map_params(K, Ko, stab.warp_rotation(i))
+            ey, euv = expect.warp_planar(frames[i + 1], p, cw, ch)
+            assert np.array_equal(yuv[0].cpu().numpy(), ey) and np.array_equal(yuv[1].cpu().numpy(), euv), (kw, i)
+        stab.close()
     stab = vs.Stabilizer(dev_frames, total=n, smooth_radius=r, seed=5)
     for i in range(n - 1):
         p = None
@@ -308,8 +317,8 @@ def test_pipeline_pull_p010_planar(vs, cuda):
     wide = [((f.astype(np.uint16) << 8) | (rng.integers(0, 4, f.shape, dtype=np.uint16) << 6) | rng.integers(0, 64, f.shape, dtype=np.uint16)) for f in frames8]
     dev_frames = [torch.from_numpy(x.view(np.int16)).to(cuda) for x in wide]
     Ko, (cw, ch) = oracle.get_output_camera(K, W, H)
-    for blend in (0, 1):
-        stab = vs.Stabilizer(dev_frames, total=n, bit_depth=10, smooth_radius=r, seed=5, pixel_depth=10, blend=blend)
+    for blend, kw in ((0, {}), (1, {}), (1, {"ring_hold": 0})):   # ring_hold 0: the 16-bit planes are copied into library memory on ingest
+        stab = vs.Stabilizer(dev_frames, total=n, bit_depth=10, smooth_radius=r, seed=5, pixel_depth=10, blend=blend, **kw)
         for i in range(n - 1):
             oy = torch.empty((ch, cw), dtype=torch.int16, device=cuda)
             ouv = torch.empty(((ch + 1) // 2, 2 * ((cw + 1) // 2)), dtype=torch.int16, device=cuda)
