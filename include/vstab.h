@@ -583,6 +583,12 @@ typedef struct vstab_profile {
     long epochs_in_turn; /* planned key frames whose detection and tracker launches ran on the second of the handle's two epoch streams, beside
                             the epoch still being tracked on the first (frames up to 1920 x 1200 with a caller on the default stream; 0 otherwise) */
 } vstab_profile;
+/* Loads the library's five GPU code objects now.  The HIP runtime loads a code object at the first launch of one of its kernels -- tens of
+ * milliseconds in the middle of the first frames -- and on ROCm 7.2 such a late load can FAULT ("write access to a read-only page") when the
+ * process has unloaded another module before it (hipModuleUnload; an OpenCL program released by a filter next door): the new code object may
+ * be placed where the old one was still mapped read-only.  vstab_create calls this itself; a host that uses the stateless operators
+ * (vstab_warp_nv12, vstab_pyr_lk, ...) without a handle, or wants the load at start-up, calls it once after selecting the device. */
+VSTAB_API vstab_status vstab_preload_kernels(void);
 /* level 0 = off, 1 = time every 8th warp launch only (event records are expensive host calls), 2 = every GPU stage */
 VSTAB_API vstab_status vstab_enable_profiling(vstab_handle *h, int level);
 /* Synchronises the stream, folds all pending event pairs into the sums and returns them. */

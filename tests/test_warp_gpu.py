@@ -216,3 +216,11 @@ def test_warp_properties_at_full_size_identity_shift_and_half_pixel(vs, cuda):
     yo, uvo = vs.warp_nv12(fd, oracle.map_params(K, K, np.eye(3)), w, h, vs.MAP_RECT_TO_RECT, vs.OUT_NV12)
     ey, euv = oracle.cvt_bgr_nv12(bgr.cpu().numpy())
     assert np.array_equal(yo.cpu().numpy(), ey) and np.array_equal(uvo.cpu().numpy().reshape(euv.shape), euv)
+
+
+@pytest.mark.gpu
+def test_preload_kernels_loads_the_code_objects_and_can_be_repeated(vs, cuda):
+    """vstab_preload_kernels: the library's five code objects loaded on request (vstab_create calls it): succeeds, and a
+    second call is a no-op."""
+    vs.preload_kernels()
+    vs.preload_kernels()

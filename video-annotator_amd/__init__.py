@@ -122,6 +122,7 @@ SIGNATURES = {
     "vstab_sg_weights": (_i, [_i, _dp]),
     "vstab_gyro_integrate": (_i, [_vp, _i, _d, _d, _d, _d, _dp, _dp]),
     "vstab_gpmf_parse_gyro": (_i, [_vp, _sz, _d, _d, _vp, _i, _ip]),
+    "vstab_preload_kernels": (_i, []),
     "vstab_rotation_filter_create": (_i, [_i, _pp]),
     "vstab_rotation_filter_add": (_i, [_vp, _dp]),
     "vstab_rotation_filter_filter": (_i, [_vp, _dp]),
@@ -564,6 +565,11 @@ def gyro_integrate(samples, rate_scale, t_prev_first_row, t_first_row, t_last_ro
     _check(_L.vstab_gyro_integrate(a.ctypes.data_as(_vp), a.shape[0], float(rate_scale), float(t_prev_first_row), float(t_first_row),
                                    float(t_last_row), Rd.ctypes.data_as(_dp), Rr.ctypes.data_as(_dp)), "vstab_gyro_integrate")
     return Rd.reshape(3, 3), Rr.reshape(3, 3)
+
+
+def preload_kernels():
+    """vstab_preload_kernels: load the library's GPU code objects now (vstab_create does it itself)."""
+    _check(_L.vstab_preload_kernels(), "vstab_preload_kernels")
 
 
 def gpmf_parse_gyro(payload, pkt_ts, pkt_dur, cap=None):

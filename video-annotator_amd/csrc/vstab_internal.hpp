@@ -33,6 +33,13 @@ struct LaunchEvents {
 };
 void set_launch_events(hipEvent_t start, hipEvent_t stop);
 LaunchEvents take_launch_events();
+
+// one per translation unit with kernels: loads that unit's code object now (vstab_preload_kernels)
+vstab_status preload_track_kernels();
+vstab_status preload_warp_kernels();
+vstab_status preload_fused_kernels();
+vstab_status preload_p010_kernels();
+vstab_status preload_planar_kernels();
 bool launch_events_pending();
 
 // vstab_pack_p010 with a choice of planes (vstab_warp.hip): luma_only narrows the luma plane alone -- what the 10-bit

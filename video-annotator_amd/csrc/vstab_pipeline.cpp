@@ -1509,6 +1509,15 @@ void vstab_config_default(vstab_config *cfg) {
     cfg->read_ahead = 0;  // the library's default (PREFETCH_DEPTH)
 }
 
+vstab_status vstab_preload_kernels(void) {
+    VSTAB_TRY(preload_track_kernels());
+    VSTAB_TRY(preload_warp_kernels());
+    VSTAB_TRY(preload_fused_kernels());
+    VSTAB_TRY(preload_p010_kernels());
+    VSTAB_TRY(preload_planar_kernels());
+    return VSTAB_OK;
+}
+
 vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vstab_handle **out) {
     if (!cfg || !src || !out || !src->pull || !src->peek) return fail(VSTAB_ERR_INVALID, "vstab_create: null argument");
     if (cfg->abi_version != VSTAB_ABI_VERSION)
@@ -1543,6 +1552,9 @@ vstab_status vstab_create(const vstab_config *cfg, const vstab_source *src, vsta
     {
         // the tracking chain is the per-frame critical path; the warp only has to finish before the
         // caller looks at dst, so the tracking stream gets the highest priority the device offers
+        // every code object of the library now, not at the first launch of one of its kernels in the middle of the frame loop (and not after
+        // whatever else the process has loaded and unloaded by then: vstab.h, vstab_preload_kernels)
+        VSTAB_TRY(vstab_preload_kernels());
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         VSTAB_HIP_TRY(hipStreamCreateWithPriority(&H->tstream, hipStreamNonBlocking, hi));

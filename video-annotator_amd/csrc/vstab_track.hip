@@ -1462,4 +1462,13 @@ vstab_status launch_lk(const LkSegArgs &a, hipStream_t s) {
     return VSTAB_OK;
 }
 
+
+// Kernels of this translation unit are one code object, loaded by the runtime at the first launch of any of them.  Touching one of them
+// here (vstab_preload_kernels) moves that load to a moment the caller chooses.
+vstab_status preload_track_kernels() {
+    hipFuncAttributes at;
+    VSTAB_HIP_TRY(hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_lk_track)));
+    return VSTAB_OK;
+}
+
 }  // namespace vstab

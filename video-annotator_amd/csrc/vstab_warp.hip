@@ -412,6 +412,15 @@ vstab_status pack_nv12_planes(const void *y, size_t pitch_y, const void *uv, siz
     VSTAB_HIP_TRY(hipGetLastError());
     return VSTAB_OK;
 }
+
+// Kernels of this translation unit are one code object, loaded by the runtime at the first launch of any of them.  Touching one of them
+// here (vstab_preload_kernels) moves that load to a moment the caller chooses.
+vstab_status preload_warp_kernels() {
+    hipFuncAttributes at;
+    VSTAB_HIP_TRY(hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_pack_nv12<uint32_t>)));
+    return VSTAB_OK;
+}
+
 }  // namespace vstab
 
 extern "C" {

@@ -622,4 +622,13 @@ vstab_status launch_warp_fused(const WarpArgs &a, const float params[17], int ma
     return VSTAB_OK;
 }
 
+
+// Kernels of this translation unit are one code object, loaded by the runtime at the first launch of any of them.  Touching one of them
+// here (vstab_preload_kernels) moves that load to a moment the caller chooses.
+vstab_status preload_fused_kernels() {
+    hipFuncAttributes at;
+    VSTAB_HIP_TRY(hipFuncGetAttributes(&at, reinterpret_cast<const void *>((&k_warp_fused<8, MAP_CREATEMAP_CL_OPENCL, 0, false, 8, 0>))));
+    return VSTAB_OK;
+}
+
 }  // namespace vstab

@@ -131,6 +131,15 @@ __global__ void __launch_bounds__(256) k_cvt_bgr10_p010(const uint8_t *__restric
     }
 }
 
+
+// Kernels of this translation unit are one code object, loaded by the runtime at the first launch of any of them.  Touching one of them
+// here (vstab_preload_kernels) moves that load to a moment the caller chooses.
+vstab_status preload_p010_kernels() {
+    hipFuncAttributes at;
+    VSTAB_HIP_TRY(hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_warp_p010<MAP_CREATEMAP_CL, VSTAB_BLEND_EXACT>)));
+    return VSTAB_OK;
+}
+
 }  // namespace vstab
 
 using namespace vstab;
