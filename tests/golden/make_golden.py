@@ -6,6 +6,9 @@ the createMap.cl build in oracle/_ref):  python tests/golden/make_golden.py
   oracle_kat.npz      known-answer vectors of the CPU restatement (oracle/), pinning it against
                       accidental change and giving the GPU tests a fixture that does not depend
                       on rebuilding the oracle.
+  planar_kat.npz      the same for the plane-wise NV12 -> NV12 / P010 -> P010 warp (round 5; the definition is this
+                      repository's: include/vstab.h VSTAB_OUT_NV12_PLANAR).  `python tests/golden/make_golden.py planar`
+                      writes this file alone.
 
 Fixtures are data only: inputs (seeds / parameters) and expected outputs.
 """
@@ -124,6 +127,31 @@ def make_oracle_kat():
     print("oracle_kat.npz", sum(v.nbytes for v in out.values()), "bytes raw")
 
 
+def make_planar_kat():
+    """Known answers of the PLANE-WISE warp's definition (oracle/vstab_oracle.c: vo_warp_planar_mapped; include/vstab.h, VSTAB_OUT_NV12_PLANAR):
+    a seeded 128x72 NV12 frame and its 10-bit twin (low six bits of every word junk), four rotations, both 10-bit blends."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from test_p010_cpu import p010_frame
+    out = {}
+    K, Ko, (cw, ch) = cameras(128, 72)
+    frame = synth.nv12(11, 128, 72)
+    y16, uv16, _, _ = p010_frame(11, 128, 72)
+    out["seed"] = np.array([11, 128, 72])
+    out["p010_y"], out["p010_uv"] = y16, uv16
+    for i, rv in enumerate(ROTS):
+        p = oracle.map_params(K, Ko, oracle.rodrigues(rv))
+        out[f"params_{i}"] = p
+        out[f"nv12_y_{i}"], out[f"nv12_uv_{i}"] = oracle.warp_nv12_planar(frame, p, cw, ch, 0)
+        for blend in (0, 1):
+            out[f"p010_y_{i}_{blend}"], out[f"p010_uv_{i}_{blend}"] = oracle.warp_p010_planar(y16, uv16, p, cw, ch, 0, None, blend)
+    np.savez_compressed(os.path.join(HERE, "planar_kat.npz"), **out)
+    print("planar_kat.npz", sum(v.nbytes for v in out.values()), "bytes raw")
+
+
 if __name__ == "__main__":
-    make_createmap_ref()
-    make_oracle_kat()
+    if len(sys.argv) > 1 and sys.argv[1] == "planar":   # (the other two files date from rounds 1 - 2 and are left as they are)
+        make_planar_kat()
+    else:
+        make_createmap_ref()
+        make_oracle_kat()
+        make_planar_kat()

@@ -173,3 +173,20 @@ def test_planar_agrees_with_the_bgr_round_trip_on_smooth_content():
     assert dy.max() <= 2 and dy.mean() < 0.2
     duv = np.abs(guv.reshape(ruv.shape).astype(int) - ruv.astype(int))[inside[0::2, 0::2]]
     assert duv.max() <= 2 and duv.mean() < 0.3
+
+
+def test_planar_oracle_matches_the_committed_golden_vectors():
+    """tests/golden/planar_kat.npz (tests/golden/make_golden.py planar): the definition's outputs for a seeded 128 x 72 frame, four rotations, 8-bit and
+    10-bit (both blends), pinned against accidental change of the oracle."""
+    import os
+    kat = np.load(os.path.join(os.path.dirname(__file__), "golden", "planar_kat.npz"))
+    seed, w, h = (int(v) for v in kat["seed"])
+    frame = synth.nv12(seed, w, h)
+    for i in range(4):
+        p = kat[f"params_{i}"]
+        ch, cw = kat[f"nv12_y_{i}"].shape
+        y, uv = oracle.warp_nv12_planar(frame, p, cw, ch, 0)
+        assert np.array_equal(y, kat[f"nv12_y_{i}"]) and np.array_equal(uv, kat[f"nv12_uv_{i}"]), i
+        for blend in (0, 1):
+            y, uv = oracle.warp_p010_planar(kat["p010_y"], kat["p010_uv"], p, cw, ch, 0, None, blend)
+            assert np.array_equal(y, kat[f"p010_y_{i}_{blend}"]) and np.array_equal(uv, kat[f"p010_uv_{i}_{blend}"]), (i, blend)

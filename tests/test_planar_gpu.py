@@ -329,3 +329,21 @@ def test_pipeline_pull_p010_planar(vs, cuda):
         with pytest.raises(vs.VstabError):
             stab.pull_nv12(planar=True)
         stab.close()
+
+
+def test_planar_against_the_committed_golden_vectors(vs, cuda):
+    """The HIP kernels against tests/golden/planar_kat.npz directly (a fixture that does not depend on rebuilding the oracle): 128 x 72, four rotations,
+    NV12 and P010 (exact and binary16 blend), CPU-reproducible map arithmetic."""
+    import os
+    import torch
+    kat = np.load(os.path.join(os.path.dirname(__file__), "golden", "planar_kat.npz"))
+    seed, w, h = (int(v) for v in kat["seed"])
+    frame = synth.nv12(seed, w, h)
+    for i in range(4):
+        p = kat[f"params_{i}"]
+        dh, dw = kat[f"nv12_y_{i}"].shape
+        gy, guv = run8(vs, cuda, frame, p, dw, dh, vs.MAP_CREATEMAP_CL)
+        assert np.array_equal(gy, kat[f"nv12_y_{i}"]) and np.array_equal(guv, kat[f"nv12_uv_{i}"]), i
+        for blend in (0, 1):
+            gy, guv = run10(vs, cuda, kat["p010_y"], kat["p010_uv"], p, dw, dh, vs.MAP_CREATEMAP_CL, blend)
+            assert np.array_equal(gy, kat[f"p010_y_{i}_{blend}"]) and np.array_equal(guv, kat[f"p010_uv_{i}_{blend}"]), (i, blend)
