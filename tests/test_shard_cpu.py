@@ -126,3 +126,22 @@ def test_launcher_rehearsal_with_eight_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     listing = open(os.path.join(root, "gpurun_out", "concat_list_8gpu_rehearsal.txt")).read().splitlines()
     assert listing == [f"file 'clip_{i:02d}_stabilised.mp4'" for i in range(8)]
+
+
+def test_bench_cpu_baseline_legs_of_the_plane_wise_outputs():
+    """bench.py's CPU-baseline leg for --out-format nv12-planar / p010-planar times the oracle's plane-wise restatement (createMap + remap of the two
+    planes), on a bounded sample: small frames here, a fraction of a second each."""
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import oracle
+    import synth
+    w, h = 320, 180
+    K = oracle.get_preset_camera(4, w, h)
+    Ko, (cw, ch) = oracle.get_output_camera(K, w, h)
+    f = synth.nv12(0, w, h)
+    for frame, depth, blend in ((f, 8, 0), (f.astype(np.uint16) << 8, 10, 1)):
+        leg = bench.cpu_baseline_planar(frame, w, h, K, Ko, cw, ch, depth, blend=blend, budget_s=0.2, threads=1)
+        assert leg["kind"] == "port" and leg["unit"] == "frames/s" and leg["cores"] == 1 and leg["value"] > 0
+        assert "plane-wise" in leg["sample"] and ("NV12" if depth == 8 else "P010") in leg["sample"]
