@@ -131,6 +131,7 @@ def test_launcher_rehearsal_with_eight_ranks():
 def test_bench_cpu_baseline_legs_of_the_plane_wise_outputs():
     """bench.py's CPU-baseline leg for --out-format nv12-planar / p010-planar times the oracle's plane-wise restatement (createMap + remap of the two
     planes), on a bounded sample: small frames here, a fraction of a second each."""
+    import sys
     import numpy as np
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
